@@ -1,0 +1,296 @@
+// Implicit-GEMM convolution kernels on the gfx950 f32 matrix cores
+// (v_mfma_f32_32x32x2_f32: exact fp32 fma chains, 157 TFLOP/s peak).
+//
+// Every Conv1d variant of the reference's backbones (hippie/backbones.py:13-16,24-33,
+// 50-62,78) and both halves of its backward are one of two kernels over a "tap map"
+// (include/hippie_hip.h): stride, zero padding, nearest-neighbour upsampling and the
+// transposed/flipped forms needed by the input gradient are all row-index arithmetic in
+// the A-operand gather, never materialised tensors.  Activations are channels-last
+// [B*L][C], so a GEMM row is one contiguous channel vector.
+#include "hp_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct TapMap {
+  int M, N, K, Lout, Lin, P, a, sh, even, ntaps;
+  int tap_o[HP_MAX_TAPS];
+  int tap_w[HP_MAX_TAPS];
+};
+
+static TapMap tapmap_from(const HpOp& op) {
+  TapMap t;
+  t.M = op.i[0]; t.N = op.i[1]; t.K = op.i[2]; t.Lout = op.i[3]; t.Lin = op.i[4];
+  t.P = op.i[5]; t.a = op.i[6]; t.sh = op.i[7]; t.even = op.i[8]; t.ntaps = op.i[9];
+  for (int j = 0; j < HP_MAX_TAPS; ++j) { t.tap_o[j] = op.i[10 + j]; t.tap_w[j] = op.i[16 + j]; }
+  return t;
+}
+
+// blockIdx -> tile id such that each XCD (blocks are dealt round-robin over the 8 XCDs)
+// owns one contiguous run of tile ids: the N-tiles that share an A row-panel then hit the
+// same L2.  Bijective for any nblk.  Speed only; correctness never depends on it.
+__device__ __forceinline__ int xcd_remap(int id, int nblk) {
+  const int xcd = id & 7, q = nblk >> 3, r = nblk & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
+// ------------------------------------------------------------------------------------
+// out[M][N] = sum_taps A[src(m,tap)][0:K] . Wslab[tap]   (+bias, +BN statistics)
+// 64x64 output tile per 256-thread workgroup, 2x2 waves of one 32x32 MFMA tile each,
+// K consumed 32 at a time through double-buffered LDS, global->register prefetch of the
+// next K-slice while the MFMAs of the current one run.
+// ------------------------------------------------------------------------------------
+struct ConvArgs {
+  const float* A; const float* W; float* out; const float* bias; double* stats;
+  TapMap t;
+};
+
+template <bool W_KN>
+__global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
+  constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
+  constexpr int LDBK = 68;   // [k][n] image row stride
+  constexpr int TILE = 64 * LDA;   // 2304 floats; the [32][68] image (2176) fits too
+  __shared__ __attribute__((aligned(16))) float smem[4 * TILE];
+
+  const TapMap& t = p.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int nt = (t.N + 63) >> 6, mt = (t.M + 63) >> 6;
+  const int tile = xcd_remap(blockIdx.x, mt * nt);
+  const int m0 = (tile / nt) << 6, n0 = (tile % nt) << 6;
+
+  // fixed per-thread load slots: rows ar, ar+32 of the A tile; 16-byte column aq
+  const int ar = tid >> 3, aq = (tid & 7) << 2;
+  int rbase[2], rl[2];
+  bool rvalid[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = m0 + ar + 32 * j;
+    rvalid[j] = m < t.M;
+    const int b = m / t.Lout;
+    rbase[j] = b * t.Lin;
+    rl[j] = t.a * (m - b * t.Lout);
+  }
+  const int kr = tid >> 4, nq = (tid & 15) << 2;   // [k][n] weight image slots
+
+  const int kper = (t.K + 31) >> 5;
+  const int nsteps = t.ntaps * kper;
+  const size_t wslab = (size_t)t.N * t.K;
+
+  float4 ra[2], rb[2];
+  auto load_regs = [&](int step) {
+    const int tap = step / kper;
+    const int c0 = (step - tap * kper) << 5;
+    const int to = t.tap_o[tap];
+    const float* wp = p.W + (size_t)t.tap_w[tap] * wslab;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pos = rl[j] + to;
+      const bool ok = rvalid[j] && pos >= 0 && pos < t.P && (!t.even || !(pos & 1)) && (c0 + aq < t.K);
+      ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) ra[j] = *reinterpret_cast<const float4*>(p.A + (size_t)(rbase[j] + (pos >> t.sh)) * t.K + c0 + aq);
+      rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!W_KN) {
+        const int n = n0 + ar + 32 * j;
+        if (n < t.N && c0 + aq < t.K) rb[j] = *reinterpret_cast<const float4*>(wp + (size_t)n * t.K + c0 + aq);
+      } else {
+        const int k = c0 + kr + 16 * j, n = n0 + nq;
+        if (k < t.K && n < t.N) rb[j] = *reinterpret_cast<const float4*>(wp + (size_t)k * t.N + n);
+      }
+    }
+  };
+  auto store_lds = [&](int buf) {
+    float* As = smem + buf * TILE;
+    float* Bs = smem + 2 * TILE + buf * TILE;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *reinterpret_cast<float4*>(As + (ar + 32 * j) * LDA + aq) = ra[j];
+      if (!W_KN) *reinterpret_cast<float4*>(Bs + (ar + 32 * j) * LDA + aq) = rb[j];
+      else       *reinterpret_cast<float4*>(Bs + (kr + 16 * j) * LDBK + nq) = rb[j];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) load_regs(s + 1);
+    const float* As = smem + buf * TILE + (wm * 32 + li) * LDA + lh * 4;
+    const float* Bs = smem + 2 * TILE + buf * TILE;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      // lane (i,h) takes k = 8kk+4h .. +3 of its row; MFMA jj pairs element jj of both
+      // operands, i.e. a K permutation applied identically to A and B.
+      const float4 a4 = *reinterpret_cast<const float4*>(As + kk * 8);
+      float4 b4;
+      if (!W_KN) {
+        b4 = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDA + kk * 8 + lh * 4);
+      } else {
+        const float* bk = Bs + (kk * 8 + lh * 4) * LDBK + wn * 32 + li;
+        b4 = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    if (s + 1 < nsteps) store_lds(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int n = n0 + wn * 32 + li;
+  const bool nok = n < t.N;
+  const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (nok && m < t.M) {
+      const float v = acc[r] + bv;
+      p.out[(size_t)m * t.N + n] = v;
+      s1 += (double)v;
+      s2 += (double)v * (double)v;
+    }
+  }
+  if (p.stats != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lh == 0 && nok) {
+      atomic_add_f64(p.stats + n, s1);
+      atomic_add_f64(p.stats + t.N + n, s2);
+    }
+  }
+}
+
+hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
+  ConvArgs a;
+  a.t = tapmap_from(op);
+  a.A = hp::ptr<const float>(op, 0, bases);
+  a.W = hp::ptr<const float>(op, 1, bases);
+  a.out = hp::ptr<float>(op, 2, bases);
+  a.bias = (op.flags & 2) ? hp::ptr<const float>(op, 3, bases) : nullptr;
+  a.stats = (op.flags & 4) ? hp::ptr<double>(op, 4, bases) : nullptr;
+  const int nblk = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64);
+  if (op.flags & 1) hipLaunchKernelGGL(conv_taps_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
+  else              hipLaunchKernelGGL(conv_taps_kernel<false>, dim3(nblk), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------
+// slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]
+// Contraction over rows: both MFMA operands are read K-major from LDS with ds_read_b32
+// (lane = output row / column, conflict-free).  One DY slice feeds all taps.
+// ------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* DY; const float* X; float* slab;
+  TapMap t;
+  int nsplit, rows_per_split, slab_stride;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
+  constexpr int T = 32 * 64;   // one [32 rows][64 cols] image
+  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * T];
+  const TapMap& t = p.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntc = (t.K + 63) >> 6;
+  const int n0 = (blockIdx.x / ntc) << 6, c0 = (blockIdx.x % ntc) << 6;
+  const int split = blockIdx.y;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(t.M, mbeg + p.rows_per_split);
+
+  const int lr = tid >> 4, cq = (tid & 15) << 2;
+  float4 rdy[2], rx[NT][2];
+  auto load_regs = [&](int mb) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = mb + lr + 16 * j;
+      const bool mv = m < mend;
+      rdy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (mv && n0 + cq < t.N) rdy[j] = *reinterpret_cast<const float4*>(p.DY + (size_t)m * t.N + n0 + cq);
+      const int b = m / t.Lout;
+      const int al = t.a * (m - b * t.Lout);
+#pragma unroll
+      for (int tau = 0; tau < NT; ++tau) {
+        const int pos = al + t.tap_o[tau];
+        const bool ok = mv && pos >= 0 && pos < t.P && (!t.even || !(pos & 1)) && (c0 + cq < t.K);
+        rx[tau][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok) rx[tau][j] = *reinterpret_cast<const float4*>(p.X + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
+      }
+    }
+  };
+  auto store_lds = [&]() {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      *reinterpret_cast<float4*>(smem + (lr + 16 * j) * 64 + cq) = rdy[j];
+#pragma unroll
+      for (int tau = 0; tau < NT; ++tau)
+        *reinterpret_cast<float4*>(smem + (1 + tau) * T + (lr + 16 * j) * 64 + cq) = rx[tau][j];
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int tau = 0; tau < NT; ++tau)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tau][r] = 0.f;
+
+  if (mbeg < mend) {
+    load_regs(mbeg);
+    store_lds();
+    __syncthreads();
+    for (int mb = mbeg; mb < mend; mb += 32) {
+      const bool more = mb + 32 < mend;
+      if (more) load_regs(mb + 32);
+      const float* dys = smem + lh * 64 + wn * 32 + li;
+      const float* xs = smem + T + lh * 64 + wc * 32 + li;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        const float a = dys[kk * 128];
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau)
+          acc[tau] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[tau * T + kk * 128], acc[tau], 0, 0, 0);
+      }
+      __syncthreads();
+      if (more) {
+        store_lds();
+        __syncthreads();
+      }
+    }
+  }
+
+  const int c = c0 + wc * 32 + li;
+  if (c < t.K) {
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+      float* dst = p.slab + (size_t)split * p.slab_stride + (size_t)t.tap_w[tau] * t.N * t.K;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < t.N) dst[(size_t)n * t.K + c] = acc[tau][r];
+      }
+    }
+  }
+}
+
+hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t s) {
+  WgradArgs a;
+  a.t = tapmap_from(op);
+  a.DY = hp::ptr<const float>(op, 0, bases);
+  a.X = hp::ptr<const float>(op, 1, bases);
+  a.slab = hp::ptr<float>(op, 2, bases);
+  a.nsplit = op.i[22];
+  a.rows_per_split = op.i[23];
+  a.slab_stride = op.i[24];
+  dim3 grid(hp::cdiv(a.t.N, 64) * hp::cdiv(a.t.K, 64), a.nsplit);
+  if (a.t.ntaps == 1)      hipLaunchKernelGGL(wgrad_taps_kernel<1>, grid, dim3(256), 0, s, a);
+  else if (a.t.ntaps == 3) hipLaunchKernelGGL(wgrad_taps_kernel<3>, grid, dim3(256), 0, s, a);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}

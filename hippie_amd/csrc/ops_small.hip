@@ -1,0 +1,736 @@
+// HBM/L2-bound and latency-bound ops of the cVAE step: BatchNorm apply / backward,
+// stem and tail convolutions (C_in = 1 / C_out = 1), pooling, the small Linear heads,
+// reparameterisation + KL, MSE, AdamW.  Semantics: include/hippie_hip.h.
+//
+// Shared thread mapping ("column-fixed"): a 256-thread block covers CW = min(C,256)
+// channels x RL = 256/CW row lanes; a thread keeps ONE channel for its whole life, so
+// per-channel coefficients live in registers and per-channel sums need one LDS fold and
+// one fp64 atomic per block.  Consecutive lanes touch consecutive channels (coalesced).
+#include "hp_common.h"
+
+namespace {
+
+constexpr int kRowsPerLane = 16;
+
+struct ColMap {
+  int c, row, rstep, rend;
+  int cw, rl, rlane;
+  bool active;
+};
+
+__device__ __forceinline__ ColMap colmap(int M, int C) {
+  ColMap m;
+  m.cw = C < 256 ? C : 256;
+  m.rl = 256 / m.cw;
+  const int tid = threadIdx.x;
+  m.rlane = tid / m.cw;
+  m.c = blockIdx.y * m.cw + (tid - m.rlane * m.cw);
+  const int rpb = m.rl * kRowsPerLane;
+  m.row = blockIdx.x * rpb + m.rlane;
+  m.rstep = m.rl;
+  m.rend = min(M, (int)(blockIdx.x + 1) * rpb);
+  m.active = (m.rlane < m.rl) && (m.c < C);
+  return m;
+}
+
+inline dim3 colgrid(int M, int C) {
+  const int cw = C < 256 ? C : 256;
+  const int rpb = (256 / cw) * kRowsPerLane;
+  return dim3(hp::cdiv(M, rpb), hp::cdiv(C, cw));
+}
+
+// fold per-thread partials over the row lanes of a block; returns the total in row lane 0
+template <int NV>
+__device__ __forceinline__ void fold_rowlanes(const ColMap& m, double (&v)[NV], double* lds /* [NV][256] */) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) lds[k * 256 + threadIdx.x] = m.active ? v[k] : 0.0;
+  __syncthreads();
+  if (m.active && m.rlane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double s = 0.0;
+      for (int r = 0; r < m.rl; ++r) s += lds[k * 256 + r * m.cw + (threadIdx.x)];
+      v[k] = s;
+    }
+  }
+}
+
+struct BnCoef { float mean, invstd, scale, shift; double var; };
+
+__device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* stats, int C, int c, const float* gamma,
+                                          const float* beta, const float* rmean, const float* rvar, float eps) {
+  BnCoef k;
+  double mean, var;
+  if (training) {
+    mean = stats[c] / (double)M;
+    var = stats[C + c] / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+  } else {
+    mean = (double)rmean[c];
+    var = (double)rvar[c];
+  }
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)gamma[c] * invstd;
+  k.mean = (float)mean; k.invstd = (float)invstd; k.var = var;
+  k.scale = (float)sc; k.shift = (float)((double)beta[c] - mean * sc);
+  return k;
+}
+
+// ---- BN apply --------------------------------------------------------------------
+struct BnApplyArgs {
+  const float* raw; float* out; const double* stats; const float* gamma; const float* beta;
+  float* rmean; float* rvar; float* save;
+  const float* res; const double* stats2; const float* gamma2; const float* beta2;
+  float* rmean2; float* rvar2; float* save2;
+  int M, C, res_mode, training, act;
+  float slope, eps, momentum;
+};
+
+__device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, int c, float* save, float* rmean,
+                                                float* rvar, float momentum) {
+  save[c] = k.mean;
+  save[C + c] = k.invstd;
+  const double unb = M > 1 ? k.var * (double)M / (double)(M - 1) : k.var;
+  rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * (double)k.mean);
+  rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
+  const ColMap m = colmap(p.M, p.C);
+  if (!m.active) return;
+  const BnCoef k = bn_coef(p.training, p.M, p.stats, p.C, m.c, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
+  BnCoef k2 = k;
+  if (p.res_mode == 2) k2 = bn_coef(p.training, p.M, p.stats2, p.C, m.c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
+  for (int r = m.row; r < m.rend; r += m.rstep) {
+    const size_t idx = (size_t)r * p.C + m.c;
+    float v = fmaf(p.raw[idx], k.scale, k.shift);
+    if (p.res_mode == 1) v += p.res[idx];
+    else if (p.res_mode == 2) v += fmaf(p.res[idx], k2.scale, k2.shift);
+    if (p.act) v = lrelu(v, p.slope);
+    p.out[idx] = v;
+  }
+  if (p.training && blockIdx.x == 0 && m.rlane == 0) {
+    bn_side_effects(k, p.M, p.C, m.c, p.save, p.rmean, p.rvar, p.momentum);
+    if (p.res_mode == 2) bn_side_effects(k2, p.M, p.C, m.c, p.save2, p.rmean2, p.rvar2, p.momentum);
+  }
+}
+
+// ---- BN backward -----------------------------------------------------------------
+struct BnBwdReduceArgs {
+  const float* g1; const float* g2; const float* act; float* gout;
+  const float* raw; const float* save; double* bs;
+  const float* raw2; const float* save2; double* bs2;
+  int M, C, has_second;
+  float slope;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdReduceArgs p) {
+  __shared__ double lds[4 * 256];
+  const ColMap m = colmap(p.M, p.C);
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (m.active) {
+    const float mean = p.save[m.c], invstd = p.save[p.C + m.c];
+    float mean2 = 0.f, invstd2 = 0.f;
+    if (p.has_second) { mean2 = p.save2[m.c]; invstd2 = p.save2[p.C + m.c]; }
+    for (int r = m.row; r < m.rend; r += m.rstep) {
+      const size_t idx = (size_t)r * p.C + m.c;
+      float g = p.g1[idx];
+      if (p.g2 != nullptr) g += p.g2[idx];
+      g *= lrelu_grad(p.act[idx], p.slope);
+      p.gout[idx] = g;
+      v[0] += (double)g;
+      v[1] += (double)g * (double)((p.raw[idx] - mean) * invstd);
+      if (p.has_second) v[3] += (double)g * (double)((p.raw2[idx] - mean2) * invstd2);
+    }
+    v[2] = v[0];
+  }
+  fold_rowlanes<4>(m, v, lds);
+  if (m.active && m.rlane == 0) {
+    atomic_add_f64(p.bs + m.c, v[0]);
+    atomic_add_f64(p.bs + p.C + m.c, v[1]);
+    if (p.has_second) {
+      atomic_add_f64(p.bs2 + m.c, v[2]);
+      atomic_add_f64(p.bs2 + p.C + m.c, v[3]);
+    }
+  }
+}
+
+struct BnBwdApplyArgs {
+  const float* g; const float* raw; const float* save; const double* bs; const float* gamma;
+  float* dr; float* dgamma; float* dbeta;
+  int M, C;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs p) {
+  const ColMap m = colmap(p.M, p.C);
+  if (!m.active) return;
+  const float mean = p.save[m.c], invstd = p.save[p.C + m.c];
+  const double sg = p.bs[m.c], sgx = p.bs[p.C + m.c];
+  const float c1 = (float)(sg / (double)p.M), c2 = (float)(sgx / (double)p.M);
+  const float sc = p.gamma[m.c] * invstd;
+  for (int r = m.row; r < m.rend; r += m.rstep) {
+    const size_t idx = (size_t)r * p.C + m.c;
+    const float xh = (p.raw[idx] - mean) * invstd;
+    p.dr[idx] = sc * (p.g[idx] - c1 - xh * c2);
+  }
+  if (blockIdx.x == 0 && m.rlane == 0) {
+    p.dgamma[m.c] = (float)sgx;
+    p.dbeta[m.c] = (float)sg;
+  }
+}
+
+// ---- stem conv (C_in = 1) --------------------------------------------------------
+struct StemArgs { const float* x; const float* w; float* out; double* stats; const float* dr; float* dw; int B, Lin, Lout, C; };
+
+__global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs p) {
+  __shared__ double lds[2 * 256];
+  const int M = p.B * p.Lout;
+  const ColMap m = colmap(M, p.C);
+  double v[2] = {0.0, 0.0};
+  if (m.active) {
+    const float w0 = p.w[m.c * 3 + 0], w1 = p.w[m.c * 3 + 1], w2 = p.w[m.c * 3 + 2];
+    for (int r = m.row; r < m.rend; r += m.rstep) {
+      const int b = r / p.Lout, l = r - b * p.Lout;
+      const float* xb = p.x + (size_t)b * p.Lin;
+      const int j = 2 * l - 1;
+      const float x0 = j >= 0 ? xb[j] : 0.f;
+      const float x1 = xb[j + 1];
+      const float x2 = (j + 2 < p.Lin) ? xb[j + 2] : 0.f;
+      const float o = fmaf(x2, w2, fmaf(x1, w1, x0 * w0));
+      p.out[(size_t)r * p.C + m.c] = o;
+      v[0] += (double)o;
+      v[1] += (double)o * (double)o;
+    }
+  }
+  fold_rowlanes<2>(m, v, lds);
+  if (p.stats != nullptr && m.active && m.rlane == 0) {
+    atomic_add_f64(p.stats + m.c, v[0]);
+    atomic_add_f64(p.stats + p.C + m.c, v[1]);
+  }
+}
+
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs p) {
+  __shared__ double lds[3 * 256];
+  const int M = p.B * p.Lout;
+  const ColMap m = colmap(M, p.C);
+  double v[3] = {0.0, 0.0, 0.0};
+  if (m.active) {
+    for (int r = m.row; r < m.rend; r += m.rstep) {
+      const int b = r / p.Lout, l = r - b * p.Lout;
+      const float* xb = p.x + (size_t)b * p.Lin;
+      const int j = 2 * l - 1;
+      const float d = p.dr[(size_t)r * p.C + m.c];
+      if (j >= 0) v[0] += (double)(d * xb[j]);
+      v[1] += (double)(d * xb[j + 1]);
+      if (j + 2 < p.Lin) v[2] += (double)(d * xb[j + 2]);
+    }
+  }
+  fold_rowlanes<3>(m, v, lds);
+  if (m.active && m.rlane == 0) {
+    atomic_add_f32(p.dw + m.c * 3 + 0, (float)v[0]);
+    atomic_add_f32(p.dw + m.c * 3 + 1, (float)v[1]);
+    atomic_add_f32(p.dw + m.c * 3 + 2, (float)v[2]);
+  }
+}
+
+// ---- pool / repeat ---------------------------------------------------------------
+__global__ void pool_fwd_kernel(const float* in, float* out, int B, int L, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  float s = 0.f;
+  for (int l = 0; l < L; ++l) s += in[((size_t)b * L + l) * C + c];
+  out[idx] = s / (float)L;
+}
+__global__ void pool_bwd_kernel(const float* d, float* g, int B, int L, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * L * C) return;
+  const int c = idx % C;
+  const int b = (idx / C) / L;
+  g[idx] = d[(size_t)b * C + c] / (float)L;
+}
+__global__ void repeat_fwd_kernel(const float* in, float* out, int B, int R, int C) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)B * R * C) return;
+  const int c = idx % C;
+  const int b = (idx / C) / R;
+  out[idx] = in[(size_t)b * C + c];
+}
+__global__ void repeat_bwd_kernel(const float* g1, const float* g2, float* d, int B, int R, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * C) return;
+  const int b = idx / C, c = idx - b * C;
+  float s = 0.f;
+  for (int l = 0; l < R; ++l) {
+    const size_t j = ((size_t)b * R + l) * C + c;
+    s += g1[j];
+    if (g2 != nullptr) s += g2[j];
+  }
+  d[idx] = s;
+}
+
+// ---- concat / embedding ----------------------------------------------------------
+struct ConcatArgs { float* out; const float* src[4]; const int64_t* idx[4]; int kind[4], w[4], ld[4]; int B, nseg, ldo; };
+__global__ void concat_kernel(ConcatArgs p) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= p.B * p.ldo) return;
+  const int b = id / p.ldo;
+  int col = id - b * p.ldo;
+  float v = 0.f;
+  for (int j = 0; j < p.nseg; ++j) {
+    if (col < p.w[j]) {
+      if (p.kind[j] == 0) v = p.src[j][(size_t)b * p.ld[j] + col];
+      else if (p.kind[j] == 1) v = p.src[j][(size_t)p.idx[j][b] * p.ld[j] + col];
+      break;
+    }
+    col -= p.w[j];
+  }
+  p.out[id] = v;
+}
+__global__ void emb_bwd_kernel(const float* d, const int64_t* idx, float* dt, int B, int w, int ld, int col0) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * w) return;
+  const int b = id / w, k = id - b * w;
+  atomic_add_f32(dt + (size_t)idx[b] * w + k, d[(size_t)b * ld + col0 + k]);
+}
+
+// ---- Linear ----------------------------------------------------------------------
+struct LinArgs {
+  const float* X; const float* W; const float* Bv; float* Y; double* stats;
+  const float* DY; float* DX; const float* ACT; float* DW; float* DB;
+  int M, N, K, ldx, ldy, act, has_mask, lda, accumulate;
+  float slope;
+};
+// one thread per output (small K)
+__global__ void linear_fwd_thread_kernel(LinArgs p) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= p.M * p.N) return;
+  const int m = id / p.N, n = id - m * p.N;
+  const float* x = p.X + (size_t)m * p.ldx;
+  const float* w = p.W + (size_t)n * p.K;
+  float s = 0.f;
+  for (int k = 0; k < p.K; ++k) s = fmaf(x[k], w[k], s);
+  if (p.Bv != nullptr) s += p.Bv[n];
+  if (p.stats != nullptr) {
+    atomic_add_f64(p.stats + n, (double)s);
+    atomic_add_f64(p.stats + p.N + n, (double)s * (double)s);
+  }
+  if (p.act) s = lrelu(s, p.slope);
+  p.Y[(size_t)m * p.ldy + n] = s;
+}
+// one wave per output (long K): coalesced reads of both operands
+__global__ __launch_bounds__(256) void linear_fwd_wave_kernel(LinArgs p) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wid >= p.M * p.N) return;
+  const int m = wid / p.N, n = wid - m * p.N;
+  const float* x = p.X + (size_t)m * p.ldx;
+  const float* w = p.W + (size_t)n * p.K;
+  float s = 0.f;
+  for (int k = lane; k < p.K; k += 64) s = fmaf(x[k], w[k], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (p.Bv != nullptr) s += p.Bv[n];
+    if (p.stats != nullptr) {
+      atomic_add_f64(p.stats + n, (double)s);
+      atomic_add_f64(p.stats + p.N + n, (double)s * (double)s);
+    }
+    if (p.act) s = lrelu(s, p.slope);
+    p.Y[(size_t)m * p.ldy + n] = s;
+  }
+}
+__global__ void linear_bwd_x_kernel(LinArgs p) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= p.M * p.K) return;
+  const int m = id / p.K, k = id - m * p.K;
+  const float* dy = p.DY + (size_t)m * p.ldy;
+  float s = 0.f;
+  for (int n = 0; n < p.N; ++n) s = fmaf(dy[n], p.W[(size_t)n * p.K + k], s);
+  if (p.has_mask) s *= lrelu_grad(p.ACT[(size_t)m * p.lda + k], p.slope);
+  float* dst = p.DX + (size_t)m * p.ldx + k;
+  *dst = p.accumulate ? *dst + s : s;
+}
+// block = (output row n, chunk of <=256 input columns, slice of M); fp32 atomics into zeroed DW/DB
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinArgs p, int rows_per_z) {
+  __shared__ double lds[2 * 256];
+  const int n = blockIdx.x;
+  const int kw = p.K < 256 ? p.K : 256;
+  const int ml = 256 / kw;
+  const int tid = threadIdx.x, mlane = tid / kw;
+  const int k = blockIdx.y * kw + (tid - mlane * kw);
+  const bool active = mlane < ml && k < p.K;
+  const int mbeg = blockIdx.z * rows_per_z, mend = min(p.M, mbeg + rows_per_z);
+  double v[2] = {0.0, 0.0};
+  if (active) {
+    for (int m = mbeg + mlane; m < mend; m += ml) {
+      const float d = p.DY[(size_t)m * p.ldy + n];
+      v[0] += (double)(d * p.X[(size_t)m * p.ldx + k]);
+      v[1] += (double)d;
+    }
+  }
+  lds[tid] = active ? v[0] : 0.0;
+  lds[256 + tid] = active ? v[1] : 0.0;
+  __syncthreads();
+  if (active && mlane == 0) {
+    double s = 0.0, sb = 0.0;
+    for (int r = 0; r < ml; ++r) { s += lds[r * kw + tid]; sb += lds[256 + r * kw + tid]; }
+    atomic_add_f32(p.DW + (size_t)n * p.K + k, (float)s);
+    if (p.DB != nullptr && k == 0) atomic_add_f32(p.DB + n, (float)sb);
+  }
+}
+
+// ---- reparameterisation / losses ---------------------------------------------------
+__device__ __forceinline__ void block_atomic_f64(double v, double* dst) {
+  __shared__ double red[4];
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += red[i];
+    atomic_add_f64(dst, s);
+  }
+}
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, const float* eps, float* z, double* loss, int B, int zd) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  double kl = 0.0;
+  if (id < B * zd) {
+    const int b = id / zd, j = id - b * zd;
+    const float mu = mulv[(size_t)b * 2 * zd + j], lv = mulv[(size_t)b * 2 * zd + zd + j];
+    z[id] = fmaf(eps[id], expf(0.5f * lv), mu);
+    kl = -0.5 * (double)(1.f + lv - mu * mu - expf(lv));
+  }
+  block_atomic_f64(kl, loss + 0);
+}
+__global__ void reparam_kl_bwd_kernel(const float* mulv, const float* eps, const float* dz, float* dmulv, int B, int zd, int lddz, float beta) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= B * zd) return;
+  const int b = id / zd, j = id - b * zd;
+  const float mu = mulv[(size_t)b * 2 * zd + j], lv = mulv[(size_t)b * 2 * zd + zd + j];
+  const float g = dz[(size_t)b * lddz + j];
+  const float invB = 1.f / (float)B;
+  dmulv[(size_t)b * 2 * zd + j] = g + beta * mu * invB;
+  dmulv[(size_t)b * 2 * zd + zd + j] = g * eps[id] * 0.5f * expf(0.5f * lv) + beta * 0.5f * (expf(lv) - 1.f) * invB;
+}
+__global__ __launch_bounds__(256) void mse_kernel(const float* x, const float* rec, float* drec, double* loss, int n, int slot, float w) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  double sq = 0.0;
+  if (id < n) {
+    const float d = rec[id] - x[id];
+    sq = (double)d * (double)d;
+    drec[id] = w * 2.f * d / (float)n;
+  }
+  block_atomic_f64(sq, loss + slot);
+}
+__global__ void loss_finalize_kernel(const double* loss, float* out, int B, int n1, int n2, float beta, float w1, float w2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double kl = loss[0] / (double)B;
+  const double m1 = loss[1] / (double)n1;
+  const double m2 = n2 > 0 ? loss[2] / (double)n2 : 0.0;
+  out[0] = (float)((double)w1 * m1 + (double)w2 * m2 + (double)beta * kl);
+  out[1] = (float)m1;
+  out[2] = (float)m2;
+  out[3] = (float)kl;
+}
+
+// ---- decoder tail (C_out = 1) -----------------------------------------------------
+__global__ void tail_fwd_kernel(const float* act, const float* w, const float* bias, float* out, int B, int Lh, int C) {
+  const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  const int Lo = 2 * Lh;
+  if (wid >= B * Lo) return;
+  const int b = wid / Lo, pz = wid - b * Lo;
+  float s = 0.f;
+  for (int t = 0; t < 3; ++t) {
+    const int u = pz + t - 1;
+    if (u < 0 || u >= Lo) continue;
+    const float* row = act + ((size_t)b * Lh + (u >> 1)) * C;
+    for (int c = lane; c < C; c += 64) s = fmaf(row[c], w[c * 3 + t], s);
+  }
+  s = wave_sum(s);
+  if (lane == 0) out[wid] = s + bias[0];
+}
+__global__ void tail_bwd_x_kernel(const float* dt, const float* w, float* dact, int B, int Lh, int C) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= (size_t)B * Lh * C) return;
+  const int c = id % C;
+  const int j = (id / C) % Lh;
+  const int b = (id / C) / Lh;
+  const int Lo = 2 * Lh;
+  const float* d = dt + (size_t)b * Lo;
+  float s = 0.f;
+  for (int e = 0; e < 2; ++e)
+    for (int t = 0; t < 3; ++t) {
+      const int q = 2 * j + e - t + 1;
+      if (q >= 0 && q < Lo) s = fmaf(d[q], w[c * 3 + t], s);
+    }
+  dact[id] = s;
+}
+// grid.x over batch slices; thread = (channel c, tap t); fp32 atomics into zeroed DW/DB
+__global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int bper) {
+  const int tid = threadIdx.x;
+  const int Lo = 2 * Lh;
+  const int b0 = blockIdx.x * bper, b1 = min(B, b0 + bper);
+  for (int ct = tid; ct < C * 3; ct += 256) {
+    const int c = ct / 3, t = ct - c * 3;
+    double s = 0.0;
+    for (int b = b0; b < b1; ++b)
+      for (int pz = 0; pz < Lo; ++pz) {
+        const int u = pz + t - 1;
+        if (u < 0 || u >= Lo) continue;
+        s += (double)(dt[(size_t)b * Lo + pz] * act[((size_t)b * Lh + (u >> 1)) * C + c]);
+      }
+    atomic_add_f32(dw + ct, (float)s);
+  }
+  if (tid == 0) {
+    double s = 0.0;
+    for (int b = b0; b < b1; ++b)
+      for (int pz = 0; pz < Lo; ++pz) s += (double)dt[(size_t)b * Lo + pz];
+    atomic_add_f32(db, (float)s);
+  }
+}
+
+// ---- slab reduce / optimiser ------------------------------------------------------
+__global__ void slab_reduce_kernel(const float* slab, float* out, int n, int nsplit, int stride) {
+  const int nv = n >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+    float4 s = *reinterpret_cast<const float4*>(slab + (size_t)i * 4);
+    for (int k = 1; k < nsplit; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(slab + (size_t)k * stride + (size_t)i * 4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + (size_t)i * 4) = s;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int i = (nv << 2) + threadIdx.x;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab[(size_t)k * stride + i];
+    out[i] = s;
+  }
+}
+__global__ __launch_bounds__(256) void gradnorm_kernel(const float* g, double* norm2, int n) {
+  double s = 0.0;
+  const int nv = n >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+    const float4 v = *reinterpret_cast<const float4*>(g + (size_t)i * 4);
+    s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(nv << 2) + threadIdx.x]; s += (double)v * v; }
+  block_atomic_f64(s, norm2);
+}
+
+struct AdamArgs { float* p; const float* g; float* m; float* v; const int64_t* step; const double* norm2; int n; float lr, b1, b2, eps, wd, clip; };
+__device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float coef, float step_size, float bc2s) {
+  g *= coef;
+  p *= (1.f - a.lr * a.wd);
+  m = m + (1.f - a.b1) * (g - m);          // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.b2 + (1.f - a.b2) * g * g;
+  const float denom = sqrtf(v) / bc2s + a.eps;
+  p = p - step_size * (m / denom);
+}
+__global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+  const double t = (double)a.step[0];
+  const double bc1 = 1.0 - pow((double)a.b1, t), bc2 = 1.0 - pow((double)a.b2, t);
+  const float step_size = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
+  float coef = 1.f;
+  if (a.clip > 0.f) {
+    const float c = a.clip / ((float)sqrt(a.norm2[0]) + 1e-6f);
+    coef = c < 1.f ? c : 1.f;
+  }
+  const int nv = a.n >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+    float4 p = reinterpret_cast<float4*>(a.p)[i];
+    const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+    float4 m = reinterpret_cast<float4*>(a.m)[i];
+    float4 v = reinterpret_cast<float4*>(a.v)[i];
+    adam1(p.x, g.x, m.x, v.x, a, coef, step_size, bc2s);
+    adam1(p.y, g.y, m.y, v.y, a, coef, step_size, bc2s);
+    adam1(p.z, g.z, m.z, v.z, a, coef, step_size, bc2s);
+    adam1(p.w, g.w, m.w, v.w, a, coef, step_size, bc2s);
+    reinterpret_cast<float4*>(a.p)[i] = p;
+    reinterpret_cast<float4*>(a.m)[i] = m;
+    reinterpret_cast<float4*>(a.v)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    const int i = (nv << 2) + threadIdx.x;
+    adam1(a.p[i], a.g[i], a.m[i], a.v[i], a, coef, step_size, bc2s);
+  }
+}
+__global__ void step_inc_kernel(int64_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
+
+inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / per); }
+
+}  // namespace
+
+hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
+  using hp::ptr;
+  const int32_t* I = op.i;
+  switch (op.op) {
+    case HP_OP_SLAB_REDUCE: {
+      const int n = I[0];
+      hipLaunchKernelGGL(slab_reduce_kernel, dim3(min(2048, max(1, blocks_for(n >> 2)))), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), n, I[1], I[2]);
+      break;
+    }
+    case HP_OP_BN_APPLY: {
+      BnApplyArgs a;
+      a.raw = ptr<const float>(op, 0, bases); a.out = ptr<float>(op, 1, bases); a.stats = ptr<const double>(op, 2, bases);
+      a.gamma = ptr<const float>(op, 3, bases); a.beta = ptr<const float>(op, 4, bases);
+      a.rmean = ptr<float>(op, 5, bases); a.rvar = ptr<float>(op, 6, bases); a.save = ptr<float>(op, 7, bases);
+      a.res = ptr<const float>(op, 8, bases); a.stats2 = ptr<const double>(op, 9, bases);
+      a.gamma2 = ptr<const float>(op, 10, bases); a.beta2 = ptr<const float>(op, 11, bases);
+      a.rmean2 = ptr<float>(op, 12, bases); a.rvar2 = ptr<float>(op, 13, bases); a.save2 = ptr<float>(op, 14, bases);
+      a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
+      a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
+      hipLaunchKernelGGL(bn_apply_kernel, colgrid(a.M, a.C), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_BN_BWD_REDUCE: {
+      BnBwdReduceArgs a;
+      a.g1 = ptr<const float>(op, 0, bases); a.g2 = I[2] ? ptr<const float>(op, 1, bases) : nullptr;
+      a.act = ptr<const float>(op, 2, bases); a.gout = ptr<float>(op, 3, bases);
+      a.raw = ptr<const float>(op, 4, bases); a.save = ptr<const float>(op, 5, bases); a.bs = ptr<double>(op, 6, bases);
+      a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
+      a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
+      hipLaunchKernelGGL(bn_bwd_reduce_kernel, colgrid(a.M, a.C), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_BN_BWD_APPLY: {
+      BnBwdApplyArgs a;
+      a.g = ptr<const float>(op, 0, bases); a.raw = ptr<const float>(op, 1, bases); a.save = ptr<const float>(op, 2, bases);
+      a.bs = ptr<const double>(op, 3, bases); a.gamma = ptr<const float>(op, 4, bases); a.dr = ptr<float>(op, 5, bases);
+      a.dgamma = ptr<float>(op, 6, bases); a.dbeta = ptr<float>(op, 7, bases);
+      a.M = I[0]; a.C = I[1];
+      hipLaunchKernelGGL(bn_bwd_apply_kernel, colgrid(a.M, a.C), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_STEM_FWD: {
+      StemArgs a{};
+      a.x = ptr<const float>(op, 0, bases); a.w = ptr<const float>(op, 1, bases); a.out = ptr<float>(op, 2, bases);
+      a.stats = ptr<double>(op, 3, bases); a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3];
+      hipLaunchKernelGGL(stem_fwd_kernel, colgrid(a.B * a.Lout, a.C), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_STEM_WGRAD: {
+      StemArgs a{};
+      a.dr = ptr<const float>(op, 0, bases); a.x = ptr<const float>(op, 1, bases); a.dw = ptr<float>(op, 2, bases);
+      a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3];
+      hipLaunchKernelGGL(stem_wgrad_kernel, colgrid(a.B * a.Lout, a.C), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_POOL_FWD:
+      hipLaunchKernelGGL(pool_fwd_kernel, dim3(blocks_for((int64_t)I[0] * I[2])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2]);
+      break;
+    case HP_OP_POOL_BWD:
+      hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1] * I[2])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2]);
+      break;
+    case HP_OP_REPEAT_FWD:
+      hipLaunchKernelGGL(repeat_fwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1] * I[2])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2]);
+      break;
+    case HP_OP_REPEAT_BWD:
+      hipLaunchKernelGGL(repeat_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[2])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), I[3] ? ptr<const float>(op, 1, bases) : nullptr,
+                         ptr<float>(op, 2, bases), I[0], I[1], I[2]);
+      break;
+    case HP_OP_CONCAT: {
+      ConcatArgs a{};
+      a.out = ptr<float>(op, 0, bases); a.B = I[0]; a.nseg = I[1]; a.ldo = I[2];
+      for (int j = 0; j < 4; ++j) {
+        a.kind[j] = I[4 + 3 * j]; a.w[j] = I[5 + 3 * j]; a.ld[j] = I[6 + 3 * j];
+        a.src[j] = ptr<const float>(op, 1 + 2 * j, bases); a.idx[j] = ptr<const int64_t>(op, 2 + 2 * j, bases);
+      }
+      hipLaunchKernelGGL(concat_kernel, dim3(blocks_for((int64_t)a.B * a.ldo)), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_EMB_BWD:
+      hipLaunchKernelGGL(emb_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases),
+                         I[0], I[1], I[2], I[3]);
+      break;
+    case HP_OP_LINEAR_FWD: {
+      LinArgs a{};
+      a.X = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.Bv = ptr<const float>(op, 2, bases);
+      a.Y = ptr<float>(op, 3, bases); a.stats = I[6] ? ptr<double>(op, 4, bases) : nullptr;
+      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldx = I[3]; a.ldy = I[4]; a.act = I[5]; a.slope = op.f[0];
+      if (a.K >= 128) hipLaunchKernelGGL(linear_fwd_wave_kernel, dim3(blocks_for((int64_t)a.M * a.N, 4)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(linear_fwd_thread_kernel, dim3(blocks_for((int64_t)a.M * a.N)), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_LINEAR_BWD_X: {
+      LinArgs a{};
+      a.DY = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.DX = ptr<float>(op, 2, bases);
+      a.ACT = ptr<const float>(op, 3, bases);
+      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4]; a.has_mask = I[5]; a.lda = I[6]; a.accumulate = I[7];
+      a.slope = op.f[0];
+      hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(blocks_for((int64_t)a.M * a.K)), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_LINEAR_BWD_W: {
+      LinArgs a{};
+      a.DY = ptr<const float>(op, 0, bases); a.X = ptr<const float>(op, 1, bases); a.DW = ptr<float>(op, 2, bases);
+      a.DB = ptr<float>(op, 3, bases);
+      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
+      const int kw = a.K < 256 ? a.K : 256;
+      const int rows_per_z = 1024;
+      dim3 grid(a.N, hp::cdiv(a.K, kw), hp::cdiv(a.M, rows_per_z));
+      hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(256), 0, s, a, rows_per_z);
+      break;
+    }
+    case HP_OP_REPARAM_KL_FWD:
+      hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases),
+                         ptr<double>(op, 3, bases), I[0], I[1]);
+      break;
+    case HP_OP_REPARAM_KL_BWD:
+      hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<const float>(op, 2, bases),
+                         ptr<float>(op, 3, bases), I[0], I[1], I[2], op.f[0]);
+      break;
+    case HP_OP_MSE_FWD_BWD:
+      hipLaunchKernelGGL(mse_kernel, dim3(blocks_for(I[0])), dim3(256), 0, s, ptr<const float>(op, 0, bases),
+                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<double>(op, 3, bases), I[0], I[1], op.f[0]);
+      break;
+    case HP_OP_TAIL_FWD:
+      hipLaunchKernelGGL(tail_fwd_kernel, dim3(blocks_for((int64_t)I[0] * 2 * I[1], 4)), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<const float>(op, 2, bases),
+                         ptr<float>(op, 3, bases), I[0], I[1], I[2]);
+      break;
+    case HP_OP_TAIL_BWD_X:
+      hipLaunchKernelGGL(tail_bwd_x_kernel, dim3(blocks_for((int64_t)I[0] * I[1] * I[2])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2]);
+      break;
+    case HP_OP_TAIL_BWD_W: {
+      const int bper = 8;
+      hipLaunchKernelGGL(tail_bwd_w_kernel, dim3(hp::cdiv(I[0], bper)), dim3(256), 0, s, ptr<const float>(op, 0, bases),
+                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], bper);
+      break;
+    }
+    case HP_OP_LOSS_FINALIZE:
+      hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, ptr<const double>(op, 0, bases),
+                         ptr<float>(op, 1, bases), I[0], I[1], I[2], op.f[0], op.f[1], op.f[2]);
+      break;
+    case HP_OP_GRADNORM:
+      hipLaunchKernelGGL(gradnorm_kernel, dim3(min(1024, max(1, blocks_for(I[0] >> 2)))), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<double>(op, 1, bases), I[0]);
+      break;
+    case HP_OP_ADAMW: {
+      AdamArgs a;
+      a.p = ptr<float>(op, 0, bases); a.g = ptr<const float>(op, 1, bases); a.m = ptr<float>(op, 2, bases);
+      a.v = ptr<float>(op, 3, bases); a.step = ptr<const int64_t>(op, 4, bases); a.norm2 = ptr<const double>(op, 5, bases);
+      a.n = I[0]; a.lr = op.f[0]; a.b1 = op.f[1]; a.b2 = op.f[2]; a.eps = op.f[3]; a.wd = op.f[4]; a.clip = op.f[5];
+      hipLaunchKernelGGL(adamw_kernel, dim3(min(2048, max(1, blocks_for(a.n >> 2)))), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_STEP_INC:
+      hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, ptr<int64_t>(op, 0, bases));
+      break;
+    case HP_OP_ZERO:
+      return hipMemsetAsync(ptr<void>(op, 0, bases), 0, (size_t)(uint32_t)I[0] + ((size_t)(uint32_t)I[1] << 32), s);
+    default:
+      return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}

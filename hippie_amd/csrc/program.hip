@@ -1,0 +1,203 @@
+// Program executor and C ABI of libhippie_hip.so (see include/hippie_hip.h).
+#include "hp_common.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+struct HpProgram {
+  std::vector<HpOp> ops;
+  void* bases[HP_NUM_SPACES];
+  int64_t sizes[HP_NUM_SPACES];
+  std::vector<hipGraphExec_t> segs;
+  std::vector<hipGraph_t> graphs;
+  hipStream_t capture_stream = nullptr;
+};
+
+namespace {
+thread_local std::string g_err;
+
+int fail(const std::string& msg) {
+  g_err = msg;
+  return 1;
+}
+int fail_hip(const char* what, hipError_t e) {
+  g_err = std::string(what) + ": " + hipGetErrorString(e);
+  return 1;
+}
+
+hipError_t dispatch(const HpOp& op, void* const* bases, hipStream_t s) {
+  switch (op.op) {
+    case HP_OP_CONV_TAPS: return hp::launch_conv_taps(op, bases, s);
+    case HP_OP_WGRAD_TAPS: return hp::launch_wgrad_taps(op, bases, s);
+    default: return hp::launch_small(op, bases, s);
+  }
+}
+
+// number of buffer slots each op may reference (for validation)
+int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& why) {
+  char buf[256];
+  if (op.op <= 0 || op.op >= HP_OP__COUNT) {
+    snprintf(buf, sizeof buf, "op %d: unknown opcode %d", index, op.op);
+    why = buf;
+    return 1;
+  }
+  for (int k = 0; k < HP_OP_NB; ++k) {
+    const int64_t r = op.buf[k];
+    if (r == HP_NULL) continue;
+    const int sp = hp::space_of(r);
+    const int64_t off = hp::offset_of(r);
+    if (sp < 0 || sp >= HP_NUM_SPACES || off < 0 || off >= sizes[sp] || (off & 3)) {
+      snprintf(buf, sizeof buf, "op %d (opcode %d): buffer slot %d out of range (space %d offset %lld size %lld)", index,
+               op.op, k, sp, (long long)off, (long long)(sp >= 0 && sp < HP_NUM_SPACES ? sizes[sp] : -1));
+      why = buf;
+      return 1;
+    }
+  }
+  if (op.op == HP_OP_CONV_TAPS || op.op == HP_OP_WGRAD_TAPS) {
+    const int M = op.i[0], N = op.i[1], K = op.i[2], nt = op.i[9];
+    bool ok = M > 0 && N > 0 && K > 0 && (K % 4) == 0 && (N % 4) == 0 && op.i[3] > 0 && op.i[4] > 0 && nt >= 1 &&
+              nt <= HP_MAX_TAPS && op.i[6] >= 1 && op.i[7] >= 0 && op.i[7] <= 1;
+    if (op.op == HP_OP_WGRAD_TAPS)
+      ok = ok && (nt == 1 || nt == 3) && op.i[22] >= 1 && op.i[23] > 0 && (op.i[23] % 32) == 0 &&
+           (int64_t)op.i[22] * op.i[23] >= M;
+    if (!ok) {
+      snprintf(buf, sizeof buf, "op %d (opcode %d): bad tap-map shape M=%d N=%d K=%d ntaps=%d", index, op.op, M, N, K, nt);
+      why = buf;
+      return 1;
+    }
+  }
+  if ((op.op == HP_OP_BN_APPLY || op.op == HP_OP_BN_BWD_REDUCE || op.op == HP_OP_BN_BWD_APPLY) &&
+      (op.i[0] <= 0 || op.i[1] <= 0)) {
+    snprintf(buf, sizeof buf, "op %d (opcode %d): bad M/C", index, op.op);
+    why = buf;
+    return 1;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int hp_abi_version(void) { return HP_ABI_VERSION; }
+const char* hp_last_error(void) { return g_err.c_str(); }
+
+int hp_device_info(int* n_cu, int* wave_size, char* arch, int arch_len) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return fail_hip("hipGetDevice", e);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return fail_hip("hipGetDeviceProperties", e);
+  if (n_cu) *n_cu = prop.multiProcessorCount;
+  if (wave_size) *wave_size = prop.warpSize;
+  if (arch && arch_len > 0) {
+    strncpy(arch, prop.gcnArchName, arch_len - 1);
+    arch[arch_len - 1] = 0;
+  }
+  return 0;
+}
+
+int hp_program_create(const HpOp* ops, int n_ops, void* const bases[HP_NUM_SPACES], const int64_t sizes[HP_NUM_SPACES],
+                      HpProgram** out) {
+  if (!ops || n_ops <= 0 || !bases || !sizes || !out) return fail("hp_program_create: null argument");
+  HpProgram* p = new HpProgram();
+  p->ops.assign(ops, ops + n_ops);
+  for (int k = 0; k < HP_NUM_SPACES; ++k) { p->bases[k] = bases[k]; p->sizes[k] = sizes[k]; }
+  if (hp_program_validate(p) != 0) { delete p; return 1; }
+  *out = p;
+  return 0;
+}
+
+int hp_program_destroy(HpProgram* p) {
+  if (!p) return 0;
+  for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
+  for (auto g : p->graphs) if (g) hipGraphDestroy(g);
+  if (p->capture_stream) hipStreamDestroy(p->capture_stream);
+  delete p;
+  return 0;
+}
+
+int hp_program_validate(const HpProgram* p) {
+  if (!p) return fail("hp_program_validate: null program");
+  std::string why;
+  for (size_t k = 0; k < p->ops.size(); ++k)
+    if (validate_op(p->ops[k], p->sizes, (int)k, why)) return fail(why);
+  return 0;
+}
+
+int hp_program_run(HpProgram* p, int first, int count, void* stream) {
+  if (!p) return fail("hp_program_run: null program");
+  if (first < 0 || count < 0 || first + count > (int)p->ops.size()) return fail("hp_program_run: range out of bounds");
+  hipStream_t s = (hipStream_t)stream;
+  for (int k = first; k < first + count; ++k) {
+    hipError_t e = dispatch(p->ops[k], p->bases, s);
+    if (e != hipSuccess) {
+      char buf[96];
+      snprintf(buf, sizeof buf, "launch of op %d (opcode %d)", k, p->ops[k].op);
+      return fail_hip(buf, e);
+    }
+  }
+  return 0;
+}
+
+int hp_program_capture(HpProgram* p, int first, int count, int* seg) {
+  if (!p || !seg) return fail("hp_program_capture: null argument");
+  if (first < 0 || count <= 0 || first + count > (int)p->ops.size()) return fail("hp_program_capture: range out of bounds");
+  hipError_t e;
+  if (!p->capture_stream) {
+    e = hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail_hip("hipStreamCreate", e);
+  }
+  e = hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) return fail_hip("hipStreamBeginCapture", e);
+  int rc = hp_program_run(p, first, count, p->capture_stream);
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(p->capture_stream, &graph);
+  if (rc != 0) { if (graph) hipGraphDestroy(graph); return 1; }
+  if (e != hipSuccess) return fail_hip("hipStreamEndCapture", e);
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) { hipGraphDestroy(graph); return fail_hip("hipGraphInstantiate", e); }
+  p->graphs.push_back(graph);
+  p->segs.push_back(exec);
+  *seg = (int)p->segs.size() - 1;
+  return 0;
+}
+
+int hp_program_replay(HpProgram* p, int seg, void* stream) {
+  if (!p || seg < 0 || seg >= (int)p->segs.size()) return fail("hp_program_replay: bad segment");
+  hipError_t e = hipGraphLaunch(p->segs[seg], (hipStream_t)stream);
+  if (e != hipSuccess) return fail_hip("hipGraphLaunch", e);
+  return 0;
+}
+
+int hp_program_profile(HpProgram* p, int first, int count, void* stream, float* out_ms) {
+  if (!p || !out_ms) return fail("hp_program_profile: null argument");
+  if (first < 0 || count < 0 || first + count > (int)p->ops.size()) return fail("hp_program_profile: range out of bounds");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<hipEvent_t> ev(count + 1);
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return fail("hipEventCreate failed");
+  hipEventRecord(ev[0], s);
+  for (int k = 0; k < count; ++k) {
+    hipError_t e = dispatch(p->ops[first + k], p->bases, s);
+    if (e != hipSuccess) return fail_hip("profile launch", e);
+    hipEventRecord(ev[k + 1], s);
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return fail_hip("hipStreamSynchronize", e);
+  for (int k = 0; k < count; ++k) hipEventElapsedTime(&out_ms[k], ev[k], ev[k + 1]);
+  for (auto& x : ev) hipEventDestroy(x);
+  return 0;
+}
+
+int hp_run_op(const HpOp* op, void* const bases[HP_NUM_SPACES], void* stream) {
+  if (!op || !bases) return fail("hp_run_op: null argument");
+  if (op->op <= 0 || op->op >= HP_OP__COUNT) return fail("hp_run_op: unknown opcode");
+  hipError_t e = dispatch(*op, bases, (hipStream_t)stream);
+  if (e != hipSuccess) return fail_hip("hp_run_op launch", e);
+  return 0;
+}
+
+}  // extern "C"

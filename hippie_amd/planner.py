@@ -1,0 +1,685 @@
+"""Lower one HIPPIE cVAE configuration to an op program for libhippie_hip.so.
+
+What is lowered (citations relative to the reference root):
+  * ResNet18Enc / BasicBlockEnc       hippie/backbones.py:19-41,73-103
+  * ResNet18Dec / BasicBlockDec / ResizeConv1d   hippie/backbones.py:6-16,44-70,106-141
+  * hippieUnimodalCVAE heads + reparameterisation   hippie/model.py:12-72
+  * MultiModalCVAE                                   hippie/model.py:350-432
+  * training_step loss, AdamW, gradient clipping     hippie/model.py:93-116,454-482
+plus the backward pass the reference gets from autograd.
+
+The planner is pure host logic (no GPU, no torch): it assigns every parameter,
+BatchNorm buffer and workspace tensor an arena offset and emits HpOp records.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import program as P
+from .program import Ref, TapMap, OpList
+
+SLOPE_BACKBONE = 0.01
+SLOPE_HEADS = 0.2
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+ALIGN = 256
+
+
+@dataclass
+class ModelCfg:
+    kind: str = "unimodal"            # "unimodal" | "multimodal"
+    z_dim: int = 10
+    output_size: int = 50             # also the input length (F.mse_loss(data, dec) needs equal shapes)
+    output_size2: int = 100           # multimodal: second modality
+    class_hidden_dim: int = 5
+    num_sources: int = 5
+    num_classes: int = 5
+
+
+@dataclass
+class TrainCfg:
+    lr: float = 0.01
+    weight_decay: float = 0.01
+    beta: float = 1.0
+    clip: float = 0.0                 # 0 = no gradient clipping
+    w1: float = 1.0
+    w2: float = 1.0
+    beta1: float = 0.9
+    beta2: float = 0.999
+    adam_eps: float = 1e-8
+
+
+@dataclass
+class PInfo:
+    key: str
+    shape: tuple
+    offset: int        # in floats, into PARAM / GRAD / M / V
+    numel: int
+    layout: str        # "plain" | "tnc" (conv weight stored [3][Cout][Cin])
+
+    @property
+    def ref(self):
+        return Ref(P.PARAM, self.offset * 4)
+
+    @property
+    def gref(self):
+        return Ref(P.GRAD, self.offset * 4)
+
+
+@dataclass
+class BInfo:
+    key: str
+    numel: int
+    offset: int
+
+    @property
+    def ref(self):
+        return Ref(P.BUF, self.offset * 4)
+
+
+def _round_up(x, a):
+    return (x + a - 1) // a * a
+
+
+class Plan:
+    """Result of lowering: op list + arena layouts + named I/O slots."""
+
+    def __init__(self, cfg: ModelCfg, batch: int, train: TrainCfg, with_class: bool):
+        self.cfg, self.B, self.train, self.with_class = cfg, batch, train, with_class
+        self.ops = OpList()
+        self.params: "OrderedDict[str, PInfo]" = OrderedDict()
+        self.bufs: "OrderedDict[str, BInfo]" = OrderedDict()
+        self.bn_keys = []                    # BatchNorm prefixes (for num_batches_tracked)
+        self.io = {}                         # name -> (Ref, shape, dtype str)
+        self._poff = 0
+        self._boff = 0
+        self._ws = 0
+        self.stats_bytes = 0
+        self.slab_need = 0                   # floats
+        self.flops_fwd = 0                   # 2*MAC of conv + linear, forward
+
+    # ---- arenas -------------------------------------------------------------
+    def param(self, key, shape, layout="plain", align=4):
+        numel = int(np.prod(shape))
+        self._poff = _round_up(self._poff, align)
+        info = PInfo(key, tuple(shape), self._poff, numel, layout)
+        self.params[key] = info
+        self._poff += numel
+        return info
+
+    def bn_params(self, prefix, c):
+        w = self.param(prefix + ".weight", (c,))
+        b = self.param(prefix + ".bias", (c,))
+        rm = BInfo(prefix + ".running_mean", c, self._boff); self._boff += _round_up(c, 4)
+        rv = BInfo(prefix + ".running_var", c, self._boff); self._boff += _round_up(c, 4)
+        self.bufs[rm.key] = rm
+        self.bufs[rv.key] = rv
+        self.bn_keys.append(prefix)
+        return dict(prefix=prefix, C=c, gamma=w, beta=b, rmean=rm, rvar=rv)
+
+    def ws(self, nbytes, name=None, shape=None, dtype="f4"):
+        self._ws = _round_up(self._ws, ALIGN)
+        r = Ref(P.WS, self._ws)
+        self._ws += int(nbytes)
+        if name is not None:
+            self.io[name] = (r, tuple(shape), dtype)
+        return r
+
+    def f32(self, n, name=None, shape=None):
+        return self.ws(4 * n, name, shape if shape is not None else (n,), "f4")
+
+    def stat(self, ndoubles):
+        """fp64 accumulator slots inside the zeroed-every-step statistics region."""
+        off = _round_up(self.stats_bytes, 64)
+        self.stats_bytes = off + 8 * ndoubles
+        assert self.stats_bytes <= self.stats_cap, "statistics region overflow"
+        return Ref(P.WS, self.stats_base + off)
+
+    @property
+    def n_param_floats(self):
+        return _round_up(self._poff, 4)
+
+    @property
+    def n_buf_floats(self):
+        return max(4, _round_up(self._boff, 4))
+
+    @property
+    def ws_bytes(self):
+        return _round_up(self._ws, ALIGN)
+
+
+# ======================================================================================
+class Lowering:
+    def __init__(self, cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, wgrad_target_blocks=512):
+        self.cfg, self.B = cfg, batch
+        self.train = train or TrainCfg()
+        self.with_class = with_class
+        self.target_blocks = wgrad_target_blocks
+        self.pl = Plan(cfg, batch, self.train, with_class)
+        self.o = self.pl.ops
+
+    # ---- parameter declaration (own order; class_embedding last so that AdamW can skip it) ----
+    def declare_encoder(self, pre):
+        pl = self.pl
+        e = dict(prefix=pre)
+        e["conv1"] = pl.param(pre + "conv1.weight", (64, 1, 3))
+        e["bn1"] = pl.bn_params(pre + "bn1", 64)
+        e["blocks"] = []
+        cin = 64
+        for li, planes in enumerate((64, 128, 256, 512), start=1):
+            for bi in (0, 1):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                p = f"{pre}layer{li}.{bi}."
+                blk = dict(prefix=p, cin=cin, cout=planes, stride=stride)
+                blk["conv1"] = pl.param(p + "conv1.weight", (planes, cin, 3), "tnc")
+                blk["bn1"] = pl.bn_params(p + "bn1", planes)
+                blk["conv2"] = pl.param(p + "conv2.weight", (planes, planes, 3), "tnc")
+                blk["bn2"] = pl.bn_params(p + "bn2", planes)
+                if stride != 1:
+                    blk["sc"] = pl.param(p + "shortcut.0.weight", (planes, cin, 1))
+                    blk["scbn"] = pl.bn_params(p + "shortcut.1", planes)
+                e["blocks"].append(blk)
+                cin = planes
+        e["lin_w"] = pl.param(pre + "linear.weight", (2 * self.cfg.z_dim, 512))
+        e["lin_b"] = pl.param(pre + "linear.bias", (2 * self.cfg.z_dim,))
+        return e
+
+    def declare_decoder(self, pre, output_size):
+        pl = self.pl
+        d = dict(prefix=pre, output_size=output_size)
+        d["lin_w"] = pl.param(pre + "linear.weight", (512, 2 * self.cfg.z_dim))
+        d["lin_b"] = pl.param(pre + "linear.bias", (512,))
+        d["blocks"] = []
+        cin = 512
+        for li, planes in ((4, 256), (3, 128), (2, 64), (1, 64)):
+            for bi, stride in enumerate((1, 1 if li == 1 else 2)):
+                p = f"{pre}layer{li}.{bi}."
+                cout = cin // stride
+                blk = dict(prefix=p, cin=cin, cout=cout, stride=stride)
+                blk["conv2"] = pl.param(p + "conv2.weight", (cin, cin, 3), "tnc")
+                blk["bn2"] = pl.bn_params(p + "bn2", cin)
+                if stride == 1:
+                    blk["conv1"] = pl.param(p + "conv1.weight", (cout, cin, 3), "tnc")
+                    blk["bn1"] = pl.bn_params(p + "bn1", cout)
+                else:
+                    blk["conv1"] = pl.param(p + "conv1.conv.weight", (cout, cin, 3), "tnc")
+                    blk["conv1_b"] = pl.param(p + "conv1.conv.bias", (cout,))
+                    blk["bn1"] = pl.bn_params(p + "bn1", cout)
+                    blk["sc"] = pl.param(p + "shortcut.0.conv.weight", (cout, cin, 3), "tnc")
+                    blk["sc_b"] = pl.param(p + "shortcut.0.conv.bias", (cout,))
+                    blk["scbn"] = pl.bn_params(p + "shortcut.1", cout)
+                d["blocks"].append(blk)
+            cin = planes
+        d["tail_w"] = pl.param(pre + "conv1.conv.weight", (1, 64, 3))
+        d["tail_b"] = pl.param(pre + "conv1.conv.bias", (1,))
+        d["out_w"] = pl.param(pre + "linear_out.weight", (output_size, 64))
+        d["out_b"] = pl.param(pre + "linear_out.bias", (output_size,))
+        return d
+
+    def declare_linear(self, key, n, k):
+        return dict(w=self.pl.param(key + ".weight", (n, k)), b=self.pl.param(key + ".bias", (n,)), N=n, K=k)
+
+    def declare_zml(self):
+        """z_mean and z_log_var stacked into one [2z][z] Linear (their weights/biases are adjacent)."""
+        z = self.cfg.z_dim
+        pl = self.pl
+        wm = pl.param("z_mean.weight", (z, z), align=4)
+        wv = pl.param("z_log_var.weight", (z, z), align=1)
+        bm = pl.param("z_mean.bias", (z,), align=4)
+        bv = pl.param("z_log_var.bias", (z,), align=1)
+        assert wv.offset == wm.offset + z * z and bv.offset == bm.offset + z
+        return dict(w=wm, b=bm, N=2 * z, K=z)
+
+    # ---- op emitters --------------------------------------------------------------
+    def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note=""):
+        flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias is not None else 0) | (P.CONV_STATS if stats is not None else 0)
+        self.o.add(P.CONV_TAPS, flags, i=tm.ints(), buf=[a, w.ref, out, bias.ref if bias is not None else None, stats], note=note)
+        self.pl.flops_fwd += 2 * tm.M * tm.N * tm.K * len(tm.taps) if not w_kn else 0
+
+    def wgrad(self, tm: TapMap, dy, x, w: PInfo, note=""):
+        tiles = -(-tm.N // 64) * -(-tm.K // 64)
+        nsplit = max(1, min(self.target_blocks // tiles, -(-tm.M // 64)))
+        rps = _round_up(-(-tm.M // nsplit), 32)
+        nsplit = -(-tm.M // rps)
+        self.pl.slab_need = max(self.pl.slab_need, nsplit * w.numel)
+        self.o.add(P.WGRAD_TAPS, 0, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, self.slab], note=note)
+        self.o.add(P.SLAB_REDUCE, 0, i=[w.numel, nsplit, w.numel], buf=[self.slab, w.gref], note=note + " reduce")
+
+    def bn_apply(self, M, bn, raw, out, stats, training, act, slope, res_mode=0, res=None, bn2=None, stats2=None):
+        save = self.pl.f32(2 * bn["C"])
+        bn["save"] = save
+        bufs = [raw, out, stats if training else None, bn["gamma"].ref, bn["beta"].ref, bn["rmean"].ref, bn["rvar"].ref, save]
+        if res_mode == 1:
+            bufs += [res]
+        elif res_mode == 2:
+            save2 = self.pl.f32(2 * bn2["C"])
+            bn2["save"] = save2
+            bufs += [res, stats2 if training else None, bn2["gamma"].ref, bn2["beta"].ref, bn2["rmean"].ref, bn2["rvar"].ref, save2]
+        self.o.add(P.BN_APPLY, 0, i=[M, bn["C"], res_mode, 1 if training else 0, 1 if act else 0],
+                   f=[slope, BN_EPS, BN_MOMENTUM], buf=bufs, note=bn["prefix"])
+
+    def bn_bwd(self, M, bn, g1, g2, act, raw, slope, bn_b=None, raw_b=None):
+        """returns (g, dr, dr_b): masked upstream gradient and BN input gradients."""
+        C = bn["C"]
+        g = self.pl.f32(M * C)
+        bs = self.pl.stat(2 * C)
+        bufs = [g1, g2, act, g, raw, bn["save"], bs]
+        bs_b = None
+        if bn_b is not None:
+            bs_b = self.pl.stat(2 * C)
+            bufs += [raw_b, bn_b["save"], bs_b]
+        self.o.add(P.BN_BWD_REDUCE, 0, i=[M, C, 1 if g2 is not None else 0, 1 if bn_b is not None else 0], f=[slope],
+                   buf=bufs, note=bn["prefix"] + " bwd-reduce")
+        dr = self.pl.f32(M * C)
+        self.o.add(P.BN_BWD_APPLY, 0, i=[M, C], buf=[g, raw, bn["save"], bs, bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
+                   note=bn["prefix"] + " bwd-apply")
+        dr_b = None
+        if bn_b is not None:
+            dr_b = self.pl.f32(M * C)
+            self.o.add(P.BN_BWD_APPLY, 0, i=[M, C], buf=[g, raw_b, bn_b["save"], bs_b, bn_b["gamma"].ref, dr_b,
+                                                         bn_b["gamma"].gref, bn_b["beta"].gref], note=bn_b["prefix"] + " bwd-apply")
+        return g, dr, dr_b
+
+    def linear_fwd(self, M, lin, x, ldx, y, ldy, act=False, stats=None, note=""):
+        self.o.add(P.LINEAR_FWD, 0, i=[M, lin["N"], lin["K"], ldx, ldy, 1 if act else 0, 1 if stats is not None else 0],
+                   f=[SLOPE_HEADS], buf=[x, lin["w"].ref, lin["b"].ref, y, stats], note=note)
+        self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
+
+    def linear_bwd(self, M, lin, dy, ldy, x, ldx, dx=None, lddx=None, mask=None, ldmask=0, accumulate=False, note=""):
+        self.o.add(P.LINEAR_BWD_W, 0, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
+        if dx is not None:
+            self.o.add(P.LINEAR_BWD_X, 0, i=[M, lin["N"], lin["K"], ldy, lddx, 1 if mask is not None else 0, ldmask, 1 if accumulate else 0],
+                       f=[SLOPE_HEADS], buf=[dy, lin["w"].ref, dx, mask], note=note + " dX")
+
+    # ---- tap maps --------------------------------------------------------------
+    def map_fwd(self, Lin, cin, cout, stride, k=3):
+        if k == 3:
+            Lout = (Lin + 2 - 3) // stride + 1
+            taps = [(t - 1, t) for t in range(3)]
+        else:
+            Lout = (Lin - 1) // stride + 1
+            taps = [(0, 0)]
+        return TapMap(self.B * Lout, cout, cin, Lout, Lin, Lin, stride, 0, 0, taps), Lout
+
+    def map_fwd_up(self, Lin, cin, cout):
+        Lout = 2 * Lin
+        return TapMap(self.B * Lout, cout, cin, Lout, Lin, 2 * Lin, 1, 1, 0, [(t - 1, t) for t in range(3)]), Lout
+
+    def map_dgrad(self, Lx, Ly, cin, cout, stride, k=3):
+        taps = [(1 - t, t) for t in range(3)] if k == 3 else [(0, 0)]
+        if stride == 1:
+            return TapMap(self.B * Lx, cin, cout, Lx, Ly, Ly, 1, 0, 0, taps)
+        return TapMap(self.B * Lx, cin, cout, Lx, Ly, 2 * Ly, 1, 1, 1, taps)
+
+    def map_dgrad_up(self, Lx, cin, cout):
+        Ly = 2 * Lx
+        return TapMap(self.B * Lx, cin, cout, Lx, Ly, Ly, 2, 0, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)])
+
+    # ---- encoder ------------------------------------------------------------------
+    def encoder_fwd(self, e, x, L, training):
+        pl, B = self.pl, self.B
+        L1 = (L + 2 - 3) // 2 + 1
+        M = B * L1
+        raw0 = pl.f32(M * 64)
+        st = pl.stat(128) if training else None
+        self.o.add(P.STEM_FWD, 0, i=[B, L, L1, 64], buf=[x, e["conv1"].ref, raw0, st], note=e["prefix"] + "conv1")
+        pl.flops_fwd += 2 * M * 64 * 3
+        a0 = pl.f32(M * 64)
+        self.bn_apply(M, e["bn1"], raw0, a0, st, training, True, SLOPE_BACKBONE)
+        e.update(x=x, L=L, L1=L1, raw0=raw0, a0=a0)
+        cur, Lc = a0, L1
+        for blk in e["blocks"]:
+            cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
+            tm1, Lo = self.map_fwd(Lc, cin, cout, s)
+            Mo = B * Lo
+            r1 = pl.f32(Mo * cout)
+            st1 = pl.stat(2 * cout) if training else None
+            self.conv(tm1, cur, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1")
+            a1 = pl.f32(Mo * cout)
+            self.bn_apply(Mo, blk["bn1"], r1, a1, st1, training, True, SLOPE_BACKBONE)
+            tm2, _ = self.map_fwd(Lo, cout, cout, 1)
+            r2 = pl.f32(Mo * cout)
+            st2 = pl.stat(2 * cout) if training else None
+            self.conv(tm2, a1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
+            out = pl.f32(Mo * cout)
+            blk.update(x=cur, Lin=Lc, Lout=Lo, r1=r1, a1=a1, r2=r2, out=out, tm1=tm1, tm2=tm2)
+            if s == 1:
+                self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 1, cur)
+            else:
+                tms, _ = self.map_fwd(Lc, cin, cout, s, k=1)
+                rs = pl.f32(Mo * cout)
+                sts = pl.stat(2 * cout) if training else None
+                self.conv(tms, cur, blk["sc"], rs, stats=sts, note=blk["prefix"] + "shortcut.0")
+                self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
+                blk.update(rs=rs, tms=tms)
+            cur, Lc = out, Lo
+        pooled = pl.f32(B * 512)
+        self.o.add(P.POOL_FWD, 0, i=[B, Lc, 512], buf=[cur, pooled], note=e["prefix"] + "avgpool")
+        e.update(pooled=pooled, Llast=Lc, last=cur)
+        return pooled
+
+    def encoder_bwd(self, e, dpooled):
+        """dpooled: [B][512] gradient of the pooled features."""
+        pl, B = self.pl, self.B
+        Lc = e["Llast"]
+        G1 = pl.f32(B * Lc * 512)
+        self.o.add(P.POOL_BWD, 0, i=[B, Lc, 512], buf=[dpooled, G1], note=e["prefix"] + "avgpool bwd")
+        G2 = None
+        for blk in reversed(e["blocks"]):
+            cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
+            Lo, Li = blk["Lout"], blk["Lin"]
+            Mo, Mi = B * Lo, B * Li
+            if s == 1:
+                g, dr2, drs = self.bn_bwd(Mo, blk["bn2"], G1, G2, blk["out"], blk["r2"], SLOPE_BACKBONE)
+            else:
+                g, dr2, drs = self.bn_bwd(Mo, blk["bn2"], G1, G2, blk["out"], blk["r2"], SLOPE_BACKBONE, blk["scbn"], blk["rs"])
+            self.wgrad(blk["tm2"], dr2, blk["a1"], blk["conv2"], note=blk["prefix"] + "conv2 wgrad")
+            da1 = pl.f32(Mo * cout)
+            self.conv(self.map_dgrad(Lo, Lo, cout, cout, 1), dr2, blk["conv2"], da1, w_kn=True, note=blk["prefix"] + "conv2 dgrad")
+            _, dr1, _ = self.bn_bwd(Mo, blk["bn1"], da1, None, blk["a1"], blk["r1"], SLOPE_BACKBONE)
+            self.wgrad(blk["tm1"], dr1, blk["x"], blk["conv1"], note=blk["prefix"] + "conv1 wgrad")
+            dxa = pl.f32(Mi * cin)
+            self.conv(self.map_dgrad(Li, Lo, cin, cout, s), dr1, blk["conv1"], dxa, w_kn=True, note=blk["prefix"] + "conv1 dgrad")
+            if s == 1:
+                G1, G2 = dxa, g
+            else:
+                self.wgrad(blk["tms"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut wgrad")
+                dxs = pl.f32(Mi * cin)
+                self.conv(self.map_dgrad(Li, Lo, cin, cout, s, k=1), drs, blk["sc"], dxs, w_kn=True, note=blk["prefix"] + "shortcut dgrad")
+                G1, G2 = dxa, dxs
+        M = B * e["L1"]
+        _, dr0, _ = self.bn_bwd(M, e["bn1"], G1, G2, e["a0"], e["raw0"], SLOPE_BACKBONE)
+        self.o.add(P.STEM_WGRAD, 0, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
+
+    # ---- decoder ------------------------------------------------------------------
+    def decoder_fwd(self, d, din, training):
+        """din: [B][2z] -> rec [B][output_size]"""
+        pl, B, z = self.pl, self.B, self.cfg.z_dim
+        lin = dict(w=d["lin_w"], b=d["lin_b"], N=512, K=2 * z)
+        y = pl.f32(B * 512)
+        self.linear_fwd(B, lin, din, 2 * z, y, 512, note=d["prefix"] + "linear")
+        act0 = pl.f32(B * 4 * 512)
+        self.o.add(P.REPEAT_FWD, 0, i=[B, 4, 512], buf=[y, act0], note=d["prefix"] + "interpolate x4")
+        d.update(din=din, lin=lin, y=y, act0=act0)
+        cur, Lc = act0, 4
+        for blk in d["blocks"]:
+            cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
+            Mi = B * Lc
+            tm2, _ = self.map_fwd(Lc, cin, cin, 1)
+            r2 = pl.f32(Mi * cin)
+            st2 = pl.stat(2 * cin) if training else None
+            self.conv(tm2, cur, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
+            a2 = pl.f32(Mi * cin)
+            self.bn_apply(Mi, blk["bn2"], r2, a2, st2, training, True, SLOPE_BACKBONE)
+            blk.update(x=cur, Lin=Lc, r2=r2, a2=a2, tm2=tm2)
+            if s == 1:
+                tm1, Lo = self.map_fwd(Lc, cin, cout, 1)
+                r1 = pl.f32(Mi * cout)
+                st1 = pl.stat(2 * cout) if training else None
+                self.conv(tm1, a2, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1")
+                out = pl.f32(Mi * cout)
+                self.bn_apply(Mi, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 1, cur)
+            else:
+                tm1, Lo = self.map_fwd_up(Lc, cin, cout)
+                Mo = B * Lo
+                r1 = pl.f32(Mo * cout)
+                st1 = pl.stat(2 * cout) if training else None
+                self.conv(tm1, a2, blk["conv1"], r1, bias=blk["conv1_b"], stats=st1, note=blk["prefix"] + "conv1 (resize)")
+                rs = pl.f32(Mo * cout)
+                sts = pl.stat(2 * cout) if training else None
+                self.conv(tm1, cur, blk["sc"], rs, bias=blk["sc_b"], stats=sts, note=blk["prefix"] + "shortcut (resize)")
+                out = pl.f32(Mo * cout)
+                self.bn_apply(Mo, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
+                blk.update(rs=rs)
+            blk.update(r1=r1, out=out, tm1=tm1, Lout=Lo)
+            cur, Lc = out, Lo
+        assert Lc == 32
+        t = pl.f32(B * 64)
+        self.o.add(P.TAIL_FWD, 0, i=[B, 32, 64], buf=[cur, d["tail_w"].ref, d["tail_b"].ref, t], note=d["prefix"] + "conv1 (resize 64->1)")
+        pl.flops_fwd += 2 * B * 64 * 64 * 3
+        lo = dict(w=d["out_w"], b=d["out_b"], N=d["output_size"], K=64)
+        rec = pl.f32(B * d["output_size"])
+        self.linear_fwd(B, lo, t, 64, rec, d["output_size"], note=d["prefix"] + "linear_out")
+        d.update(last=cur, t=t, lo=lo, rec=rec)
+        return rec
+
+    def decoder_bwd(self, d, drec, ddin, accumulate=False):
+        """drec: [B][out] ; writes d(din) [B][2z] into ddin."""
+        pl, B, z = self.pl, self.B, self.cfg.z_dim
+        dt = pl.f32(B * 64)
+        self.linear_bwd(B, d["lo"], drec, d["output_size"], d["t"], 64, dt, 64, note=d["prefix"] + "linear_out")
+        self.o.add(P.TAIL_BWD_W, 0, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
+        G1 = pl.f32(B * 32 * 64)
+        self.o.add(P.TAIL_BWD_X, 0, i=[B, 32, 64], buf=[dt, d["tail_w"].ref, G1], note=d["prefix"] + "tail dX")
+        G2 = None
+        for blk in reversed(d["blocks"]):
+            cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
+            Li, Lo = blk["Lin"], blk["Lout"]
+            Mi, Mo = B * Li, B * Lo
+            if s == 1:
+                g, dr1, _ = self.bn_bwd(Mo, blk["bn1"], G1, G2, blk["out"], blk["r1"], SLOPE_BACKBONE)
+                self.wgrad(blk["tm1"], dr1, blk["a2"], blk["conv1"], note=blk["prefix"] + "conv1 wgrad")
+                da2 = pl.f32(Mi * cin)
+                self.conv(self.map_dgrad(Li, Lo, cin, cout, 1), dr1, blk["conv1"], da2, w_kn=True, note=blk["prefix"] + "conv1 dgrad")
+                side = g
+            else:
+                g, dr1, drs = self.bn_bwd(Mo, blk["bn1"], G1, G2, blk["out"], blk["r1"], SLOPE_BACKBONE, blk["scbn"], blk["rs"])
+                self.wgrad(blk["tm1"], dr1, blk["a2"], blk["conv1"], note=blk["prefix"] + "conv1 (resize) wgrad")
+                da2 = pl.f32(Mi * cin)
+                self.conv(self.map_dgrad_up(Li, cin, cout), dr1, blk["conv1"], da2, w_kn=True, note=blk["prefix"] + "conv1 (resize) dgrad")
+                self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut (resize) wgrad")
+                side = pl.f32(Mi * cin)
+                self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, note=blk["prefix"] + "shortcut (resize) dgrad")
+            _, dr2, _ = self.bn_bwd(Mi, blk["bn2"], da2, None, blk["a2"], blk["r2"], SLOPE_BACKBONE)
+            self.wgrad(blk["tm2"], dr2, blk["x"], blk["conv2"], note=blk["prefix"] + "conv2 wgrad")
+            dxa = pl.f32(Mi * cin)
+            self.conv(self.map_dgrad(Li, Li, cin, cin, 1), dr2, blk["conv2"], dxa, w_kn=True, note=blk["prefix"] + "conv2 dgrad")
+            G1, G2 = dxa, side
+        dy = pl.f32(B * 512)
+        self.o.add(P.REPEAT_BWD, 0, i=[B, 4, 512, 1], buf=[G1, G2, dy], note=d["prefix"] + "interpolate x4 bwd")
+        self.linear_bwd(B, d["lin"], dy, 512, d["din"], 2 * z, ddin, 2 * z, accumulate=accumulate, note=d["prefix"] + "linear")
+
+    # ---- heads: shared pieces --------------------------------------------------
+    def concat(self, out, ldo, segs, note):
+        """segs: list of (kind, width, ld, src_ref, idx_ref)"""
+        ii = [self.B, len(segs), ldo, 0]
+        bufs = [out]
+        for (kind, w, ld, src, idx) in segs:
+            ii += [kind, w, ld]
+            bufs += [src, idx]
+        ii += [0] * (16 - len(ii))
+        self.o.add(P.CONCAT, 0, i=ii, buf=bufs, note=note)
+
+    def emb_segs(self):
+        H = self.cfg.class_hidden_dim
+        segs = [(1, H, H, self.semb.ref, self.src)]
+        segs.append((1, H, H, self.cemb.ref, self.cls) if self.with_class else (2, H, 0, None, None))
+        return segs
+
+    def emb_bwd(self, dcat, ld, col0):
+        H = self.cfg.class_hidden_dim
+        self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0], buf=[dcat, self.src, self.semb.gref], note="source_embedding grad")
+        if self.with_class:
+            self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0 + H], buf=[dcat, self.cls, self.cemb.gref], note="class_embedding grad")
+
+    # ---- whole model ---------------------------------------------------------------
+    def build(self):
+        cfg, pl, B, z, H = self.cfg, self.pl, self.B, self.cfg.z_dim, self.cfg.class_hidden_dim
+        multi = cfg.kind == "multimodal"
+        # ---------------- parameters ----------------
+        if not multi:
+            enc = [self.declare_encoder("encoder.")]
+            fc0 = self.declare_linear("encoder_fc.0", 2 * z, 2 * z + 2 * H)
+            bn_e1 = pl.bn_params("encoder_fc.1", 2 * z)
+            fc3 = self.declare_linear("encoder_fc.3", z, 2 * z)
+            bn_e4 = pl.bn_params("encoder_fc.4", z)
+        else:
+            enc = [self.declare_encoder("encoder_mod1."), self.declare_encoder("encoder_mod2.")]
+            fc0 = self.declare_linear("fusion_encoder.0", 2 * z, 4 * z + 2 * H)
+            bn_e1 = pl.bn_params("fusion_encoder.1", 2 * z)
+            fc3 = self.declare_linear("fusion_encoder.3", z, 2 * z)
+            bn_e4 = None
+        self.semb = pl.param("source_embedding.weight", (cfg.num_sources, H))
+        zml = self.declare_zml()
+        decs, dfc = [], []
+        names = [("decoder_fc", "decoder.", cfg.output_size)] if not multi else [
+            ("decoder_fc_mod1", "decoder_mod1.", cfg.output_size), ("decoder_fc_mod2", "decoder_mod2.", cfg.output_size2)]
+        for fcname, dpre, osz in names:
+            f0 = self.declare_linear(fcname + ".0", 2 * z, z + 2 * H)
+            f2 = self.declare_linear(fcname + ".2", 2 * z, 2 * z)
+            bn3 = pl.bn_params(fcname + ".3", 2 * z)
+            dfc.append(dict(f0=f0, f2=f2, bn3=bn3))
+            decs.append(self.declare_decoder(dpre, osz))
+        self.cemb = pl.param("class_embedding.weight", (cfg.num_classes, H))    # LAST: skipped by AdamW without class labels
+        pl.n_active = pl.n_param_floats if self.with_class else _round_up(self.cemb.offset, 4)
+        # the floats between n_active and cemb.offset (alignment gap) are zero padding
+
+        # ---------------- workspace: persistent + I/O ----------------
+        pl.stats_cap = 4 << 20
+        pl.stats_base = pl.ws(pl.stats_cap).offset
+        self.step_ref = pl.ws(64, "adam_step", (1,), "i8")
+        lens = [cfg.output_size] if not multi else [cfg.output_size, cfg.output_size2]
+        xs = [pl.f32(B * L, "x" if i == 0 else "x2", (B, 1, L)) for i, L in enumerate(lens)]
+        self.src = pl.ws(8 * B, "src", (B,), "i8")
+        self.cls = pl.ws(8 * B, "cls", (B,), "i8")
+        eps = pl.f32(B * z, "eps", (B, z))
+        scal = pl.f32(4, "scalars", (4,))
+        self.slab = pl.ws(0)                 # sized at the end (placed last)
+        loss = pl.stat(4)
+        norm2 = pl.stat(1)
+
+        segs = {}
+        for mode in ("train", "eval"):
+            training = mode == "train"
+            self.o.begin("fwd_" + mode)
+            zero_idx = self.o.add(P.ZERO, 0, i=[0, 0], buf=[Ref(P.WS, pl.stats_base)], note="zero statistics")
+            pooled = [self.encoder_fwd(e, x, L, training) for e, x, L in zip(enc, xs, lens)]
+            ncat = (2 * z) * len(enc) + 2 * H
+            c0 = pl.f32(B * ncat)
+            hsegs = []
+            hs = []
+            for e, pz in zip(enc, pooled):
+                h = pl.f32(B * 2 * z)
+                self.linear_fwd(B, dict(w=e["lin_w"], b=e["lin_b"], N=2 * z, K=512), pz, 512, h, 2 * z, note=e["prefix"] + "linear")
+                hs.append(h)
+                hsegs.append((0, 2 * z, 2 * z, h, None))
+            self.concat(c0, ncat, hsegs + self.emb_segs(), "cat(enc, source_emb, class_emb)")
+            u1 = pl.f32(B * 2 * z)
+            st = pl.stat(4 * z) if training else None
+            self.linear_fwd(B, fc0, c0, ncat, u1, 2 * z, stats=st, note="encoder_fc.0")
+            a1 = pl.f32(B * 2 * z)
+            self.bn_apply(B, bn_e1, u1, a1, st, training, True, SLOPE_HEADS)
+            if not multi:
+                u2 = pl.f32(B * z)
+                st2 = pl.stat(2 * z) if training else None
+                self.linear_fwd(B, fc3, a1, 2 * z, u2, z, stats=st2, note="encoder_fc.3")
+                encv = pl.f32(B * z, "enc_" + mode, (B, z))
+                self.bn_apply(B, bn_e4, u2, encv, st2, training, True, SLOPE_HEADS)
+            else:
+                u2 = None
+                encv = pl.f32(B * z, "enc_" + mode, (B, z))
+                self.linear_fwd(B, fc3, a1, 2 * z, encv, z, note="fusion_encoder.3")
+            mulv = pl.f32(B * 2 * z, "mulv_" + mode, (B, 2 * z))
+            self.linear_fwd(B, zml, encv, z, mulv, 2 * z, note="z_mean | z_log_var")
+            zz = pl.f32(B * z)
+            self.o.add(P.REPARAM_KL_FWD, 0, i=[B, z], buf=[mulv, eps, zz, loss], note="reparameterize + KL")
+            ncat1 = z + 2 * H
+            c1 = pl.f32(B * ncat1)
+            self.concat(c1, ncat1, [(0, z, z, zz, None)] + self.emb_segs(), "cat(z, source_emb, class_emb)")
+            heads = []
+            recs = []
+            for k, (fc, dd) in enumerate(zip(dfc, decs)):
+                u3 = pl.f32(B * 2 * z)
+                self.linear_fwd(B, fc["f0"], c1, ncat1, u3, 2 * z, act=True, note="decoder_fc.0 + LeakyReLU")
+                u4 = pl.f32(B * 2 * z)
+                st4 = pl.stat(4 * z) if training else None
+                self.linear_fwd(B, fc["f2"], u3, 2 * z, u4, 2 * z, stats=st4, note="decoder_fc.2")
+                dv = pl.f32(B * 2 * z)
+                self.bn_apply(B, fc["bn3"], u4, dv, st4, training, True, SLOPE_HEADS)
+                rec = self.decoder_fwd(dd, dv, training)
+                pl.io[("rec_" if k == 0 else "rec2_") + mode] = (rec, (B, 1, dd["output_size"]), "f4")
+                drec = pl.f32(B * dd["output_size"])
+                n = B * dd["output_size"]
+                w = self.train.w1 if k == 0 else self.train.w2
+                self.o.add(P.MSE_FWD_BWD, 0, i=[n, 1 + k], f=[w if multi else 1.0], buf=[xs[k], rec, drec, loss], note="mse")
+                heads.append(dict(u3=u3, u4=u4, dv=dv, drec=drec))
+                recs.append(rec)
+            n1 = B * lens[0]
+            n2 = B * lens[1] if multi else 0
+            self.o.add(P.LOSS_FINALIZE, 0, i=[B, n1, n2], f=[self.train.beta, self.train.w1 if multi else 1.0,
+                                                             self.train.w2 if multi else 0.0], buf=[loss, scal], note="loss scalars")
+            self.o.end()
+            if not training:
+                self.o.recs[zero_idx]["i"][0] = pl.stats_cap   # patched below
+                segs["eval_zero"] = zero_idx
+                continue
+            segs["train_zero"] = zero_idx
+            if mode == "train":
+                fwd_flops = pl.flops_fwd
+
+            # ---------------- backward ----------------
+            self.o.begin("bwd")
+            nb = pl.n_param_floats * 4
+            self.o.add(P.ZERO, 0, i=[nb & 0xFFFFFFFF, nb >> 32], buf=[Ref(P.GRAD, 0)], note="zero gradients")
+            dc1 = pl.f32(B * ncat1)
+            for k, (fc, dd, hd) in enumerate(zip(dfc, decs, heads)):
+                ddv = pl.f32(B * 2 * z)
+                self.decoder_bwd(dd, hd["drec"], ddv)
+                _, du4, _ = self.bn_bwd(B, fc["bn3"], ddv, None, hd["dv"], hd["u4"], SLOPE_HEADS)
+                du3 = pl.f32(B * 2 * z)
+                self.linear_bwd(B, fc["f2"], du4, 2 * z, hd["u3"], 2 * z, du3, 2 * z, mask=hd["u3"], ldmask=2 * z, note="decoder_fc.2")
+                self.linear_bwd(B, fc["f0"], du3, 2 * z, c1, ncat1, dc1, ncat1, accumulate=(k > 0), note="decoder_fc.0")
+            self.emb_bwd(dc1, ncat1, z)
+            dmulv = pl.f32(B * 2 * z)
+            self.o.add(P.REPARAM_KL_BWD, 0, i=[B, z, ncat1], f=[self.train.beta], buf=[mulv, eps, dc1, dmulv], note="reparameterize + KL bwd")
+            denc = pl.f32(B * z)
+            self.linear_bwd(B, zml, dmulv, 2 * z, encv, z, denc, z, note="z_mean | z_log_var")
+            if not multi:
+                _, du2, _ = self.bn_bwd(B, bn_e4, denc, None, encv, u2, SLOPE_HEADS)
+            else:
+                du2 = denc
+            da1 = pl.f32(B * 2 * z)
+            self.linear_bwd(B, fc3, du2, z, a1, 2 * z, da1, 2 * z, note="encoder_fc.3")
+            _, du1, _ = self.bn_bwd(B, bn_e1, da1, None, a1, u1, SLOPE_HEADS)
+            dc0 = pl.f32(B * ncat)
+            self.linear_bwd(B, fc0, du1, 2 * z, c0, ncat, dc0, ncat, note="encoder_fc.0")
+            self.emb_bwd(dc0, ncat, 2 * z * len(enc))
+            for k, e in enumerate(enc):
+                dpooled = pl.f32(B * 512)
+                lin = dict(w=e["lin_w"], b=e["lin_b"], N=2 * z, K=512)
+                dh = dc0 + 4 * (2 * z * k)      # column window of dc0, leading dimension ncat
+                self.linear_bwd(B, lin, dh, ncat, e["pooled"], 512, dpooled, 512, note=e["prefix"] + "linear")
+                self.encoder_bwd(e, dpooled)
+            self.o.end()
+
+            # ---------------- optimiser ----------------
+            self.o.begin("opt")
+            n = pl.n_active
+            if self.train.clip > 0:
+                self.o.add(P.GRADNORM, 0, i=[n], buf=[Ref(P.GRAD, 0), norm2], note="clip_grad_norm: total norm")
+            self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="adam step += 1")
+            t = self.train
+            self.o.add(P.ADAMW, 0, i=[n], f=[t.lr, t.beta1, t.beta2, t.adam_eps, t.weight_decay, t.clip],
+                       buf=[Ref(P.PARAM, 0), Ref(P.GRAD, 0), Ref(P.ADAM_M, 0), Ref(P.ADAM_V, 0), self.step_ref, norm2], note="AdamW")
+            self.o.end()
+            pl.flops_fwd = 0
+        pl.flops_fwd = fwd_flops
+        # finalize: statistics region size into both ZERO ops; slab at the end of the workspace
+        used = _round_up(pl.stats_bytes, 256)
+        for key in ("train_zero", "eval_zero"):
+            self.o.recs[segs[key]]["i"][0] = used
+            self.o.recs[segs[key]]["i"][1] = 0
+        slab = pl.ws(4 * max(pl.slab_need, 4))
+        for r in self.o.recs:
+            if int(r["op"]) == P.WGRAD_TAPS:
+                r["buf"][2] = slab.encode()
+            elif int(r["op"]) == P.SLAB_REDUCE:
+                r["buf"][0] = slab.encode()
+        return pl
+
+
+def lower(cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, **kw) -> Plan:
+    return Lowering(cfg, batch, train, with_class, **kw).build()

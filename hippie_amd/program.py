@@ -1,0 +1,200 @@
+"""Op-program records and the ctypes binding of libhippie_hip.so (include/hippie_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing, or a
+GPU op is requested without a GPU, an error is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+# ---- mirrors of include/hippie_hip.h ------------------------------------------
+WS, PARAM, GRAD, BUF, ADAM_M, ADAM_V = range(6)
+NUM_SPACES = 6
+NULL = -1
+MAX_TAPS = 6
+NI, NF, NB = 28, 8, 16
+
+OP_DTYPE = np.dtype([("op", "<i4"), ("flags", "<i4"), ("i", "<i4", (NI,)), ("f", "<f4", (NF,)),
+                     ("buf", "<i8", (NB,))], align=True)
+assert OP_DTYPE.itemsize == 280
+
+(CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
+ POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
+ REPARAM_KL_BWD, MSE_FWD_BWD, TAIL_FWD, TAIL_BWD_X, TAIL_BWD_W, LOSS_FINALIZE, GRADNORM, ADAMW, STEP_INC,
+ ZERO) = range(1, 29)
+OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
+    "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
+
+CONV_W_KN, CONV_BIAS, CONV_STATS = 1, 2, 4
+
+
+@dataclass(frozen=True)
+class Ref:
+    """A buffer reference: arena + byte offset."""
+    space: int
+    offset: int
+
+    def encode(self) -> int:
+        return (self.space << 56) | self.offset
+
+    def __add__(self, nbytes: int) -> "Ref":
+        return Ref(self.space, self.offset + int(nbytes))
+
+
+def enc(ref) -> int:
+    return NULL if ref is None else ref.encode()
+
+
+@dataclass
+class TapMap:
+    """Row mapping of the implicit-GEMM convolution family (see hippie_hip.h)."""
+    M: int
+    N: int
+    K: int
+    Lout: int
+    Lin: int
+    P: int
+    a: int = 1
+    sh: int = 0
+    even: int = 0
+    taps: list = field(default_factory=list)   # [(offset, weight_slab)]
+
+    def ints(self):
+        o = [t[0] for t in self.taps] + [0] * (MAX_TAPS - len(self.taps))
+        w = [t[1] for t in self.taps] + [0] * (MAX_TAPS - len(self.taps))
+        return [self.M, self.N, self.K, self.Lout, self.Lin, self.P, self.a, self.sh, self.even, len(self.taps)] + o + w
+
+
+class OpList:
+    """Growable list of op records with named segments."""
+
+    def __init__(self):
+        self.recs = []
+        self.notes = []
+        self.segments = {}
+        self._open = None
+
+    def begin(self, name):
+        assert self._open is None
+        self._open = (name, len(self.recs))
+
+    def end(self):
+        name, start = self._open
+        self.segments[name] = (start, len(self.recs) - start)
+        self._open = None
+
+    def add(self, op, flags=0, i=(), f=(), buf=(), note=""):
+        r = np.zeros((), dtype=OP_DTYPE)
+        r["op"] = op
+        r["flags"] = flags
+        ii = list(i)
+        assert len(ii) <= NI and len(f) <= NF and len(buf) <= NB, (op, len(ii), len(f), len(buf))
+        r["i"][: len(ii)] = ii
+        r["f"][: len(f)] = list(f)
+        b = [enc(x) for x in buf] + [NULL] * (NB - len(buf))
+        r["buf"][:] = b
+        self.recs.append(r)
+        self.notes.append(note)
+        return len(self.recs) - 1
+
+    def array(self):
+        return np.array(self.recs, dtype=OP_DTYPE)
+
+
+# ---- shared library ---------------------------------------------------------------
+_LIB = None
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")
+
+EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",
+           "hp_program_validate", "hp_program_run", "hp_program_capture", "hp_program_replay", "hp_program_profile",
+           "hp_run_op")
+
+
+class HipEngineError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load libhippie_hip.so (built by hippie_amd/csrc/Makefile).  Fails loudly when absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise HipEngineError(f"{LIB_PATH} not found: build it with `make -C hippie_amd/csrc` "
+                             "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        getattr(lib, name)   # AttributeError if the ABI is incomplete
+    lib.hp_last_error.restype = ctypes.c_char_p
+    lib.hp_abi_version.restype = ctypes.c_int
+    vp, ip = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)
+    lib.hp_device_info.argtypes = [ip, ip, ctypes.c_char_p, ctypes.c_int]
+    lib.hp_program_create.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(vp)]
+    lib.hp_program_destroy.argtypes = [vp]
+    lib.hp_program_validate.argtypes = [vp]
+    lib.hp_program_run.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.hp_program_capture.argtypes = [vp, ctypes.c_int, ctypes.c_int, ip]
+    lib.hp_program_replay.argtypes = [vp, ctypes.c_int, vp]
+    lib.hp_program_profile.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
+    lib.hp_run_op.argtypes = [vp, ctypes.POINTER(vp), vp]
+    if lib.hp_abi_version() != 1:
+        raise HipEngineError("libhippie_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise HipEngineError(f"{what}: {lib.hp_last_error().decode()}")
+
+
+class DeviceProgram:
+    """A validated program bound to six arena base pointers."""
+
+    def __init__(self, ops: np.ndarray, bases, sizes):
+        self.lib = load_library()
+        self.ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
+        self._bases = (ctypes.c_void_p * NUM_SPACES)(*[ctypes.c_void_p(int(b)) for b in bases])
+        self._sizes = (ctypes.c_int64 * NUM_SPACES)(*[int(s) for s in sizes])
+        self.handle = ctypes.c_void_p()
+        rc = self.lib.hp_program_create(self.ops.ctypes.data_as(ctypes.c_void_p), len(self.ops), self._bases, self._sizes,
+                                        ctypes.byref(self.handle))
+        _check(self.lib, rc, "hp_program_create")
+
+    def run(self, first, count, stream=0):
+        _check(self.lib, self.lib.hp_program_run(self.handle, first, count, ctypes.c_void_p(stream)), "hp_program_run")
+
+    def capture(self, first, count):
+        seg = ctypes.c_int(-1)
+        _check(self.lib, self.lib.hp_program_capture(self.handle, first, count, ctypes.byref(seg)), "hp_program_capture")
+        return seg.value
+
+    def replay(self, seg, stream=0):
+        _check(self.lib, self.lib.hp_program_replay(self.handle, seg, ctypes.c_void_p(stream)), "hp_program_replay")
+
+    def profile(self, first, count, stream=0):
+        out = (ctypes.c_float * count)()
+        _check(self.lib, self.lib.hp_program_profile(self.handle, first, count, ctypes.c_void_p(stream), out), "hp_program_profile")
+        return np.array(out[:], dtype=np.float32)
+
+    def close(self):
+        if self.handle:
+            self.lib.hp_program_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def run_single_op(rec: np.ndarray, bases, stream=0):
+    lib = load_library()
+    rec = np.ascontiguousarray(rec, dtype=OP_DTYPE)
+    b = (ctypes.c_void_p * NUM_SPACES)(*[ctypes.c_void_p(int(x)) for x in bases])
+    _check(lib, lib.hp_run_op(rec.ctypes.data_as(ctypes.c_void_p), b, ctypes.c_void_p(stream)), "hp_run_op")

@@ -1,0 +1,204 @@
+/*
+ * hippie_hip.h — C ABI of libhippie_hip.so, the MI355X (gfx950) engine behind the
+ * HIPPIE cVAE hot path.
+ *
+ * Boundary.  The reference (aghatpande/HIPPIE) has no FFI: its hot path is the Python
+ * class surface of hippie/backbones.py + hippie/model.py executed by stock ATen ops.
+ * This library replaces what those modules make ATen do, at the granularity of the
+ * reference's own layers.  Each op below cites the reference call site it replaces
+ * (paths relative to the reference root).  The host side (hippie_amd/, Python like the
+ * reference) lowers one optimisation step of a model into an array of HpOp records — a
+ * "program" — which this library executes as HIP kernels on a caller-supplied stream and
+ * can capture into a hipGraph.  No torch types cross this boundary: plain device
+ * pointers, sizes and POD records only.
+ *
+ * Memory model.  The caller owns six device arenas and passes their base pointers:
+ *   HP_SPACE_WS     workspace (activations, saved tensors, slabs, fp64 statistic slots,
+ *                   staged inputs x / labels / eps, scalar outputs)
+ *   HP_SPACE_PARAM  fp32 parameters (conv weights stored tap-major [3][Cout][Cin])
+ *   HP_SPACE_GRAD   fp32 gradients, same layout as PARAM
+ *   HP_SPACE_BUF    BatchNorm running_mean / running_var
+ *   HP_SPACE_M/V    AdamW exp_avg / exp_avg_sq, same layout as PARAM
+ * A buffer reference inside an op is  (space << 56) | byte_offset ;  HP_NULL = none.
+ * Activations are channels-last: tensor [B, C, L] of the reference is stored as the
+ * row-major matrix [B*L][C] (row m = b*L + l).
+ *
+ * Errors: every function returns 0 on success, nonzero otherwise; hp_last_error()
+ * returns a static message for the calling thread.  Never aborts.
+ * Threading: a program is not thread-safe; all work is stream-ordered and asynchronous.
+ */
+#ifndef HIPPIE_HIP_H
+#define HIPPIE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HP_ABI_VERSION 1
+
+enum {
+  HP_SPACE_WS = 0, HP_SPACE_PARAM = 1, HP_SPACE_GRAD = 2, HP_SPACE_BUF = 3,
+  HP_SPACE_M = 4, HP_SPACE_V = 5, HP_NUM_SPACES = 6
+};
+#define HP_NULL ((int64_t)-1)
+#define HP_MAX_TAPS 6
+#define HP_OP_NI 28
+#define HP_OP_NF 8
+#define HP_OP_NB 16
+
+/* One op record (POD, 8-byte aligned; numpy dtype mirror in hippie_amd/program.py). */
+typedef struct HpOp {
+  int32_t op;               /* HP_OP_* */
+  int32_t flags;            /* op-specific bit flags */
+  int32_t i[HP_OP_NI];      /* integer parameters */
+  float   f[HP_OP_NF];      /* float parameters */
+  int64_t buf[HP_OP_NB];    /* buffer references */
+} HpOp;
+
+/* ---- opcodes ------------------------------------------------------------------
+ * Row mapping shared by CONV_TAPS / WGRAD_TAPS (an implicit-GEMM view of every
+ * Conv1d variant of the reference):  output row m -> (b = m / Lout, l = m % Lout);
+ * for tap j:  pos = a*l + tap_o[j];  the tap contributes iff 0 <= pos < P and
+ * (!even || pos % 2 == 0);  source row = b*Lin + (pos >> sh);  weight slab tap_w[j].
+ *   i[0]=M  i[1]=N  i[2]=K  i[3]=Lout  i[4]=Lin  i[5]=P  i[6]=a  i[7]=sh  i[8]=even
+ *   i[9]=ntaps  i[10..15]=tap_o  i[16..21]=tap_w
+ */
+enum {
+  /* out[m][n] = sum_taps sum_k A[src(m,tap)][k] * W[tap_w][..] (+bias[n]);  f32 MFMA.
+   * Replaces nn.Conv1d forward (backbones.py:24,26,33,50,55), ResizeConv1d =
+   * F.interpolate(nearest)+Conv1d (backbones.py:13-16) with the upsample folded into
+   * the row mapping, and their input-gradients (ATen convolution_backward) with
+   * transposed weights.  flags: 1 = weight slab is [K][N] (else [N][K]); 2 = bias;
+   * 4 = accumulate per-column sum / sum of squares (fp64 atomics) into buf[4] for the
+   * following BatchNorm.   buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[2][N]) */
+  HP_OP_CONV_TAPS = 1,
+  /* slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]; f32 MFMA.
+   * Replaces the weight-gradient half of ATen convolution_backward.
+   * i[22]=nsplit i[23]=rows_per_split (multiple of 32) i[24]=slab stride per split (floats).
+   * buf: 0 DY, 1 X, 2 SLAB */
+  HP_OP_WGRAD_TAPS = 2,
+  /* out[j] = sum_s slab[s*stride + j], j < n.  i[0]=n i[1]=nsplit i[2]=stride. buf: 0 SLAB 1 OUT */
+  HP_OP_SLAB_REDUCE = 3,
+  /* nn.BatchNorm1d forward (+ residual + leaky_relu): backbones.py:36-41,65-70,95;
+   * model.py:23-27,39-40.   out = act(scale*raw + shift + res)
+   * training: mean/var from STATS (sum, sumsq) over M rows; saves (mean, invstd);
+   * updates running stats (momentum, unbiased var).  eval: running stats.
+   * i[0]=M i[1]=C i[2]=res_mode(0 none,1 tensor,2 second BN) i[3]=training i[4]=act
+   * f[0]=slope f[1]=eps f[2]=momentum
+   * buf: 0 RAW 1 OUT 2 STATS 3 GAMMA 4 BETA 5 RMEAN 6 RVAR 7 SAVE(float[2][C])
+   *      8 RES(tensor or second raw) 9 STATS2 10 GAMMA2 11 BETA2 12 RMEAN2 13 RVAR2 14 SAVE2 */
+  HP_OP_BN_APPLY = 4,
+  /* g = (G1 [+ G2]) * leaky_relu'(ACT);  BS[0][c] += sum g;  BS[1][c] += sum g*xhat
+   * (xhat = (raw-mean)*invstd), optionally for a second BN fed by the same g.
+   * First half of ATen native_batch_norm_backward + leaky_relu_backward + residual fan-out.
+   * i[0]=M i[1]=C i[2]=has_g2 i[3]=has_second  f[0]=slope
+   * buf: 0 G1 1 G2 2 ACT 3 GOUT 4 RAW 5 SAVE 6 BS(double[2][C]) 7 RAW2 8 SAVE2 9 BS2 */
+  HP_OP_BN_BWD_REDUCE = 5,
+  /* dr = gamma*invstd*(g - BS0/M - xhat*BS1/M);  dgamma = BS1;  dbeta = BS0.
+   * i[0]=M i[1]=C.  buf: 0 G 1 RAW 2 SAVE 3 BS 4 GAMMA 5 DR 6 DGAMMA 7 DBETA */
+  HP_OP_BN_BWD_APPLY = 6,
+  /* encoder stem Conv1d(1,64,k3,s2,p1) (backbones.py:78,95): raw[b*Lout+l][n] =
+   * sum_t x[b][2l+t-1]*W[n][t] (+stats).  i[0]=B i[1]=Lin i[2]=Lout i[3]=C
+   * buf: 0 X 1 W 2 OUT 3 STATS */
+  HP_OP_STEM_FWD = 7,
+  /* dW[n][t] = sum_{b,l} DR[b*Lout+l][n]*x[b][2l+t-1].  buf: 0 DR 1 X 2 DW */
+  HP_OP_STEM_WGRAD = 8,
+  /* adaptive_avg_pool1d(x,1) (backbones.py:100): out[b][c] = mean_l in[b*L+l][c]
+   * i[0]=B i[1]=L i[2]=C.  buf: 0 IN 1 OUT */
+  HP_OP_POOL_FWD = 9,
+  /* G[b*L+l][c] = d[b][c]/L.  buf: 0 D 1 G */
+  HP_OP_POOL_BWD = 10,
+  /* F.interpolate(x.unsqueeze(-1), scale_factor=4) (backbones.py:130-131):
+   * out[b*R+l][c] = in[b][c].  i[0]=B i[1]=R i[2]=C.  buf: 0 IN 1 OUT */
+  HP_OP_REPEAT_FWD = 11,
+  /* d[b][c] = sum_l (G1 [+G2])[b*R+l][c].  i[3]=has_g2.  buf: 0 G1 1 G2 2 D */
+  HP_OP_REPEAT_BWD = 12,
+  /* torch.cat([...], dim=1) with nn.Embedding gathers (model.py:53,60,65-66).
+   * up to 4 segments j: kind i[4+3j] (0 dense, 1 embedding rows, 2 zeros), width
+   * i[5+3j], ld i[6+3j].  i[0]=B i[1]=nseg i[2]=ldo.
+   * buf: 0 OUT; 1+2j SRC/TABLE; 2+2j IDX(int64) */
+  HP_OP_CONCAT = 13,
+  /* embedding gradient: DT[idx[b]][k] += D[b*ld + col0 + k] (fp32 atomics).
+   * i[0]=B i[1]=w i[2]=ld i[3]=col0.  buf: 0 D 1 IDX 2 DT */
+  HP_OP_EMB_BWD = 14,
+  /* nn.Linear (model.py:21-41, backbones.py:84,102,111,118,129,138):
+   * Y[m*ldy+n] = act(sum_k X[m*ldx+k]*W[n*K+k] + b[n]) (+stats on the pre-activation).
+   * i[0]=M i[1]=N i[2]=K i[3]=ldx i[4]=ldy i[5]=act i[6]=stats  f[0]=slope
+   * buf: 0 X 1 W 2 B 3 Y 4 STATS */
+  HP_OP_LINEAR_FWD = 15,
+  /* DX[m*ldx+k] (+)= (sum_n DY[m*ldy+n]*W[n*K+k]) * [leaky_relu'(ACT[m*lda+k])]
+   * i[0]=M i[1]=N i[2]=K i[3]=ldy i[4]=ldx i[5]=has_mask i[6]=lda i[7]=accumulate
+   * f[0]=slope.  buf: 0 DY 1 W 2 DX 3 ACT */
+  HP_OP_LINEAR_BWD_X = 16,
+  /* DW[n*K+k] = sum_m DY[m*ldy+n]*X[m*ldx+k];  DB[n] = sum_m DY[m*ldy+n].
+   * i[0]=M i[1]=N i[2]=K i[3]=ldy i[4]=ldx.  buf: 0 DY 1 X 2 DW 3 DB */
+  HP_OP_LINEAR_BWD_W = 17,
+  /* reparameterize + KL (model.py:46-49,104): z = mu + eps*exp(0.5*lv);
+   * LOSS[0] += sum_i -0.5*sum_j(1+lv-mu^2-exp(lv)).  MULV is [B][2z] = (mu | lv).
+   * i[0]=B i[1]=z.  buf: 0 MULV 1 EPS 2 Z 3 LOSS(double[4]) */
+  HP_OP_REPARAM_KL_FWD = 18,
+  /* dmu = dz + beta*mu/B;  dlv = dz*eps*0.5*exp(0.5 lv) + beta*0.5*(exp(lv)-1)/B.
+   * i[0]=B i[1]=z i[2]=ld of DZ.  f[0]=beta.  buf: 0 MULV 1 EPS 2 DZ 3 DMULV */
+  HP_OP_REPARAM_KL_BWD = 19,
+  /* F.mse_loss(data, dec) (model.py:103) + its gradient:
+   * LOSS[slot] += sum (x-rec)^2;  DREC = w*2*(rec-x)/n.  i[0]=n i[1]=slot f[0]=w
+   * buf: 0 X 1 REC 2 DREC 3 LOSS */
+  HP_OP_MSE_FWD_BWD = 20,
+  /* decoder tail ResizeConv1d(64,1,k3,scale2) (backbones.py:117,136):
+   * t[b][p] = bias + sum_t sum_c act[b*Lh + ((p+t-1)>>1)][c]*W[c*3+t], 0<=p+t-1<2Lh.
+   * i[0]=B i[1]=Lh i[2]=C.  buf: 0 ACT 1 W 2 BIAS 3 OUT */
+  HP_OP_TAIL_FWD = 21,
+  /* buf: 0 DT 1 W 2 DACT */
+  HP_OP_TAIL_BWD_X = 22,
+  /* buf: 0 DT 1 ACT 2 DW 3 DB */
+  HP_OP_TAIL_BWD_W = 23,
+  /* training_step scalars (model.py:103-113, 465-479): OUT[0]=loss OUT[1]=mse1 OUT[2]=mse2
+   * OUT[3]=kl_mean.  i[0]=B i[1]=n1 i[2]=n2 f[0]=beta f[1]=w1 f[2]=w2
+   * buf: 0 LOSS(double[4]) 1 OUT(float[4]) */
+  HP_OP_LOSS_FINALIZE = 24,
+  /* NORM2[0] += sum g^2 (fp64).  i[0]=n.  buf: 0 G 1 NORM2(double[1]) */
+  HP_OP_GRADNORM = 25,
+  /* torch.optim.AdamW step (model.py:93) with optional clip_grad_norm_ scale folded in.
+   * step count t is read from STEP (int64, incremented by HP_OP_STEP_INC).
+   * i[0]=n  f: 0 lr 1 beta1 2 beta2 3 eps 4 weight_decay 5 clip(0 = off)
+   * buf: 0 P 1 G 2 M 3 V 4 STEP(int64[1]) 5 NORM2(double[1]) */
+  HP_OP_ADAMW = 26,
+  /* STEP[0] += 1.  buf: 0 STEP */
+  HP_OP_STEP_INC = 27,
+  /* memset(dst, 0, i[0] bytes).  buf: 0 DST */
+  HP_OP_ZERO = 28,
+  HP_OP__COUNT
+};
+
+typedef struct HpProgram HpProgram;
+
+/* Library / device info. */
+int hp_abi_version(void);
+const char* hp_last_error(void);
+/* Writes CU count, XCD count (8), wave size and the gfx arch name of the current device. */
+int hp_device_info(int* n_cu, int* wave_size, char* arch, int arch_len);
+
+/* Program lifecycle.  ops are copied; bases are the six arena base pointers. */
+int hp_program_create(const HpOp* ops, int n_ops, void* const bases[HP_NUM_SPACES],
+                      const int64_t sizes[HP_NUM_SPACES], HpProgram** out);
+int hp_program_destroy(HpProgram* p);
+/* Validate every op (opcode, sizes, buffer ranges against arena sizes).  No GPU needed. */
+int hp_program_validate(const HpProgram* p);
+/* Enqueue ops [first, first+count) on `stream` (a hipStream_t; NULL = default stream). */
+int hp_program_run(HpProgram* p, int first, int count, void* stream);
+/* Capture ops [first, first+count) into a hipGraph (segment id returned in *seg);
+ * hp_program_replay launches the captured graph on `stream`. */
+int hp_program_capture(HpProgram* p, int first, int count, int* seg);
+int hp_program_replay(HpProgram* p, int seg, void* stream);
+/* Time ops one by one with HIP events on `stream` (ms per op into out_ms[n]); synchronises. */
+int hp_program_profile(HpProgram* p, int first, int count, void* stream, float* out_ms);
+
+/* Single-op launch without a program (unit tests, benchmarks). */
+int hp_run_op(const HpOp* op, void* const bases[HP_NUM_SPACES], void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPPIE_HIP_H */

@@ -1,0 +1,354 @@
+"""numpy interpreter of HpOp programs — TEST INFRASTRUCTURE ONLY (never imported by hippie_amd).
+
+An executable restatement of the op semantics documented in include/hippie_hip.h.
+tests/ run the planner's program through it on the CPU and compare with the
+torch oracle (oracle/cvae_oracle.py), which is itself pinned to the reference by
+tests/golden/.  That validates the host-side lowering (arena layout, tap maps,
+backward wiring) without a GPU; the GPU tests then compare each HIP kernel with
+these same semantics.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+NULL = -1
+MASK = (1 << 56) - 1
+
+
+class Arenas:
+    def __init__(self, sizes):
+        self.mem = [np.zeros(int(s), dtype=np.uint8) for s in sizes]
+
+    def view(self, ref, dtype, count):
+        ref = int(ref)
+        if ref == NULL:
+            return None
+        sp, off = ref >> 56, ref & MASK
+        nb = np.dtype(dtype).itemsize * int(count)
+        assert off + nb <= self.mem[sp].size, (sp, off, nb, self.mem[sp].size)
+        return self.mem[sp][off: off + nb].view(dtype)
+
+    def f32(self, ref, n):
+        return self.view(ref, np.float32, n)
+
+    def f64(self, ref, n):
+        return self.view(ref, np.float64, n)
+
+    def i64(self, ref, n):
+        return self.view(ref, np.int64, n)
+
+
+def _tapmap(i):
+    M, N, K, Lout, Lin, Pb, a, sh, even, nt = [int(v) for v in i[:10]]
+    taps = [(int(i[10 + j]), int(i[16 + j])) for j in range(nt)]
+    return M, N, K, Lout, Lin, Pb, a, sh, even, taps
+
+
+def _src_rows(M, Lout, Lin, Pb, a, sh, even, off):
+    m = np.arange(M)
+    b, l = m // Lout, m % Lout
+    pos = a * l + off
+    ok = (pos >= 0) & (pos < Pb)
+    if even:
+        ok &= (pos % 2 == 0)
+    src = b * Lin + (np.where(ok, pos, 0) >> sh)
+    return src, ok
+
+
+def _lrelu(x, s):
+    return np.where(x > 0, x, x * np.float32(s)).astype(np.float32)
+
+
+def _lrelu_grad(out, s):
+    return np.where(out > 0, np.float32(1), np.float32(s)).astype(np.float32)
+
+
+def _bn_coef(A, training, M, C, stats, gamma, beta, rmean, rvar, eps):
+    if training:
+        st = A.f64(stats, 2 * C)
+        mean = st[:C] / M
+        var = np.maximum(st[C:] / M - mean * mean, 0.0)
+    else:
+        mean = A.f32(rmean, C).astype(np.float64)
+        var = A.f32(rvar, C).astype(np.float64)
+    invstd = 1.0 / np.sqrt(var + np.float64(np.float32(eps)))
+    g = A.f32(gamma, C).astype(np.float64)
+    sc = g * invstd
+    sh = A.f32(beta, C).astype(np.float64) - mean * sc
+    return mean, var, invstd, sc.astype(np.float32), sh.astype(np.float32)
+
+
+def _bn_side(A, M, C, mean, var, invstd, save, rmean, rvar, mom):
+    sv = A.f32(save, 2 * C)
+    sv[:C] = mean.astype(np.float32)
+    sv[C:] = invstd.astype(np.float32)
+    unb = var * M / (M - 1) if M > 1 else var
+    rm, rv = A.f32(rmean, C), A.f32(rvar, C)
+    mom = np.float64(np.float32(mom))
+    rm[:] = ((1 - mom) * rm.astype(np.float64) + mom * mean.astype(np.float32).astype(np.float64)).astype(np.float32)
+    rv[:] = ((1 - mom) * rv.astype(np.float64) + mom * unb).astype(np.float32)
+
+
+def run(ops, A: Arenas, first=0, count=None):
+    count = len(ops) - first if count is None else count
+    for r in ops[first: first + count]:
+        op, flags, i, f, b = int(r["op"]), int(r["flags"]), r["i"], r["f"], r["buf"]
+        if op == 1:      # CONV_TAPS
+            M, N, K, Lout, Lin, Pb, a, sh, even, taps = _tapmap(i)
+            nin = (M // Lout) * Lin
+            X = A.f32(b[0], nin * K).reshape(nin, K)
+            nslab = max(w for _, w in taps) + 1
+            W = A.f32(b[1], nslab * N * K)
+            acc = np.zeros((M, N), dtype=np.float64)
+            for off, w in taps:
+                src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, even, off)
+                Ag = np.where(ok[:, None], X[src], 0).astype(np.float64)
+                Ws = W[w * N * K: (w + 1) * N * K]
+                Wm = Ws.reshape(K, N) if flags & 1 else Ws.reshape(N, K).T
+                acc += Ag @ Wm.astype(np.float64)
+            out = acc.astype(np.float32)
+            if flags & 2:
+                out = out + A.f32(b[3], N)[None, :]
+            A.f32(b[2], M * N)[:] = out.reshape(-1)
+            if flags & 4:
+                st = A.f64(b[4], 2 * N)
+                st[:N] += out.astype(np.float64).sum(0)
+                st[N:] += (out.astype(np.float64) ** 2).sum(0)
+        elif op == 2:    # WGRAD_TAPS
+            M, N, K, Lout, Lin, Pb, a, sh, even, taps = _tapmap(i)
+            nsplit, rps, stride = int(i[22]), int(i[23]), int(i[24])
+            nin = (M // Lout) * Lin
+            DY = A.f32(b[0], M * N).reshape(M, N).astype(np.float64)
+            X = A.f32(b[1], nin * K).reshape(nin, K)
+            slab = A.f32(b[2], nsplit * stride)
+            slab[:] = 0  # the kernel writes every tile of every split it owns
+            for s in range(nsplit):
+                lo, hi = s * rps, min(M, (s + 1) * rps)
+                for off, w in taps:
+                    src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, even, off)
+                    Xg = np.where(ok[:, None], X[src], 0).astype(np.float64)
+                    part = DY[lo:hi].T @ Xg[lo:hi]
+                    slab[s * stride + w * N * K: s * stride + (w + 1) * N * K] = part.astype(np.float32).reshape(-1)
+        elif op == 3:    # SLAB_REDUCE
+            n, nsplit, stride = int(i[0]), int(i[1]), int(i[2])
+            slab = A.f32(b[0], nsplit * stride)
+            out = A.f32(b[1], n)
+            acc = slab[:n].copy()
+            for s in range(1, nsplit):
+                acc = acc + slab[s * stride: s * stride + n]
+            out[:] = acc
+        elif op == 4:    # BN_APPLY
+            M, C, res_mode, training, act = [int(v) for v in i[:5]]
+            slope, eps, mom = f[0], f[1], f[2]
+            raw = A.f32(b[0], M * C).reshape(M, C)
+            mean, var, invstd, sc, sh = _bn_coef(A, training, M, C, b[2], b[3], b[4], b[5], b[6], eps)
+            v = raw * sc[None, :] + sh[None, :]
+            if res_mode == 1:
+                v = v + A.f32(b[8], M * C).reshape(M, C)
+            elif res_mode == 2:
+                mean2, var2, invstd2, sc2, sh2 = _bn_coef(A, training, M, C, b[9], b[10], b[11], b[12], b[13], eps)
+                v = v + (A.f32(b[8], M * C).reshape(M, C) * sc2[None, :] + sh2[None, :])
+            if act:
+                v = _lrelu(v, slope)
+            A.f32(b[1], M * C)[:] = v.astype(np.float32).reshape(-1)
+            if training:
+                _bn_side(A, M, C, mean, var, invstd, b[7], b[5], b[6], mom)
+                if res_mode == 2:
+                    _bn_side(A, M, C, mean2, var2, invstd2, b[14], b[12], b[13], mom)
+        elif op == 5:    # BN_BWD_REDUCE
+            M, C, has_g2, has_second = [int(v) for v in i[:4]]
+            g = A.f32(b[0], M * C).reshape(M, C).copy()
+            if has_g2:
+                g = g + A.f32(b[1], M * C).reshape(M, C)
+            g = (g * _lrelu_grad(A.f32(b[2], M * C).reshape(M, C), f[0])).astype(np.float32)
+            A.f32(b[3], M * C)[:] = g.reshape(-1)
+            for (raw_r, save_r, bs_r) in ([(b[4], b[5], b[6])] + ([(b[7], b[8], b[9])] if has_second else [])):
+                raw = A.f32(raw_r, M * C).reshape(M, C)
+                sv = A.f32(save_r, 2 * C)
+                xh = ((raw - sv[None, :C]) * sv[None, C:]).astype(np.float32)
+                bs = A.f64(bs_r, 2 * C)
+                bs[:C] += g.astype(np.float64).sum(0)
+                bs[C:] += (g.astype(np.float64) * xh.astype(np.float64)).sum(0)
+        elif op == 6:    # BN_BWD_APPLY
+            M, C = int(i[0]), int(i[1])
+            g = A.f32(b[0], M * C).reshape(M, C)
+            raw = A.f32(b[1], M * C).reshape(M, C)
+            sv = A.f32(b[2], 2 * C)
+            bs = A.f64(b[3], 2 * C)
+            gamma = A.f32(b[4], C)
+            xh = (raw - sv[None, :C]) * sv[None, C:]
+            c1 = (bs[:C] / M).astype(np.float32)
+            c2 = (bs[C:] / M).astype(np.float32)
+            A.f32(b[5], M * C)[:] = ((gamma * sv[C:])[None, :] * (g - c1[None, :] - xh * c2[None, :])).astype(np.float32).reshape(-1)
+            A.f32(b[6], C)[:] = bs[C:].astype(np.float32)
+            A.f32(b[7], C)[:] = bs[:C].astype(np.float32)
+        elif op in (7, 8):    # STEM_FWD / STEM_WGRAD
+            B, Lin, Lout, C = [int(v) for v in i[:4]]
+            xr = b[0] if op == 7 else b[1]
+            x = A.f32(xr, B * Lin).reshape(B, Lin)
+            xp = np.pad(x, ((0, 0), (1, 2)))
+            cols = np.stack([xp[:, 2 * np.arange(Lout) + t] for t in range(3)], axis=-1)   # [B, Lout, 3]
+            if op == 7:
+                W = A.f32(b[1], C * 3).reshape(C, 3)
+                out = (cols.reshape(B * Lout, 3).astype(np.float64) @ W.T.astype(np.float64)).astype(np.float32)
+                A.f32(b[2], B * Lout * C)[:] = out.reshape(-1)
+                if int(b[3]) != NULL:
+                    st = A.f64(b[3], 2 * C)
+                    st[:C] += out.astype(np.float64).sum(0)
+                    st[C:] += (out.astype(np.float64) ** 2).sum(0)
+            else:
+                dr = A.f32(b[0], B * Lout * C).reshape(B * Lout, C).astype(np.float64)
+                A.f32(b[2], C * 3)[:] += (dr.T @ cols.reshape(B * Lout, 3).astype(np.float64)).astype(np.float32).reshape(-1)
+        elif op == 9:    # POOL_FWD
+            B, L, C = [int(v) for v in i[:3]]
+            A.f32(b[1], B * C)[:] = (A.f32(b[0], B * L * C).reshape(B, L, C).sum(1) / np.float32(L)).reshape(-1)
+        elif op == 10:   # POOL_BWD
+            B, L, C = [int(v) for v in i[:3]]
+            d = A.f32(b[0], B * C).reshape(B, 1, C) / np.float32(L)
+            A.f32(b[1], B * L * C)[:] = np.broadcast_to(d, (B, L, C)).reshape(-1)
+        elif op == 11:   # REPEAT_FWD
+            B, R, C = [int(v) for v in i[:3]]
+            A.f32(b[1], B * R * C)[:] = np.broadcast_to(A.f32(b[0], B * C).reshape(B, 1, C), (B, R, C)).reshape(-1)
+        elif op == 12:   # REPEAT_BWD
+            B, R, C, has_g2 = [int(v) for v in i[:4]]
+            g = A.f32(b[0], B * R * C).reshape(B, R, C).copy()
+            if has_g2:
+                g = g + A.f32(b[1], B * R * C).reshape(B, R, C)
+            A.f32(b[2], B * C)[:] = g.sum(1).reshape(-1)
+        elif op == 13:   # CONCAT
+            B, nseg, ldo = int(i[0]), int(i[1]), int(i[2])
+            out = A.f32(b[0], B * ldo).reshape(B, ldo)
+            col = 0
+            for j in range(nseg):
+                kind, w, ld = int(i[4 + 3 * j]), int(i[5 + 3 * j]), int(i[6 + 3 * j])
+                if kind == 0:
+                    out[:, col: col + w] = A.f32(b[1 + 2 * j], B * ld).reshape(B, ld)[:, :w]
+                elif kind == 1:
+                    idx = A.i64(b[2 + 2 * j], B)
+                    tab = A.f32(b[1 + 2 * j], (int(idx.max()) + 1) * ld).reshape(-1, ld)
+                    out[:, col: col + w] = tab[idx][:, :w]
+                else:
+                    out[:, col: col + w] = 0
+                col += w
+            assert col == ldo
+        elif op == 14:   # EMB_BWD
+            B, w, ld, col0 = [int(v) for v in i[:4]]
+            d = A.f32(b[0], B * ld).reshape(B, ld)[:, col0: col0 + w]
+            idx = A.i64(b[1], B)
+            dt = A.f32(b[2], (int(idx.max()) + 1) * w).reshape(-1, w)
+            np.add.at(dt, idx, d)
+        elif op == 15:   # LINEAR_FWD
+            M, N, K, ldx, ldy, act, stats = [int(v) for v in i[:7]]
+            X = A.f32(b[0], (M - 1) * ldx + K)
+            Xm = np.lib.stride_tricks.as_strided(X, (M, K), (ldx * 4, 4))
+            W = A.f32(b[1], N * K).reshape(N, K)
+            y = (Xm.astype(np.float64) @ W.T.astype(np.float64)).astype(np.float32)
+            if int(b[2]) != NULL:
+                y = y + A.f32(b[2], N)[None, :]
+            if stats:
+                st = A.f64(b[4], 2 * N)
+                st[:N] += y.astype(np.float64).sum(0)
+                st[N:] += (y.astype(np.float64) ** 2).sum(0)
+            if act:
+                y = _lrelu(y, f[0])
+            Y = A.f32(b[3], (M - 1) * ldy + N)
+            np.lib.stride_tricks.as_strided(Y, (M, N), (ldy * 4, 4))[:] = y
+        elif op == 16:   # LINEAR_BWD_X
+            M, N, K, ldy, ldx, has_mask, lda, accum = [int(v) for v in i[:8]]
+            DY = np.lib.stride_tricks.as_strided(A.f32(b[0], (M - 1) * ldy + N), (M, N), (ldy * 4, 4))
+            W = A.f32(b[1], N * K).reshape(N, K)
+            dx = (DY.astype(np.float64) @ W.astype(np.float64)).astype(np.float32)
+            if has_mask:
+                act = np.lib.stride_tricks.as_strided(A.f32(b[3], (M - 1) * lda + K), (M, K), (lda * 4, 4))
+                dx = dx * _lrelu_grad(act, f[0])
+            DX = np.lib.stride_tricks.as_strided(A.f32(b[2], (M - 1) * ldx + K), (M, K), (ldx * 4, 4))
+            if accum:
+                DX[:] = DX + dx
+            else:
+                DX[:] = dx
+        elif op == 17:   # LINEAR_BWD_W
+            M, N, K, ldy, ldx = [int(v) for v in i[:5]]
+            DY = np.lib.stride_tricks.as_strided(A.f32(b[0], (M - 1) * ldy + N), (M, N), (ldy * 4, 4)).astype(np.float64)
+            X = np.lib.stride_tricks.as_strided(A.f32(b[1], (M - 1) * ldx + K), (M, K), (ldx * 4, 4)).astype(np.float64)
+            A.f32(b[2], N * K)[:] += (DY.T @ X).astype(np.float32).reshape(-1)
+            if int(b[3]) != NULL:
+                A.f32(b[3], N)[:] += DY.sum(0).astype(np.float32)
+        elif op == 18:   # REPARAM_KL_FWD
+            B, z = int(i[0]), int(i[1])
+            mulv = A.f32(b[0], B * 2 * z).reshape(B, 2 * z)
+            mu, lv = mulv[:, :z], mulv[:, z:]
+            eps = A.f32(b[1], B * z).reshape(B, z)
+            A.f32(b[2], B * z)[:] = (mu + eps * np.exp(np.float32(0.5) * lv)).astype(np.float32).reshape(-1)
+            A.f64(b[3], 4)[0] += float((-0.5 * (1 + lv - mu * mu - np.exp(lv)).astype(np.float64)).sum())
+        elif op == 19:   # REPARAM_KL_BWD
+            B, z, ld = int(i[0]), int(i[1]), int(i[2])
+            beta = np.float32(f[0])
+            mulv = A.f32(b[0], B * 2 * z).reshape(B, 2 * z)
+            mu, lv = mulv[:, :z], mulv[:, z:]
+            eps = A.f32(b[1], B * z).reshape(B, z)
+            dz = np.lib.stride_tricks.as_strided(A.f32(b[2], (B - 1) * ld + z), (B, z), (ld * 4, 4))
+            out = A.f32(b[3], B * 2 * z).reshape(B, 2 * z)
+            out[:, :z] = dz + beta * mu / np.float32(B)
+            out[:, z:] = dz * eps * np.float32(0.5) * np.exp(np.float32(0.5) * lv) + beta * np.float32(0.5) * (np.exp(lv) - 1) / np.float32(B)
+        elif op == 20:   # MSE_FWD_BWD
+            n, slot = int(i[0]), int(i[1])
+            x, rec = A.f32(b[0], n), A.f32(b[1], n)
+            d = rec - x
+            A.f64(b[3], 4)[slot] += float((d.astype(np.float64) ** 2).sum())
+            A.f32(b[2], n)[:] = np.float32(f[0]) * np.float32(2) * d / np.float32(n)
+        elif op in (21, 22, 23):   # TAIL ops
+            B, Lh, C = [int(v) for v in i[:3]]
+            Lo = 2 * Lh
+            if op == 21:
+                act = A.f32(b[0], B * Lh * C).reshape(B, Lh, C)
+                W = A.f32(b[1], C * 3).reshape(C, 3).astype(np.float64)
+                up = np.pad(np.repeat(act, 2, axis=1), ((0, 0), (1, 1), (0, 0))).astype(np.float64)   # [B, Lo+2, C]
+                out = sum(up[:, t: t + Lo, :] @ W[:, t] for t in range(3)) + float(A.f32(b[2], 1)[0])
+                A.f32(b[3], B * Lo)[:] = out.astype(np.float32).reshape(-1)
+            elif op == 22:
+                dt = np.pad(A.f32(b[0], B * Lo).reshape(B, Lo), ((0, 0), (2, 2))).astype(np.float64)
+                W = A.f32(b[1], C * 3).reshape(C, 3).astype(np.float64)
+                dup = sum(dt[:, 2 + 1 - t: 2 + 1 - t + Lo, None] * W[None, None, :, t] for t in range(3))   # [B, Lo, C]
+                A.f32(b[2], B * Lh * C)[:] = (dup[:, 0::2] + dup[:, 1::2]).astype(np.float32).reshape(-1)
+            else:
+                dt = A.f32(b[0], B * Lo).reshape(B, Lo).astype(np.float64)
+                act = A.f32(b[1], B * Lh * C).reshape(B, Lh, C)
+                up = np.pad(np.repeat(act, 2, axis=1), ((0, 0), (1, 1), (0, 0))).astype(np.float64)
+                dw = np.stack([np.einsum("bp,bpc->c", dt, up[:, t: t + Lo, :]) for t in range(3)], axis=1)   # [C,3]
+                A.f32(b[2], C * 3)[:] += dw.astype(np.float32).reshape(-1)
+                A.f32(b[3], 1)[0] += np.float32(dt.sum())
+        elif op == 24:   # LOSS_FINALIZE
+            B, n1, n2 = int(i[0]), int(i[1]), int(i[2])
+            L = A.f64(b[0], 4)
+            kl, m1 = L[0] / B, L[1] / n1
+            m2 = L[2] / n2 if n2 > 0 else 0.0
+            out = A.f32(b[1], 4)
+            out[0] = np.float32(float(f[1]) * m1 + float(f[2]) * m2 + float(f[0]) * kl)
+            out[1], out[2], out[3] = np.float32(m1), np.float32(m2), np.float32(kl)
+        elif op == 25:   # GRADNORM
+            n = int(i[0])
+            A.f64(b[1], 1)[0] += float((A.f32(b[0], n).astype(np.float64) ** 2).sum())
+        elif op == 26:   # ADAMW
+            n = int(i[0])
+            lr, b1, b2, eps, wd, clip = [np.float32(v) for v in f[:6]]
+            p, g, m, v = A.f32(b[0], n), A.f32(b[1], n), A.f32(b[2], n), A.f32(b[3], n)
+            t = float(A.i64(b[4], 1)[0])
+            bc1 = 1.0 - float(b1) ** t
+            bc2 = 1.0 - float(b2) ** t
+            coef = np.float32(1)
+            if clip > 0:
+                c = clip / (np.float32(np.sqrt(A.f64(b[5], 1)[0])) + np.float32(1e-6))
+                coef = min(c, np.float32(1))
+            gg = (g * coef).astype(np.float32)
+            p[:] = p * (np.float32(1) - lr * wd)
+            m[:] = m + (np.float32(1) - b1) * (gg - m)
+            v[:] = v * b2 + (np.float32(1) - b2) * gg * gg
+            denom = np.sqrt(v) / np.float32(np.sqrt(bc2)) + eps
+            p[:] = p - np.float32(float(lr) / bc1) * (m / denom)
+        elif op == 27:   # STEP_INC
+            A.i64(b[0], 1)[0] += 1
+        elif op == 28:   # ZERO
+            nb = int(np.uint32(i[0])) + (int(np.uint32(i[1])) << 32)
+            A.view(b[0], np.uint8, nb)[:] = 0
+        else:
+            raise ValueError(f"unknown opcode {op}")

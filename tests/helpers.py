@@ -1,0 +1,107 @@
+"""Shared test helpers: numpy arena <-> state_dict conversion for planner programs."""
+import numpy as np
+import torch
+
+from hippie_amd import planner, program as P
+from oracle import cvae_oracle as O
+from oracle import interp
+
+
+def to_arena_layout(info, value):
+    v = np.asarray(value, dtype=np.float32)
+    if info.layout == "tnc":
+        v = np.transpose(v, (2, 0, 1))     # [Cout,Cin,3] -> [3,Cout,Cin]
+    return np.ascontiguousarray(v).reshape(-1)
+
+
+def from_arena_layout(info, flat):
+    if info.layout == "tnc":
+        co, ci, k = info.shape
+        return np.transpose(flat.reshape(k, co, ci), (1, 2, 0))
+    return flat.reshape(info.shape)
+
+
+def make_arenas(plan):
+    n = plan.n_param_floats * 4
+    return interp.Arenas([plan.ws_bytes, n, n, plan.n_buf_floats * 4, n, n])
+
+
+def load_state(plan, A, state):
+    p = A.mem[P.PARAM].view(np.float32)
+    for k, info in plan.params.items():
+        p[info.offset: info.offset + info.numel] = to_arena_layout(info, state[k].detach().numpy())
+    bf = A.mem[P.BUF].view(np.float32)
+    for k, info in plan.bufs.items():
+        bf[info.offset: info.offset + info.numel] = state[k].detach().numpy().astype(np.float32)
+
+
+def read_params(plan, A, space=P.PARAM):
+    p = A.mem[space].view(np.float32)
+    return {k: from_arena_layout(info, p[info.offset: info.offset + info.numel].copy()) for k, info in plan.params.items()}
+
+
+def read_bufs(plan, A):
+    bf = A.mem[P.BUF].view(np.float32)
+    return {k: bf[info.offset: info.offset + info.numel].copy() for k, info in plan.bufs.items()}
+
+
+def set_io(plan, A, name, value):
+    ref, shape, dt = plan.io[name]
+    arr = np.ascontiguousarray(np.asarray(value)).astype(np.float32 if dt == "f4" else np.int64).reshape(-1)
+    A.view(ref.encode(), arr.dtype, arr.size)[:] = arr
+
+
+def get_io(plan, A, name):
+    ref, shape, dt = plan.io[name]
+    n = int(np.prod(shape))
+    return A.view(ref.encode(), np.float32 if dt == "f4" else np.int64, n).reshape(shape).copy()
+
+
+ZERO_GRAD_RE = (r"(encoder(_mod\d)?\.linear\.bias|encoder_fc\.[03]\.bias|fusion_encoder\.0\.bias|"
+                r"decoder_fc(_mod\d)?\.2\.bias|layer\d\.1\.(conv1|shortcut\.0)\.conv\.bias)$")
+
+
+def assert_close(actual, desired, rel=1e-4, msg=""):
+    """max|a-b| <= rel * max|b|  (the north-star's "1e-4 relative" read per tensor)."""
+    a = np.asarray(actual, dtype=np.float64)
+    d = np.asarray(desired, dtype=np.float64)
+    assert a.shape == d.shape, (msg, a.shape, d.shape)
+    scale = max(np.abs(d).max(), 1e-30)
+    err = np.abs(a - d).max() / scale
+    assert np.isfinite(a).all() and err <= rel, f"{msg}: rel err {err:.3e} > {rel:.1e} (scale {scale:.3e})"
+    return err
+
+
+def assert_adam_close(actual, desired, lr, msg="", grad=None, steps=1):
+    """Parameters after Adam steps.  Adam's update is lr * m/(sqrt(v)+eps) ~ lr * sign(g) early on, so an
+    element whose gradient is at rounding-noise level (analytically zero: e.g. a bias in front of a
+    BatchNorm, or a channel whose leaky-ReLU never changes sign in a tiny batch) may legitimately differ
+    by up to 2*lr per step.  Elements with a significant reference gradient must agree to 1e-4 relative."""
+    a = np.asarray(actual, dtype=np.float64).reshape(-1)
+    d = np.asarray(desired, dtype=np.float64).reshape(-1)
+    diff = np.abs(a - d)
+    assert diff.max() <= 2.2 * lr * steps + 1e-7, f"{msg}: max diff {diff.max():.3e} > 2.2*lr*steps"
+    bad = diff > (1e-4 * np.abs(d) + 0.02 * lr)
+    if grad is not None:
+        g = np.abs(np.asarray(grad, dtype=np.float64).reshape(-1))
+        bad &= g > 1e-2 * max(g.max(), 1e-30)
+        assert not bad.any(), f"{msg}: {bad.sum()} of {bad.size} elements with significant gradient differ"
+    else:
+        assert bad.mean() <= 2e-3, f"{msg}: {bad.sum()} of {bad.size} elements off by more than noise"
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def parity(mine, ref32, ref64, msg="", rel=1e-4, slack=3.0):
+    """Parity criterion used throughout: `mine` must be within `rel` of the float64 oracle, or — where
+    the problem is so ill-conditioned (tiny batch statistics) that the reference's own float32 path is
+    further than that from the float64 truth — at least within `slack` x the reference's own error."""
+    e_mine = relerr(mine, ref64)
+    e_ref = relerr(ref32, ref64)
+    assert np.isfinite(np.asarray(mine, dtype=np.float64)).all(), msg
+    assert e_mine <= max(rel, slack * e_ref), f"{msg}: err vs f64 oracle {e_mine:.3e} (reference f32 path: {e_ref:.3e})"
+    return e_mine, e_ref

@@ -1,0 +1,129 @@
+"""Host-side lowering (hippie_amd.planner) executed by the numpy op interpreter must equal the
+torch oracle: forward outputs, loss scalars, every gradient, one AdamW step, BN running stats."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from hippie_amd import planner, program as P
+from oracle import cvae_oracle as O
+from oracle import interp
+from tests import helpers as H
+
+torch.set_num_threads(4)
+
+
+def run_case(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0):
+    cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=L, output_size2=L2 or 100)
+    tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2)
+    plan = planner.lower(cfg, B, tc, with_class=with_class)
+    ops = plan.ops.array()
+    A = H.make_arenas(plan)
+    om = O.OracleModel(kind, z, L, output_size2=L2, salt=salt)
+    H.load_state(plan, A, om.state)
+    if kind == "unimodal":
+        x, src, cls, eps = O.synth_inputs(B, L, z, salt=salt)
+        batch = (x, src, cls if with_class else None)
+        H.set_io(plan, A, "x", x.numpy())
+    else:
+        x, src, cls, eps = O.synth_inputs(B, L, z, salt=salt, name="x1")
+        x2, _, _, _ = O.synth_inputs(B, L2, z, salt=salt, name="x2")
+        batch = (x, x2, src, cls if with_class else None)
+        H.set_io(plan, A, "x", x.numpy())
+        H.set_io(plan, A, "x2", x2.numpy())
+    H.set_io(plan, A, "src", src.numpy())
+    H.set_io(plan, A, "cls", cls.numpy())
+    H.set_io(plan, A, "eps", eps.numpy())
+
+    # float64 twin of the oracle: the yardstick of the parity criterion (tests/helpers.parity)
+    om64 = O.OracleModel(kind, z, L, output_size2=L2, salt=salt, dtype=torch.float64)
+    batch64 = tuple(t.double() if (t is not None and t.is_floating_point()) else t for t in batch)
+    eps64 = eps.double()
+
+    # ---- eval forward (running statistics) ----
+    s, c = plan.ops.segments["fwd_eval"]
+    interp.run(ops, A, s, c)
+    with torch.no_grad():
+        outs = om.forward(batch, eps, training=False)
+        outs64 = om64.forward(batch64, eps64, training=False)
+    H.parity(H.get_io(plan, A, "enc_eval"), outs[0].numpy(), outs64[0].numpy(), "eval enc")
+    H.parity(H.get_io(plan, A, "mulv_eval")[:, :z], outs[1].numpy(), outs64[1].numpy(), "eval mu")
+    H.parity(H.get_io(plan, A, "rec_eval"), outs[3].numpy(), outs64[3].numpy(), "eval rec")
+
+    # ---- one full training step ----
+    for seg in ("fwd_train", "bwd"):
+        s, c = plan.ops.segments[seg]
+        interp.run(ops, A, s, c)
+    outs = om.forward(batch, eps, True)
+    ls = om.losses(batch, outs, beta, w1, w2)
+    ls[0].backward()
+    outs64 = om64.forward(batch64, eps64, True)
+    ls64 = om64.losses(batch64, outs64, beta, w1, w2)
+    ls64[0].backward()
+    n = lambda t: t.detach().numpy()
+    H.parity(H.get_io(plan, A, "enc_train"), n(outs[0]), n(outs64[0]), "enc")
+    mulv = H.get_io(plan, A, "mulv_train")
+    H.parity(mulv[:, :z], n(outs[1]), n(outs64[1]), "mu")
+    H.parity(mulv[:, z:], n(outs[2]), n(outs64[2]), "logvar")
+    H.parity(H.get_io(plan, A, "rec_train"), n(outs[3]), n(outs64[3]), "rec")
+    sc = H.get_io(plan, A, "scalars")
+    if kind == "unimodal":
+        np.testing.assert_allclose(sc[[0, 1, 3]], [float(v) for v in ls64], rtol=1e-5)
+    else:
+        H.parity(H.get_io(plan, A, "rec2_train"), n(outs[4]), n(outs64[4]), "rec2")
+        np.testing.assert_allclose(sc, [float(v) for v in ls64], rtol=1e-5)
+    # gradients
+    grads = H.read_params(plan, A, P.GRAD)
+    og, og64 = om.grads(), om64.grads()
+    for k, g in og.items():
+        mine = grads[k]
+        if g is None:
+            assert np.all(mine == 0), k
+            continue
+        if re.search(H.ZERO_GRAD_RE, k):
+            assert np.abs(g.numpy()).max() < 1e-5 and np.abs(mine).max() < 1e-5, k
+            continue
+        H.parity(mine, g.numpy(), og64[k].numpy(), "grad " + k)
+    # running stats after the training forward
+    bufs = H.read_bufs(plan, A)
+    for k, v in bufs.items():
+        np.testing.assert_allclose(v, om.state[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    # optimiser (oracle: same grads -> clip -> AdamW)
+    s, c = plan.ops.segments["opt"]
+    interp.run(ops, A, s, c)
+    with torch.no_grad():
+        g = om.grads()
+        if clip:
+            O.clip_grad_norm(list(g.values()), clip)
+        for k in om.param_keys:
+            if g[k] is not None:
+                om.exp_avg[k] = torch.zeros_like(om.state[k])
+                om.exp_avg_sq[k] = torch.zeros_like(om.state[k])
+        O.adamw_step({k: om.state[k] for k in om.param_keys}, g, om.exp_avg, om.exp_avg_sq, 1, lr, 0.01)
+    params = H.read_params(plan, A)
+    for k in om.param_keys:
+        if re.search(H.ZERO_GRAD_RE, k):
+            assert np.abs(params[k] - om.state[k].detach().numpy()).max() <= 2.2 * lr, k
+            continue
+        H.assert_adam_close(params[k], om.state[k].detach().numpy(), lr, k, grad=(g[k].numpy() if g[k] is not None else None))
+    return plan
+
+
+def test_unimodal_wave_step():
+    plan = run_case("unimodal", 10, 50, 8, False, 1.0, None, 1e-3, 0)
+    # parameter count matches the reference (8 056 639 incl. class_embedding)
+    assert sum(i.numel for i in plan.params.values()) == 8056639
+    assert plan.n_active <= plan.params["class_embedding.weight"].offset
+
+
+def test_unimodal_time_step_with_clip_and_class_labels():
+    run_case("unimodal", 5, 100, 6, True, 0.5, 1.0, 1e-3, 3)
+
+
+def test_unimodal_odd_length():
+    run_case("unimodal", 10, 32, 5, False, 1.0, None, 1e-3, 6)
+
+
+def test_multimodal_step():
+    run_case("multimodal", 10, 50, 6, False, 1.0, 1.0, 1e-3, 7, L2=100, w1=1.0, w2=0.5)
