@@ -1,0 +1,195 @@
+"""Device-side engine: owns the six arenas (as torch tensors = plain HBM allocations),
+binds a lowered program to them and runs / graph-replays it.
+
+torch is plumbing here (device memory, streams, checkpoint tensors); every
+arithmetic op of the hot path runs inside libhippie_hip.so.  There is no CPU
+fallback: constructing an Engine without a GPU or without the built library
+raises.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import planner, program as P
+from .program import DeviceProgram, HipEngineError
+
+
+class Engine:
+    def __init__(self, cfg: planner.ModelCfg, batch: int, train: planner.TrainCfg = None, with_class=False,
+                 device=None, share_params_from: "Engine" = None):
+        if not torch.cuda.is_available():
+            raise HipEngineError("hippie_amd.Engine needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
+        P.load_library()
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.cfg, self.B, self.with_class = cfg, batch, with_class
+        self.train_cfg = train or planner.TrainCfg()
+        self.plan = planner.lower(cfg, batch, self.train_cfg, with_class)
+        self.ops = self.plan.ops.array()
+        n = self.plan.n_param_floats
+        with torch.cuda.device(self.device):
+            if share_params_from is not None:
+                o = share_params_from
+                assert o.plan.n_param_floats == n and list(o.plan.params) == list(self.plan.params)
+                self.params, self.grads, self.m, self.v, self.bufs = o.params, o.grads, o.m, o.v, o.bufs
+                self.num_batches_tracked = o.num_batches_tracked
+            else:
+                self.params = torch.zeros(n, dtype=torch.float32, device=self.device)
+                self.grads = torch.zeros(n, dtype=torch.float32, device=self.device)
+                self.m = torch.zeros(n, dtype=torch.float32, device=self.device)
+                self.v = torch.zeros(n, dtype=torch.float32, device=self.device)
+                self.bufs = torch.zeros(self.plan.n_buf_floats, dtype=torch.float32, device=self.device)
+                self.num_batches_tracked = {k: 0 for k in self.plan.bn_keys}
+            self.ws = torch.zeros(self.plan.ws_bytes, dtype=torch.uint8, device=self.device)
+        arenas = [self.ws, self.params, self.grads, self.bufs, self.m, self.v]
+        self.prog = DeviceProgram(self.ops, [a.data_ptr() for a in arenas], [a.numel() * a.element_size() for a in arenas])
+        self._graphs = {}
+        if share_params_from is None:
+            self._init_bn_defaults()
+
+    # ---- views -------------------------------------------------------------------
+    def _init_bn_defaults(self):
+        """BatchNorm weight = 1, running_var = 1 (torch defaults); everything else zero until loaded."""
+        for k, info in self.plan.bufs.items():
+            if k.endswith("running_var"):
+                self.bufs[info.offset: info.offset + info.numel] = 1.0
+
+    def io(self, name):
+        ref, shape, dt = self.plan.io[name]
+        tdt = torch.float32 if dt == "f4" else torch.int64
+        nb = int(np.prod(shape)) * (4 if dt == "f4" else 8)
+        return self.ws[ref.offset: ref.offset + nb].view(tdt).view(*shape)
+
+    def ws_f32(self, ref, n):
+        return self.ws[ref.offset: ref.offset + 4 * n].view(torch.float32)
+
+    def param_view(self, key, arena=None):
+        """torch-layout view ([Cout, Cin, k] for conv weights) of one parameter inside an arena."""
+        info = self.plan.params[key]
+        a = self.params if arena is None else arena
+        flat = a[info.offset: info.offset + info.numel]
+        if info.layout == "tnc":
+            co, ci, k = info.shape
+            return flat.view(k, co, ci).permute(1, 2, 0)
+        return flat.view(*info.shape)
+
+    # ---- checkpoint surface (reference state_dict keys, hippie/model.py modules) -------
+    def state_dict(self, prefix=""):
+        sd = OrderedDict()
+        bn_of = {}
+        for p in self.plan.bn_keys:
+            bn_of[p + ".bias"] = p
+        for k in self.plan.params:
+            sd[prefix + k] = self.param_view(k).contiguous().clone()
+            if k in bn_of:
+                p = bn_of[k]
+                for suffix in (".running_mean", ".running_var"):
+                    info = self.plan.bufs[p + suffix]
+                    sd[prefix + p + suffix] = self.bufs[info.offset: info.offset + info.numel].clone()
+                sd[prefix + p + ".num_batches_tracked"] = torch.tensor(self.num_batches_tracked[p], dtype=torch.int64)
+        return sd
+
+    def load_state_dict(self, sd, strict=True, prefix=""):
+        missing, unexpected = [], []
+        known = set()
+        for k, info in self.plan.params.items():
+            known.add(prefix + k)
+            if prefix + k not in sd:
+                missing.append(k)
+                continue
+            src = sd[prefix + k]
+            if tuple(src.shape) != tuple(info.shape):
+                raise ValueError(f"size mismatch for {k}: checkpoint {tuple(src.shape)} vs model {tuple(info.shape)}")
+            self.param_view(k).copy_(src.to(device=self.device, dtype=torch.float32))
+        for k, info in self.plan.bufs.items():
+            known.add(prefix + k)
+            if prefix + k not in sd:
+                missing.append(k)
+                continue
+            self.bufs[info.offset: info.offset + info.numel].copy_(sd[prefix + k].to(device=self.device, dtype=torch.float32).reshape(-1))
+        for p in self.plan.bn_keys:
+            k = prefix + p + ".num_batches_tracked"
+            known.add(k)
+            if k in sd:
+                self.num_batches_tracked[p] = int(sd[k])
+        unexpected = [k for k in sd if k.startswith(prefix) and k not in known]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}… unexpected {unexpected[:5]}…")
+        return missing, unexpected
+
+    def grad_dict(self):
+        return OrderedDict((k, self.param_view(k, self.grads).contiguous().clone()) for k in self.plan.params)
+
+    # ---- inputs ------------------------------------------------------------------
+    def set_inputs(self, x, src, cls=None, eps=None, x2=None):
+        self.io("x").copy_(x.reshape(self.io("x").shape), non_blocking=True)
+        if x2 is not None:
+            self.io("x2").copy_(x2.reshape(self.io("x2").shape), non_blocking=True)
+        self.io("src").copy_(src, non_blocking=True)
+        if cls is not None:
+            if not self.with_class:
+                raise ValueError("engine was lowered without class labels")
+            self.io("cls").copy_(cls, non_blocking=True)
+        elif self.with_class:
+            raise ValueError("engine was lowered with class labels; pass cls")
+        if eps is None:
+            self.io("eps").normal_()          # torch.randn_like(std), hippie/model.py:48
+        else:
+            self.io("eps").copy_(eps, non_blocking=True)
+
+    # ---- execution ----------------------------------------------------------------
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def run(self, seg, use_graph=False):
+        first, count = self.plan.ops.segments[seg]
+        if count == 0:
+            return
+        if use_graph:
+            g = self._graphs.get(seg)
+            if g is None:
+                g = self._graphs[seg] = self.prog.capture(first, count)
+            self.prog.replay(g, self._stream())
+        else:
+            self.prog.run(first, count, self._stream())
+
+    def forward(self, training=True, use_graph=False):
+        mode = "train" if training else "eval"
+        self.run("fwd_" + mode, use_graph)
+        if training:
+            for p in self.num_batches_tracked:
+                self.num_batches_tracked[p] += 1
+        z = self.cfg.z_dim
+        mulv = self.io("mulv_" + mode)
+        outs = [self.io("enc_" + mode), mulv[:, :z], mulv[:, z:], self.io("rec_" + mode)]
+        if self.cfg.kind == "multimodal":
+            outs.append(self.io("rec2_" + mode))
+        return tuple(outs)
+
+    def backward(self, use_graph=False):
+        self.run("bwd", use_graph)
+
+    def optimizer_step(self, use_graph=False):
+        self.run("opt", use_graph)
+
+    def train_step(self, use_graph=False):
+        """forward(train) + backward + AdamW on the staged inputs; returns the scalars tensor (device)."""
+        self.forward(True, use_graph)
+        self.backward(use_graph)
+        self.optimizer_step(use_graph)
+        return self.io("scalars")
+
+    def scalars(self):
+        """(loss, mse1, mse2, kl_mean) of the last forward, synchronising (= the reference's loss.item())."""
+        return [float(v) for v in self.io("scalars").tolist()]
+
+    @property
+    def adam_step(self):
+        return int(self.io("adam_step")[0])
+
+    def profile(self, seg):
+        first, count = self.plan.ops.segments[seg]
+        ms = self.prog.profile(first, count, self._stream())
+        return [(P.OP_NAMES[int(self.ops[first + k]["op"])], self.plan.ops.notes[first + k], float(ms[k])) for k in range(count)]

@@ -1,0 +1,363 @@
+"""GPU: every HIP kernel, launched through the C ABI (hp_run_op), against the numpy op semantics
+(oracle/interp.py) on identical memory images.  Shapes are ragged on purpose (odd lengths,
+partial tiles, rows that straddle samples)."""
+import numpy as np
+import pytest
+import torch
+
+from hippie_amd import program as P
+from hippie_amd.program import Ref, TapMap
+from oracle import interp
+
+pytestmark = pytest.mark.gpu
+
+
+class Img:
+    """One WS arena image shared by the GPU run and the interpreter run."""
+
+    def __init__(self, seed=0):
+        self.chunks = []
+        self.off = 0
+        self.rng = np.random.default_rng(seed)
+
+    def _put(self, arr):
+        pad = (-self.off) % 256
+        self.off += pad
+        self.chunks.append((pad, arr))
+        r = Ref(P.WS, self.off)
+        self.off += arr.nbytes
+        return r
+
+    def f32(self, n, scale=1.0, zero=False):
+        a = np.zeros(n, np.float32) if zero else (self.rng.standard_normal(n) * scale).astype(np.float32)
+        return self._put(a)
+
+    def f64(self, n):
+        return self._put(np.zeros(n, np.float64))
+
+    def i64(self, vals):
+        return self._put(np.asarray(vals, dtype=np.int64))
+
+    def image(self):
+        out = np.zeros(self.off + 256, np.uint8)
+        o = 0
+        for pad, arr in self.chunks:
+            o += pad
+            out[o: o + arr.nbytes] = arr.view(np.uint8).reshape(-1)
+            o += arr.nbytes
+        return out
+
+
+def rec_of(op, flags=0, i=(), f=(), buf=()):
+    ol = P.OpList()
+    ol.add(op, flags, i, f, buf)
+    return ol.array()
+
+
+def run_both(img, recs):
+    image = img.image()
+    A = interp.Arenas([image.size, 4, 4, 4, 4, 4])
+    A.mem[0][:] = image
+    interp.run(recs, A)
+    dev = torch.from_numpy(image.copy()).cuda()
+    bases = [dev.data_ptr()] + [0] * 5
+    for r in recs:
+        P.run_single_op(r, bases, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return dev.cpu().numpy(), A.mem[0]
+
+
+def view(mem, ref, dtype, n):
+    return mem[ref.offset: ref.offset + np.dtype(dtype).itemsize * n].view(dtype)
+
+
+def check(gpu, cpu, ref, n, dtype=np.float32, rel=2e-5, what=""):
+    g, c = view(gpu, ref, dtype, n).astype(np.float64), view(cpu, ref, dtype, n).astype(np.float64)
+    scale = max(np.abs(c).max(), 1e-20)
+    err = np.abs(g - c).max() / scale
+    assert np.isfinite(g).all() and err <= rel, f"{what}: rel err {err:.3e} (scale {scale:.3e})"
+
+
+B = 3
+CONV_CASES = {
+    # name: (tapmap builder, w_kn, bias, rows_in)
+    "fwd_s1": lambda: (TapMap(B * 7, 128, 64, 7, 7, 7, 1, 0, 0, [(t - 1, t) for t in range(3)]), False, False),
+    "fwd_s2_odd": lambda: (TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(t - 1, t) for t in range(3)]), False, False),
+    "fwd_1x1_s2": lambda: (TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(0, 0)]), False, False),
+    "fwd_up_bias": lambda: (TapMap(B * 16, 64, 128, 16, 8, 16, 1, 1, 0, [(t - 1, t) for t in range(3)]), False, True),
+    "dgrad_s1": lambda: (TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, 0, [(1 - t, t) for t in range(3)]), True, False),
+    "dgrad_s2": lambda: (TapMap(B * 25, 64, 128, 25, 13, 26, 1, 1, 1, [(1 - t, t) for t in range(3)]), True, False),
+    "dgrad_1x1_s2": lambda: (TapMap(B * 25, 64, 128, 25, 13, 26, 1, 1, 1, [(0, 0)]), True, False),
+    "dgrad_up": lambda: (TapMap(B * 8, 128, 64, 8, 16, 16, 2, 0, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)]), True, False),
+    "big_k": lambda: (TapMap(37 * 4, 512, 512, 4, 4, 4, 1, 0, 0, [(t - 1, t) for t in range(3)]), False, False),
+    "big_k_kn": lambda: (TapMap(37 * 4, 512, 512, 4, 4, 4, 1, 0, 0, [(1 - t, t) for t in range(3)]), True, False),
+}
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv_taps(name):
+    tm, w_kn, bias = CONV_CASES[name]()
+    img = Img(1)
+    nb = tm.M // tm.Lout
+    a = img.f32(nb * tm.Lin * tm.K)
+    nslab = max(w for _, w in tm.taps) + 1
+    w = img.f32(nslab * tm.N * tm.K, scale=0.1)
+    out = img.f32(tm.M * tm.N, zero=True)
+    bv = img.f32(tm.N) if bias else None
+    st = img.f64(2 * tm.N)
+    flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_STATS
+    recs = rec_of(P.CONV_TAPS, flags, tm.ints(), (), [a, w, out, bv, st])
+    gpu, cpu = run_both(img, recs)
+    check(gpu, cpu, out, tm.M * tm.N, what=name + " out")
+    check(gpu, cpu, st, 2 * tm.N, np.float64, rel=1e-5, what=name + " stats")
+
+
+def test_conv_mfma_layout_identity():
+    """A = I (per tap 1 of a 1-tap map) with an ASYMMETRIC weight matrix: catches transposed C/D or
+    swapped operand layouts that random data with loose tolerance could hide."""
+    K = N = 64
+    tm = TapMap(64, N, K, 64, 64, 64, 1, 0, 0, [(0, 0)])
+    for w_kn in (False, True):
+        img = Img(2)
+        a = img._put(np.eye(64, dtype=np.float32).reshape(-1))
+        wmat = (np.arange(N)[:, None] * 1000 + np.arange(K)[None, :]).astype(np.float32)   # W[n][k] = 1000n + k
+        w = img._put((wmat.T.copy() if w_kn else wmat).reshape(-1))
+        out = img.f32(64 * N, zero=True)
+        recs = rec_of(P.CONV_TAPS, P.CONV_W_KN if w_kn else 0, tm.ints(), (), [a, w, out, None, None])
+        gpu, _ = run_both(img, recs)
+        got = view(gpu, out, np.float32, 64 * N).reshape(64, N)
+        np.testing.assert_array_equal(got, wmat.T)     # out[m][n] = sum_k I[m][k] W[n][k] = W[n][m]
+
+
+WGRAD_CASES = {
+    "s1": lambda: TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, 0, [(t - 1, t) for t in range(3)]),
+    "s2": lambda: TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(t - 1, t) for t in range(3)]),
+    "1x1": lambda: TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(0, 0)]),
+    "up": lambda: TapMap(B * 16, 64, 128, 16, 8, 16, 1, 1, 0, [(t - 1, t) for t in range(3)]),
+    "big": lambda: TapMap(50 * 7, 256, 256, 7, 7, 7, 1, 0, 0, [(t - 1, t) for t in range(3)]),
+}
+
+
+@pytest.mark.parametrize("name", list(WGRAD_CASES))
+@pytest.mark.parametrize("nsplit", [1, 3])
+def test_wgrad_taps(name, nsplit):
+    tm = WGRAD_CASES[name]()
+    img = Img(3)
+    nb = tm.M // tm.Lout
+    dy = img.f32(tm.M * tm.N)
+    x = img.f32(nb * tm.Lin * tm.K)
+    numel = len(tm.taps) * tm.N * tm.K
+    rps = -(-(-(-tm.M // nsplit)) // 32) * 32
+    ns = -(-tm.M // rps)
+    slab = img.f32(ns * numel, zero=True)
+    grad = img.f32(numel, zero=True)
+    ol = P.OpList()
+    ol.add(P.WGRAD_TAPS, 0, tm.ints() + [ns, rps, numel], (), [dy, x, slab])
+    ol.add(P.SLAB_REDUCE, 0, [numel, ns, numel], (), [slab, grad])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, grad, numel, rel=3e-5, what=f"wgrad {name}")
+
+
+def test_wgrad_mfma_layout_identity():
+    """DY = I, X asymmetric: dW[n][k] = sum_m I[m][n] X[m][k] = X[n][k] exactly."""
+    tm = TapMap(64, 64, 64, 64, 64, 64, 1, 0, 0, [(0, 0)])
+    img = Img(4)
+    dy = img._put(np.eye(64, dtype=np.float32).reshape(-1))
+    xm = (np.arange(64)[:, None] * 1000 + np.arange(64)[None, :]).astype(np.float32)
+    x = img._put(xm.reshape(-1))
+    slab = img.f32(64 * 64, zero=True)
+    recs = rec_of(P.WGRAD_TAPS, 0, tm.ints() + [1, 64, 64 * 64], (), [dy, x, slab])
+    gpu, _ = run_both(img, recs)
+    np.testing.assert_array_equal(view(gpu, slab, np.float32, 64 * 64).reshape(64, 64), xm)
+
+
+@pytest.mark.parametrize("C,M", [(64, 300), (512, 37), (20, 77), (5, 33)])
+@pytest.mark.parametrize("res_mode", [0, 1, 2])
+def test_bn_apply_and_backward(C, M, res_mode):
+    img = Img(5)
+    raw, raw2 = img.f32(M * C), img.f32(M * C)
+    res = img.f32(M * C)
+    out = img.f32(M * C, zero=True)
+    gamma, beta, gamma2, beta2 = img.f32(C), img.f32(C), img.f32(C), img.f32(C)
+    rm, rm2 = img.f32(C, 0.1), img.f32(C, 0.1)
+    rv, rv2 = img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5), img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5)
+    save, save2 = img.f32(2 * C, zero=True), img.f32(2 * C, zero=True)
+    st, st2 = img.f64(2 * C), img.f64(2 * C)
+    # statistics as the producing conv would have accumulated them (patched into the fp64 chunks)
+    def chunk_array(ref):
+        o = 0
+        for pad, arr in img.chunks:
+            o += pad
+            if o == ref.offset:
+                return arr
+            o += arr.nbytes
+        raise KeyError
+    for s_ref, r_ref in ((st, raw), (st2, raw2)):
+        r = chunk_array(r_ref).reshape(M, C).astype(np.float64)
+        chunk_array(s_ref)[:C] = r.sum(0)
+        chunk_array(s_ref)[C:] = (r * r).sum(0)
+    g1, g2 = img.f32(M * C), img.f32(M * C)
+    gout, dr, dr2 = img.f32(M * C, zero=True), img.f32(M * C, zero=True), img.f32(M * C, zero=True)
+    bs, bs2 = img.f64(2 * C), img.f64(2 * C)
+    dgam, dbet, dgam2, dbet2 = (img.f32(C, zero=True) for _ in range(4))
+    ol = P.OpList()
+    bufs = [raw, out, st, gamma, beta, rm, rv, save]
+    if res_mode == 1:
+        bufs += [res]
+    elif res_mode == 2:
+        bufs += [raw2, st2, gamma2, beta2, rm2, rv2, save2]
+    ol.add(P.BN_APPLY, 0, [M, C, res_mode, 1, 1], [0.01, 1e-5, 0.1], bufs)
+    second = res_mode == 2
+    ol.add(P.BN_BWD_REDUCE, 0, [M, C, 1, 1 if second else 0], [0.01],
+           [g1, g2, out, gout, raw, save, bs] + ([raw2, save2, bs2] if second else []))
+    ol.add(P.BN_BWD_APPLY, 0, [M, C], (), [gout, raw, save, bs, gamma, dr, dgam, dbet])
+    if second:
+        ol.add(P.BN_BWD_APPLY, 0, [M, C], (), [gout, raw2, save2, bs2, gamma2, dr2, dgam2, dbet2])
+    gpu, cpu = run_both(img, ol.array())
+    for ref, n, nm in ((out, M * C, "out"), (save, 2 * C, "save"), (rm, C, "rmean"), (rv, C, "rvar"), (gout, M * C, "g"),
+                       (dr, M * C, "dr"), (dgam, C, "dgamma"), (dbet, C, "dbeta")):
+        check(gpu, cpu, ref, n, rel=3e-5, what=f"bn {nm}")
+    check(gpu, cpu, bs, 2 * C, np.float64, rel=1e-5, what="bn bs")
+    if res_mode == 2:
+        check(gpu, cpu, dr2, M * C, rel=3e-5, what="bn dr2")
+        check(gpu, cpu, rv2, C, rel=3e-5, what="bn rvar2")
+
+
+def test_bn_eval_mode():
+    C, M = 64, 100
+    img = Img(6)
+    raw, out = img.f32(M * C), img.f32(M * C, zero=True)
+    gamma, beta, rm = img.f32(C), img.f32(C), img.f32(C, 0.1)
+    rv = img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5)
+    save = img.f32(2 * C, zero=True)
+    recs = rec_of(P.BN_APPLY, 0, [M, C, 0, 0, 1], [0.2, 1e-5, 0.1], [raw, out, None, gamma, beta, rm, rv, save])
+    gpu, cpu = run_both(img, recs)
+    check(gpu, cpu, out, M * C, what="bn eval out")
+    check(gpu, cpu, rm, C, rel=0, what="running stats untouched in eval")
+
+
+@pytest.mark.parametrize("Bn,Lin", [(5, 50), (3, 33), (4, 100)])
+def test_stem(Bn, Lin):
+    Lout = (Lin - 1) // 2 + 1
+    img = Img(7)
+    x, w = img.f32(Bn * Lin), img.f32(64 * 3)
+    out, st = img.f32(Bn * Lout * 64, zero=True), img.f64(128)
+    dr, dw = img.f32(Bn * Lout * 64), img.f32(192, zero=True)
+    ol = P.OpList()
+    ol.add(P.STEM_FWD, 0, [Bn, Lin, Lout, 64], (), [x, w, out, st])
+    ol.add(P.STEM_WGRAD, 0, [Bn, Lin, Lout, 64], (), [dr, x, dw])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, out, Bn * Lout * 64, what="stem out")
+    check(gpu, cpu, st, 128, np.float64, rel=1e-5, what="stem stats")
+    check(gpu, cpu, dw, 192, rel=3e-5, what="stem dW")
+
+
+def test_tail_pool_repeat():
+    Bn, Lh, C = 5, 32, 64
+    img = Img(8)
+    act, w, bias = img.f32(Bn * Lh * C), img.f32(C * 3), img.f32(1)
+    t = img.f32(Bn * 2 * Lh, zero=True)
+    dt = img.f32(Bn * 2 * Lh)
+    dact = img.f32(Bn * Lh * C, zero=True)
+    dw, db = img.f32(C * 3, zero=True), img.f32(1, zero=True)
+    pooled, gp = img.f32(Bn * C, zero=True), img.f32(Bn * Lh * C, zero=True)
+    rep, drep = img.f32(Bn * 4 * C, zero=True), img.f32(Bn * C, zero=True)
+    g1, g2 = img.f32(Bn * 4 * C), img.f32(Bn * 4 * C)
+    ol = P.OpList()
+    ol.add(P.TAIL_FWD, 0, [Bn, Lh, C], (), [act, w, bias, t])
+    ol.add(P.TAIL_BWD_X, 0, [Bn, Lh, C], (), [dt, w, dact])
+    ol.add(P.TAIL_BWD_W, 0, [Bn, Lh, C], (), [dt, act, dw, db])
+    ol.add(P.POOL_FWD, 0, [Bn, Lh, C], (), [act, pooled])
+    ol.add(P.POOL_BWD, 0, [Bn, Lh, C], (), [pooled, gp])
+    ol.add(P.REPEAT_FWD, 0, [Bn, 4, C], (), [pooled, rep])
+    ol.add(P.REPEAT_BWD, 0, [Bn, 4, C, 1], (), [g1, g2, drep])
+    gpu, cpu = run_both(img, ol.array())
+    for ref, n, nm in ((t, Bn * 2 * Lh, "tail"), (dact, Bn * Lh * C, "tail dX"), (dw, C * 3, "tail dW"), (db, 1, "tail db"),
+                       (pooled, Bn * C, "pool"), (gp, Bn * Lh * C, "pool bwd"), (rep, Bn * 4 * C, "repeat"), (drep, Bn * C, "repeat bwd")):
+        check(gpu, cpu, ref, n, rel=3e-5, what=nm)
+
+
+@pytest.mark.parametrize("M,N,K", [(33, 20, 30), (17, 20, 512), (9, 512, 20), (1100, 10, 10), (7, 5, 10)])
+def test_linear_family(M, N, K):
+    img = Img(9)
+    ldx, ldy = K + 3, N + 2
+    x, w, bv = img.f32(M * ldx), img.f32(N * K, 0.2), img.f32(N)
+    y = img.f32(M * ldy, zero=True)
+    st = img.f64(2 * N)
+    dy = img.f32(M * ldy)
+    dx = img.f32(M * ldx, zero=True)
+    dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
+    ol = P.OpList()
+    ol.add(P.LINEAR_FWD, 0, [M, N, K, ldx, ldy, 1, 1], [0.2], [x, w, bv, y, st])
+    ol.add(P.LINEAR_BWD_X, 0, [M, N, K, ldy, ldx, 1, ldx, 0], [0.2], [dy, w, dx, x])
+    ol.add(P.LINEAR_BWD_X, 0, [M, N, K, ldy, ldx, 0, 0, 1], [0.2], [dy, w, dx, None])
+    ol.add(P.LINEAR_BWD_W, 0, [M, N, K, ldy, ldx], (), [dy, x, dw, db])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, y, M * ldy, rel=3e-5, what="linear y")
+    check(gpu, cpu, st, 2 * N, np.float64, rel=1e-5, what="linear stats")
+    check(gpu, cpu, dx, M * ldx, rel=3e-5, what="linear dx")
+    check(gpu, cpu, dw, N * K, rel=3e-5, what="linear dw")
+    check(gpu, cpu, db, N, rel=3e-5, what="linear db")
+
+
+def test_concat_embedding_reparam_mse_loss():
+    Bn, z, H = 37, 10, 5
+    img = Img(10)
+    h = img.f32(Bn * 2 * z)
+    semb, cemb = img.f32(5 * H), img.f32(7 * H)
+    src = img.i64(img.rng.integers(1, 5, Bn))
+    cls = img.i64(img.rng.integers(0, 7, Bn))
+    ld = 2 * z + 2 * H
+    c0, c0z = img.f32(Bn * ld, zero=True), img.f32(Bn * ld, zero=True)
+    dsemb = img.f32(5 * H, zero=True)
+    dcat = img.f32(Bn * ld)
+    mulv, eps = img.f32(Bn * 2 * z, 0.5), img.f32(Bn * z)
+    zz, dmulv = img.f32(Bn * z, zero=True), img.f32(Bn * 2 * z, zero=True)
+    loss = img.f64(4)
+    x, rec, drec = img.f32(Bn * 50), img.f32(Bn * 50), img.f32(Bn * 50, zero=True)
+    scal = img.f32(4, zero=True)
+    ol = P.OpList()
+    ol.add(P.CONCAT, 0, [Bn, 3, ld, 0, 0, 2 * z, 2 * z, 1, H, H, 1, H, H], (), [c0, h, None, semb, src, cemb, cls])
+    ol.add(P.CONCAT, 0, [Bn, 3, ld, 0, 0, 2 * z, 2 * z, 1, H, H, 2, H, 0], (), [c0z, h, None, semb, src, None, None])
+    ol.add(P.EMB_BWD, 0, [Bn, H, ld, 2 * z], (), [dcat, src, dsemb])
+    ol.add(P.REPARAM_KL_FWD, 0, [Bn, z], (), [mulv, eps, zz, loss])
+    ol.add(P.REPARAM_KL_BWD, 0, [Bn, z, ld], [0.7], [mulv, eps, dcat, dmulv])
+    ol.add(P.MSE_FWD_BWD, 0, [Bn * 50, 1], [0.5], [x, rec, drec, loss])
+    ol.add(P.LOSS_FINALIZE, 0, [Bn, Bn * 50, 0], [0.7, 1.0, 0.0], [loss, scal])
+    gpu, cpu = run_both(img, ol.array())
+    for ref, n, nm in ((c0, Bn * ld, "concat"), (c0z, Bn * ld, "concat zeros"), (dsemb, 5 * H, "emb bwd"), (zz, Bn * z, "z"),
+                       (dmulv, Bn * 2 * z, "dmulv"), (drec, Bn * 50, "drec"), (scal, 4, "scalars")):
+        check(gpu, cpu, ref, n, rel=3e-5, what=nm)
+    check(gpu, cpu, loss, 4, np.float64, rel=1e-5, what="loss slots")
+
+
+@pytest.mark.parametrize("n", [1027, 8056614 // 16])
+@pytest.mark.parametrize("clip", [0.0, 1.0])
+def test_adamw_gradnorm_steps(n, clip):
+    img = Img(11)
+    p, g = img.f32(n, 0.1), img.f32(n)
+    m, v = img.f32(n, zero=True), img.f32(n, zero=True)
+    step = img.i64([0])
+    norm2 = img.f64(1)
+    ol = P.OpList()
+    for _ in range(3):
+        ol.add(P.ZERO, 0, [8, 0], (), [norm2])
+        ol.add(P.GRADNORM, 0, [n], (), [g, norm2])
+        ol.add(P.STEP_INC, 0, (), (), [step])
+        ol.add(P.ADAMW, 0, [n], [1e-3, 0.9, 0.999, 1e-8, 0.01, clip], [p, g, m, v, step, norm2])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, norm2, 1, np.float64, rel=1e-9, what="norm2")
+    for ref, nm in ((p, "p"), (m, "m"), (v, "v")):
+        check(gpu, cpu, ref, n, rel=1e-5, what="adam " + nm)
+    assert view(gpu, step, np.int64, 1)[0] == 3
+    # and against torch.optim.AdamW itself on the same numbers
+    im = img.image()
+    tp = torch.tensor(view(im, p, np.float32, n).copy(), requires_grad=True)
+    opt = torch.optim.AdamW([tp], lr=1e-3, weight_decay=0.01)
+    for _ in range(3):
+        tp.grad = torch.tensor(view(im, g, np.float32, n).copy())
+        if clip:
+            torch.nn.utils.clip_grad_norm_([tp], clip)
+        opt.step()
+    got = view(gpu, p, np.float32, n)
+    np.testing.assert_allclose(got, tp.detach().numpy(), rtol=2e-5, atol=2e-6)
