@@ -109,9 +109,13 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
     }
   };
 
-  f32x16 acc;
+  // four independent accumulators (one per 8-wide k group of a slice): blocked summation keeps the
+  // fp32 rounding error of a K=1536 contraction at the level of a vectorised CPU kernel.
+  f32x16 acc4[4];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
 
   load_regs(0);
   store_lds(0);
@@ -133,14 +137,18 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
         const float* bk = Bs + (kk * 8 + lh * 4) * LDBK + wn * 32 + li;
         b4 = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);
       }
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc4[kk], 0, 0, 0);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc4[kk], 0, 0, 0);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc4[kk], 0, 0, 0);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc4[kk], 0, 0, 0);
     }
     if (s + 1 < nsteps) store_lds(buf ^ 1);
     __syncthreads();
   }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int n = n0 + wn * 32 + li;

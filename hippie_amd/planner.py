@@ -592,11 +592,12 @@ class Lowering:
             heads = []
             recs = []
             for k, (fc, dd) in enumerate(zip(dfc, decs)):
+                fcname = names[k][0]
                 u3 = pl.f32(B * 2 * z)
-                self.linear_fwd(B, fc["f0"], c1, ncat1, u3, 2 * z, act=True, note="decoder_fc.0 + LeakyReLU")
+                self.linear_fwd(B, fc["f0"], c1, ncat1, u3, 2 * z, act=True, note=fcname + ".0 + LeakyReLU")
                 u4 = pl.f32(B * 2 * z)
                 st4 = pl.stat(4 * z) if training else None
-                self.linear_fwd(B, fc["f2"], u3, 2 * z, u4, 2 * z, stats=st4, note="decoder_fc.2")
+                self.linear_fwd(B, fc["f2"], u3, 2 * z, u4, 2 * z, stats=st4, note=fcname + ".2")
                 dv = pl.f32(B * 2 * z)
                 self.bn_apply(B, fc["bn3"], u4, dv, st4, training, True, SLOPE_HEADS)
                 rec = self.decoder_fwd(dd, dv, training)

@@ -268,6 +268,7 @@ def resize_conv(P, prefix, x, scale):
 
 def enc_block(P, p, x, stride, ctx):
     out = F.leaky_relu(batch_norm(P, p + "bn1", F.conv1d(x, P[p + "conv1.weight"], None, stride, 1), ctx), SLOPE_BACKBONE)
+    ctx.tap(p + "bn1", out)
     out = batch_norm(P, p + "bn2", F.conv1d(out, P[p + "conv2.weight"], None, 1, 1), ctx)
     if stride == 1:
         sc = x
@@ -275,12 +276,14 @@ def enc_block(P, p, x, stride, ctx):
         sc = batch_norm(P, p + "shortcut.1", F.conv1d(x, P[p + "shortcut.0.weight"], None, stride, 0), ctx)
     out = F.leaky_relu(out + sc, SLOPE_BACKBONE)
     ctx.tap(p + "out", out)
+    ctx.tap(p + "bn2", out)
     return out
 
 
 def enc_forward(P, prefix, x, ctx):
     x = F.leaky_relu(batch_norm(P, prefix + "bn1", F.conv1d(x, P[prefix + "conv1.weight"], None, 2, 1), ctx), SLOPE_BACKBONE)
     ctx.tap(prefix + "stem", x)
+    ctx.tap(prefix + "bn1", x)
     for li in (1, 2, 3, 4):
         for bi in (0, 1):
             stride = 2 if (bi == 0 and li > 1) else 1
@@ -291,6 +294,7 @@ def enc_forward(P, prefix, x, ctx):
 
 def dec_block(P, p, x, stride, ctx):
     out = F.leaky_relu(batch_norm(P, p + "bn2", F.conv1d(x, P[p + "conv2.weight"], None, 1, 1), ctx), SLOPE_BACKBONE)
+    ctx.tap(p + "bn2", out)
     if stride == 1:
         out = batch_norm(P, p + "bn1", F.conv1d(out, P[p + "conv1.weight"], None, 1, 1), ctx)
         sc = x
@@ -299,6 +303,7 @@ def dec_block(P, p, x, stride, ctx):
         sc = batch_norm(P, p + "shortcut.1", resize_conv(P, p + "shortcut.0", x, stride), ctx)
     out = F.leaky_relu(out + sc, SLOPE_BACKBONE)
     ctx.tap(p + "out", out)
+    ctx.tap(p + "bn1", out)
     return out
 
 
@@ -332,13 +337,17 @@ def cvae_forward(P, data, source_labels, class_labels, eps, ctx):
     ctx.tap("enc_h", h)
     h = torch.cat([h, semb, cemb], dim=1)
     h = F.leaky_relu(batch_norm(P, "encoder_fc.1", F.linear(h, P["encoder_fc.0.weight"], P["encoder_fc.0.bias"]), ctx), SLOPE_HEADS)
+    ctx.tap("encoder_fc.1", h)
     enc = F.leaky_relu(batch_norm(P, "encoder_fc.4", F.linear(h, P["encoder_fc.3.weight"], P["encoder_fc.3.bias"]), ctx), SLOPE_HEADS)
+    ctx.tap("encoder_fc.4", enc)
     mu = F.linear(enc, P["z_mean.weight"], P["z_mean.bias"])
     logvar = F.linear(enc, P["z_log_var.weight"], P["z_log_var.bias"])
     z = _reparam(mu, logvar, eps)
     d = torch.cat([z, semb, cemb], dim=1)
     d = F.leaky_relu(F.linear(d, P["decoder_fc.0.weight"], P["decoder_fc.0.bias"]), SLOPE_HEADS)
+    ctx.tap("decoder_fc.0", d)
     d = F.leaky_relu(batch_norm(P, "decoder_fc.3", F.linear(d, P["decoder_fc.2.weight"], P["decoder_fc.2.bias"]), ctx), SLOPE_HEADS)
+    ctx.tap("decoder_fc.3", d)
     ctx.tap("dec_in", d)
     dec = dec_forward(P, "decoder.", d, ctx)
     return enc, mu, logvar, dec
@@ -351,6 +360,7 @@ def mm_forward(P, data1, data2, source_labels, class_labels, eps, ctx):
     h2 = enc_forward(P, "encoder_mod2.", data2, ctx)
     h = torch.cat([h1, h2, semb, cemb], dim=1)
     h = F.leaky_relu(batch_norm(P, "fusion_encoder.1", F.linear(h, P["fusion_encoder.0.weight"], P["fusion_encoder.0.bias"]), ctx), SLOPE_HEADS)
+    ctx.tap("fusion_encoder.1", h)
     enc = F.linear(h, P["fusion_encoder.3.weight"], P["fusion_encoder.3.bias"])
     mu = F.linear(enc, P["z_mean.weight"], P["z_mean.bias"])
     logvar = F.linear(enc, P["z_log_var.weight"], P["z_log_var.bias"])
@@ -359,7 +369,9 @@ def mm_forward(P, data1, data2, source_labels, class_labels, eps, ctx):
     recs = []
     for mod in ("mod1", "mod2"):
         d = F.leaky_relu(F.linear(zc, P[f"decoder_fc_{mod}.0.weight"], P[f"decoder_fc_{mod}.0.bias"]), SLOPE_HEADS)
+        ctx.tap(f"decoder_fc_{mod}.0", d)
         d = F.leaky_relu(batch_norm(P, f"decoder_fc_{mod}.3", F.linear(d, P[f"decoder_fc_{mod}.2.weight"], P[f"decoder_fc_{mod}.2.bias"]), ctx), SLOPE_HEADS)
+        ctx.tap(f"decoder_fc_{mod}.3", d)
         recs.append(dec_forward(P, f"decoder_{mod}.", d, ctx))
     return enc, mu, logvar, recs[0], recs[1]
 

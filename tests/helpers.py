@@ -105,3 +105,42 @@ def parity(mine, ref32, ref64, msg="", rel=1e-4, slack=3.0):
     assert np.isfinite(np.asarray(mine, dtype=np.float64)).all(), msg
     assert e_mine <= max(rel, slack * e_ref), f"{msg}: err vs f64 oracle {e_mine:.3e} (reference f32 path: {e_ref:.3e})"
     return e_mine, e_ref
+
+
+def count_sign_flips(eng, taps64):
+    """Number of leaky-ReLU inputs whose sign on the engine differs from the float64 oracle's.
+    The loss gradient is discontinuous in those signs: wherever an activation is closer to zero than
+    float32 can resolve, two correct float32 implementations may disagree on it, and everything
+    upstream of that element then differs at the 1e-3..1e-2 level (tools/diag_trace.py)."""
+    from hippie_amd import program as P
+    plan, ops, B = eng.plan, eng.ops, eng.B
+    s, c = plan.ops.segments["fwd_train"]
+    flips = sites = 0
+    for k in range(s, s + c):
+        r = ops[k]
+        op, note = int(r["op"]), plan.ops.notes[k]
+        if op == P.BN_APPLY and int(r["i"][4]) == 1:
+            key, M, C, slot = note, int(r["i"][0]), int(r["i"][1]), 1
+        elif op == P.LINEAR_FWD and int(r["i"][5]) == 1:
+            key, M, C, slot = note.split(" ")[0], int(r["i"][0]), int(r["i"][1]), 3
+        else:
+            continue
+        ref = taps64[key].detach().numpy()
+        ref = ref.transpose(0, 2, 1) if ref.ndim == 3 else ref[:, None, :]
+        off = int(r["buf"][slot]) & ((1 << 56) - 1)
+        mine = eng.ws[off: off + 4 * M * C].view(__import__("torch").float32).cpu().numpy().reshape(B, M // B, C)
+        flips += int(((mine > 0) != (ref > 0)).sum())
+        sites += 1
+    return flips, sites
+
+
+def grad_parity(mine, ref32, ref64, flips, msg=""):
+    """Gradient parity: tight (helpers.parity) when no activation sign differs from the float64 oracle;
+    otherwise bounded loosely — max error 5e-2 of scale and relative L2 error 2e-2."""
+    if flips == 0:
+        return parity(mine, ref32, ref64, msg)
+    a, d = np.asarray(mine, np.float64), np.asarray(ref64, np.float64)
+    e = relerr(a, d)
+    l2 = np.linalg.norm(a - d) / max(np.linalg.norm(d), 1e-30)
+    assert np.isfinite(a).all() and e <= 5e-2 and l2 <= 2e-2, f"{msg}: err {e:.3e} l2 {l2:.3e} with {flips} sign flips"
+    return e, relerr(ref32, ref64)

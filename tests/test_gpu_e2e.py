@@ -79,12 +79,15 @@ def test_forward_grads_and_step_vs_oracle(name):
     outs32 = oms[0].forward(batch, eps, True)
     ls32 = oms[0].losses(batch, outs32, c["beta"], c.get("w1", 1.0), c.get("w2", 1.0))
     ls32[0].backward()
-    outs64 = oms[1].forward(batch64, eps.double(), True)
+    taps64 = {}
+    outs64 = oms[1].forward(batch64, eps.double(), True, taps=taps64)
     ls64 = oms[1].losses(batch64, outs64, c["beta"], c.get("w1", 1.0), c.get("w2", 1.0))
     ls64[0].backward()
     outs = eng.forward(True)
     eng.backward()
     torch.cuda.synchronize()
+    flips, sites = H.count_sign_flips(eng, taps64)
+    print(f"[{name}] leaky-ReLU sign flips vs f64 oracle: {flips} over {sites} activation tensors")
     names = ["enc", "mu", "logvar", "rec", "rec2"]
     for k, (a, b, cc) in enumerate(zip(outs, outs32, outs64)):
         H.parity(n(a).reshape(n(b).shape), n(b), n(cc), f"train {names[k]}")
@@ -105,8 +108,9 @@ def test_forward_grads_and_step_vs_oracle(name):
             continue
         if re.search(H.ZERO_GRAD_RE, k):   # analytically zero: both sides hold rounding noise only
             continue
-        e, _ = H.parity(mine, n(gr), n(g64[k]), "grad " + k)
+        e, _ = H.grad_parity(mine, n(gr), n(g64[k]), flips, "grad " + k)
         worst = max(worst, e)
+    print(f"[{name}] worst gradient error vs f64 oracle: {worst:.3e}")
     # running statistics
     sd = eng.state_dict()
     for k in eng.plan.bufs:
@@ -127,31 +131,44 @@ def test_forward_grads_and_step_vs_oracle(name):
         O.adamw_step({k: oms[0].state[k] for k in oms[0].param_keys}, gd, oms[0].exp_avg, oms[0].exp_avg_sq, 1, c["lr"], 0.01)
     sd = eng.state_dict()
     for k in oms[0].param_keys:
-        H.assert_adam_close(n(sd[k]), n(oms[0].state[k]), c["lr"], k, grad=(n(gd[k]) if gd[k] is not None else None))
-
-
-@pytest.mark.parametrize("name", ["wave", "time_clip"])
-def test_three_training_steps_vs_reference_golden(name):
-    """Trajectory check against numbers produced by the reference's own LightningModule + AdamW."""
-    c = CASES[name]
-    eng, oms, batch, batch64, eps = build(**c)
-    g = dict(np.load(os.path.join(G, GOLDEN[name])))
-    for s in (1, 2, 3):
-        eng.train_step()
-        if s in (1, 3):
-            sc = eng.scalars()
-            np.testing.assert_allclose([sc[0], sc[1], sc[3]], g[f"scalars_step{s}"], rtol=5e-4, err_msg=f"step {s} scalars")
-    sd = eng.state_dict()
-    for name_, r in zip(g["state_names"], g["state_stats_step3"]):
-        k = str(name_)
-        v = n(sd[k]).astype(np.float64)
-        if re.search(H.ZERO_GRAD_RE, k):
+        if re.search(H.ZERO_GRAD_RE, k) or gd[k] is None:
+            assert np.abs(n(sd[k]) - n(oms[0].state[k])).max() <= 2.2 * c["lr"], k
             continue
-        l2 = np.linalg.norm(v)
-        assert abs(l2 - r[1]) <= 2e-3 * max(r[1], 1e-6) + 3 * 2.2 * c["lr"] * np.sqrt(v.size) * 0.02, (k, l2, r[1])
+        H.assert_adam_close(n(sd[k]), n(oms[0].state[k]), c["lr"], k, grad=n(gd[k]))
+
+
+TRAJ = {
+    "wave": (dict(kind="unimodal", z=10, L=50, B=32, with_class=False, beta=1.0, clip=None, lr=1e-5, salt=9), "unimodal_wave_z10_L50_B32_traj.npz"),
+    "time_clip": (dict(kind="unimodal", z=10, L=100, B=32, with_class=False, beta=1.0, clip=1.0, lr=1e-5, salt=10), "unimodal_time_z10_L100_B32_traj_clip.npz"),
+}
+
+
+@pytest.mark.parametrize("name", list(TRAJ))
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_training_trajectory_vs_reference_golden(name, use_graph):
+    """Six optimisation steps against the losses logged by the reference's own LightningModule +
+    torch.optim.AdamW (+ clip_grad_norm_ for the time model), eager and through hipGraph replay."""
+    c, fname = TRAJ[name]
+    eng, oms, batch, batch64, eps = build(**c)
+    g = dict(np.load(os.path.join(G, fname)))
+    got = []
+    for s_ in range(6):
+        eng.train_step(use_graph=use_graph)
+        sc = eng.scalars()
+        got.append([sc[0], sc[1], sc[3]])
+    got = np.array(got)
+    dev = np.abs(got - g["scalars_traj"]) / np.abs(g["scalars_traj"])
+    print(f"[traj {name} graph={use_graph}] max rel deviation per step: {dev.max(1)}")
+    np.testing.assert_allclose(got[0], g["scalars_traj"][0], rtol=1e-4)
+    np.testing.assert_allclose(got, g["scalars_traj"], rtol=3e-3)
+    assert eng.adam_step == 6
+    sd = eng.state_dict()
     for k in g:
-        if k.startswith("param_step3.") and not re.search(H.ZERO_GRAD_RE, k):
-            H.assert_adam_close(n(sd[k.split(".", 1)[1]]), g[k], c["lr"], k, steps=3)
+        if k.startswith("param_step6.") and not re.search(H.ZERO_GRAD_RE, k):
+            H.assert_adam_close(n(sd[k.split(".", 1)[1]]), g[k], c["lr"], k, steps=6)
+    for k, v in sd.items():
+        if k.endswith("num_batches_tracked"):
+            assert int(v) == 6
 
 
 def test_full_batch_512_step_matches_oracle():
@@ -161,12 +178,15 @@ def test_full_batch_512_step_matches_oracle():
     outs32 = oms[0].forward(batch, eps, True)
     ls32 = oms[0].losses(batch, outs32, 1.0)
     ls32[0].backward()
-    outs64 = oms[1].forward(batch64, eps.double(), True)
+    taps64 = {}
+    outs64 = oms[1].forward(batch64, eps.double(), True, taps=taps64)
     ls64 = oms[1].losses(batch64, outs64, 1.0)
     ls64[0].backward()
     outs = eng.forward(True)
     eng.backward()
     torch.cuda.synchronize()
+    flips, sites = H.count_sign_flips(eng, taps64)
+    print(f"[B512] leaky-ReLU sign flips vs f64 oracle: {flips} over {sites} activation tensors")
     for k, (a, b, cc) in enumerate(zip(outs, outs32, outs64)):
         H.parity(n(a).reshape(n(b).shape), n(b), n(cc), f"B512 out{k}")
     sc = eng.scalars()
@@ -176,11 +196,11 @@ def test_full_batch_512_step_matches_oracle():
     for k, gr in g32.items():
         if gr is None or re.search(H.ZERO_GRAD_RE, k):
             continue
-        H.parity(n(grads[k]), n(gr), n(g64[k]), "B512 grad " + k)
+        H.grad_parity(n(grads[k]), n(gr), n(g64[k]), flips, "B512 grad " + k)
 
 
 def test_graph_replay_equals_eager_and_is_repeatable():
-    c = CASES["wave"]
+    c = dict(CASES["wave"], lr=1e-5)
     eng, oms, batch, batch64, eps = build(**c)
     eng2 = Engine(eng.cfg, eng.B, eng.train_cfg, with_class=False)
     eng2.load_state_dict(eng.state_dict())
