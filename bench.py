@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pretrain samples/sec of the waveform + spike-timing cVAE pair at batch 512.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One *step* = one optimisation step (forward, loss, backward, [clip], AdamW) of the wave model
+(L=50, no clipping) AND of the time model (L=100, clip 1.0) on the same batch of 512 units — the
+reference's default `--model-type unimodal` pipeline trains exactly this pair
+(scripts/train_model_with_multimodal.py:200-224).  Inputs are synthetic tensors of the
+cellexplorer-celltype pretrain shape (BASELINE.json configs[1]), resident in HBM before the timed
+region; each step gathers its batch by index from them.  One process per GPU; with N > 1 every rank
+holds a replica, takes its own 512-unit batch (Lightning-DDP semantics, weak scaling) and the
+gradients are mean-all-reduced over RCCL between backward and AdamW.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the f32-MFMA implicit-GEMM
+convolution `conv_taps_kernel`), timed with HIP events per launch in an untimed pass right after the
+timed region; `cpu_baseline` times the torch-CPU oracle on a bounded sample on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from hippie_amd import planner, program as P          # noqa: E402
+from hippie_amd.engine import Engine                   # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+N_UNITS = 15631                   # cellexplorer-celltype pretrain pool, 80 % split
+BATCH = 512
+Z_DIM = 10
+
+
+def synth_dataset(n, device, seed=42):
+    """Synthetic waveform [n,50] / ISI [n,100] / source labels, SURVEY.md section 8(d)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    t = torch.linspace(0, 1, 50)[None, :]
+    ratio = 0.2 + 0.4 * torch.rand(n, 1, generator=g)
+    wave = -torch.exp(-0.5 * ((t - 0.3) / 0.04) ** 2) + ratio * torch.exp(-0.5 * ((t - 0.5) / 0.1) ** 2)
+    wave = wave + 0.02 * torch.randn(n, 50, generator=g)
+    lo, hi = wave.min(1, keepdim=True).values, wave.max(1, keepdim=True).values
+    wave = (wave - lo) / (hi - lo) * 2 - 1
+    bins = torch.arange(1, 101, dtype=torch.float32)[None, :]
+    theta = 3 + 12 * torch.rand(n, 1, generator=g)
+    pdf = bins * torch.exp(-bins / theta)
+    isi = pdf / pdf.sum(1, keepdim=True) + (1e-3 * torch.randn(n, 100, generator=g)).abs()
+    isi = torch.log1p(isi)
+    labels = torch.randint(1, 5, (n,), generator=g)
+    return wave.float().to(device), isi.float().to(device), labels.to(device)
+
+
+class Pair:
+    """wave + time engines, each on its own HIP stream, stepped with hipGraph replay."""
+
+    def __init__(self, device, world, lr=1e-3):
+        self.device, self.world = device, world
+        self.eng = [
+            Engine(planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=50), BATCH,
+                   planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0), device=device),
+            Engine(planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=100), BATCH,
+                   planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0), device=device),
+        ]
+        self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
+        self.groups = None
+        if world > 1:
+            import torch.distributed as dist
+            self.groups = [dist.new_group(list(range(world))) for _ in self.eng]
+        self.init_params()
+
+    def init_params(self):
+        """torch default init (kaiming-uniform bound 1/sqrt(fan_in); BN weight 1 / bias 0; Embedding N(0,1))."""
+        g = torch.Generator(device="cpu").manual_seed(42)
+        for e in self.eng:
+            sd = {}
+            for k, info in e.plan.params.items():
+                shp = info.shape
+                if k.endswith("embedding.weight"):
+                    v = torch.randn(shp, generator=g)
+                elif len(shp) == 1 and any(s in k for s in (".bn1.", ".bn2.", "shortcut.1.", "_fc.1.", "_fc.3.", "_fc.4.")):
+                    v = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
+                else:
+                    fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else None
+                    if fan_in is None:                      # bias of the layer declared just before
+                        wkey = k[:-4] + "weight"
+                        fan_in = int(np.prod(e.plan.params[wkey].shape[1:]))
+                    bound = 1.0 / np.sqrt(fan_in)
+                    v = (torch.rand(shp, generator=g) * 2 - 1) * bound
+                sd[k] = v
+            e.load_state_dict(sd, strict=False)
+
+    def step(self, data, idx, use_graph=True):
+        import torch.distributed as dist
+        cur = torch.cuda.current_stream(self.device)
+        for k, (e, s) in enumerate(zip(self.eng, self.streams)):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
+                e.io("src").copy_(data[2].index_select(0, idx), non_blocking=True)
+                e.io("eps").normal_()
+                e.forward(True, use_graph)
+                e.backward(use_graph)
+                if self.groups is not None:
+                    dist.all_reduce(e.grads, op=dist.ReduceOp.AVG, group=self.groups[k])
+                e.optimizer_step(use_graph)
+        for s in self.streams:
+            cur.wait_stream(s)
+
+
+def conv_roofline(pair, data, idx, reps=3):
+    """Per-launch HIP-event timing of every CONV_TAPS op (eager replay of the same programs)."""
+    tot_ms, tot_flop, launches = 0.0, 0.0, 0
+    per_kernel = {}
+    for k, e in enumerate(pair.eng):
+        e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1))
+        e.io("src").copy_(data[2].index_select(0, idx))
+        e.io("eps").normal_()
+        for seg in ("fwd_train", "bwd", "opt"):
+            first, count = e.plan.ops.segments[seg]
+            acc = np.zeros(count)
+            for _ in range(reps):
+                acc += e.prog.profile(first, count, torch.cuda.current_stream().cuda_stream)
+            acc /= reps
+            for j in range(count):
+                r = e.ops[first + j]
+                name = P.OP_NAMES[int(r["op"])]
+                d = per_kernel.setdefault(name, [0.0, 0])
+                d[0] += acc[j]
+                d[1] += 1
+                if int(r["op"]) == P.CONV_TAPS:
+                    M, N, K, nt = int(r["i"][0]), int(r["i"][1]), int(r["i"][2]), int(r["i"][9])
+                    tot_flop += 2.0 * M * N * K * nt
+                    tot_ms += acc[j]
+                    launches += 1
+    return tot_ms, tot_flop, launches, per_kernel
+
+
+def cpu_baseline(steps=3):
+    """The torch-CPU oracle (kind 'port': a restatement of the reference's PyTorch path, pinned to it
+    by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512."""
+    from oracle import cvae_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    times = []
+    for L, clip in ((50, None), (100, 1.0)):
+        m = O.OracleModel("unimodal", Z_DIM, L)
+        x, src, cls, eps = O.synth_inputs(BATCH, L, Z_DIM)
+        m.train_step((x, src, None), eps, lr=1e-6, clip=clip)        # warm-up
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            m.train_step((x, src, None), eps, lr=1e-6, clip=clip)
+        times.append((time.perf_counter() - t0) / steps)
+    return dict(value=BATCH / sum(times), unit="samples/s", cores=cores, kind="port",
+                sample=f"{steps} steps of wave (L=50) + time (L=100, clip 1.0) cVAE at batch 512, torch {torch.__version__} CPU, "
+                       f"wave {times[0]*1e3:.0f} ms + time {times[1]*1e3:.0f} ms per step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    data = synth_dataset(N_UNITS, device)
+    pair = Pair(device, world)
+    steps_per_epoch = N_UNITS // (BATCH * world)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    perm = torch.randperm(N_UNITS, generator=g).to(device)
+
+    def batch_idx(i):
+        j = (i % steps_per_epoch) * world + rank          # DistributedSampler-style interleave
+        return perm[j * BATCH:(j + 1) * BATCH]
+
+    use_graph = not args.no_graph
+    for i in range(args.warmup):
+        pair.step(data, batch_idx(i), use_graph)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        pair.step(data, batch_idx(args.warmup + i), use_graph)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = [e.scalars()[0] for e in pair.eng]
+
+    if rank == 0:
+        conv_ms, conv_flop, launches, per_kernel = conv_roofline(pair, data, batch_idx(0))
+        achieved = conv_flop / (conv_ms * 1e-3) / 1e12
+        if args.per_op:
+            tot = sum(v[0] for v in per_kernel.values())
+            for name, (ms, cnt) in sorted(per_kernel.items(), key=lambda kv: -kv[1][0]):
+                print(f"{name:18s} {cnt:4d} launches {ms:8.3f} ms {100*ms/tot:5.1f} %", file=sys.stderr)
+            print(f"{'TOTAL (eager, serial)':18s} {tot:8.3f} ms", file=sys.stderr)
+        out = {
+            "metric": "pretrain samples/sec (waveform+time cVAE, batch 512)",
+            "value": BATCH * world * args.steps / dt,
+            "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
+                                   "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "
+                                   "fp32 arithmetic on f32 MFMA (parity path; bf16 not used)",
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                       "final_loss_wave": loss[0], "final_loss_time": loss[1]},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "conv_taps_kernel (fwd conv + dgrad, f32 MFMA 32x32x2)",
+                         "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
+                         "algorithmic_gflop_per_step": conv_flop / 1e9},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -235,7 +235,7 @@ if __name__ == "__main__":
     unimodal_case("wave_z32_L256_B8", z=32, L=256, B=8, with_class=False, beta=1.0, clip=None, steps=1, lr=1e-3, salt=5)
     unimodal_case("time_z32_L32_B8", z=32, L=32, B=8, with_class=False, beta=1.0, clip=None, steps=1, lr=1e-3, salt=6)
     # trajectories at a small learning rate: Adam moves every element by ~lr per step whatever its gradient,
-    # so at lr=1e-3 elements whose gradient is rounding noise make the loss path chaotic; at 1e-5 it is not
-    unimodal_case("wave_z10_L50_B32_traj", z=10, L=50, B=32, with_class=False, beta=1.0, clip=None, steps=6, lr=1e-5, salt=9)
-    unimodal_case("time_z10_L100_B32_traj_clip", z=10, L=100, B=32, with_class=False, beta=1.0, clip=1.0, steps=6, lr=1e-5, salt=10)
+    # so at lr=1e-3 elements whose gradient is rounding noise make the loss path chaotic; at 1e-6 it is not
+    unimodal_case("wave_z10_L50_B32_traj", z=10, L=50, B=32, with_class=False, beta=1.0, clip=None, steps=6, lr=1e-6, salt=9)
+    unimodal_case("time_z10_L100_B32_traj_clip", z=10, L=100, B=32, with_class=False, beta=1.0, clip=1.0, steps=6, lr=1e-6, salt=10)
     multimodal_case("z10_B12", z=10, L1=50, L2=100, B=12, beta=1.0, w1=1.0, w2=0.5, steps=2, lr=1e-3, salt=7)
