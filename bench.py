@@ -145,7 +145,11 @@ def cpu_baseline(steps=3):
     """The torch-CPU oracle (kind 'port': a restatement of the reference's PyTorch path, pinned to it
     by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512."""
     from oracle import cvae_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # a 1-GPU box's CPU share is 16 cores
     torch.set_num_threads(cores)
     times = []
     for L, clip in ((50, None), (100, 1.0)):

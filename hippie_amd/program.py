@@ -123,6 +123,10 @@ def load_library():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # One HIP runtime per process: torch ships its own libamdhip64 (same SONAME as /opt/rocm's).  Import
+    # torch first so that libhippie_hip.so binds to the runtime torch's allocator and streams live in;
+    # loaded the other way round the two runtimes disagree and no device is found.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HipEngineError(f"{LIB_PATH} not found: build it with `make -C hippie_amd/csrc` "
                              "(or __graft_entry__.build()); there is no CPU fallback")
