@@ -169,8 +169,9 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lh == 0 && nok) {
-      atomic_add_f64(p.stats + n, s1);
-      atomic_add_f64(p.stats + t.N + n, s2);
+      double* st = stat_replica(p.stats, t.N, blockIdx.x);
+      atomic_add_f64(st + n, s1);
+      atomic_add_f64(st + t.N + n, s2);
     }
   }
 }

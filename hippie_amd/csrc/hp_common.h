@@ -32,6 +32,17 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
+// sum of one entry of a replicated statistics slot double[HP_STAT_REPL][2][C]
+__device__ __forceinline__ double stat_sum(const double* st, int C, int which, int c) {
+  double s = 0.0;
+#pragma unroll
+  for (int r = 0; r < HP_STAT_REPL; ++r) s += st[(size_t)r * 2 * C + which * C + c];
+  return s;
+}
+__device__ __forceinline__ double* stat_replica(double* st, int C, int key) {
+  return st + (size_t)(key % HP_STAT_REPL) * 2 * C;
+}
+
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
 // derivative expressed on the OUTPUT of leaky_relu (sign(out) == sign(in) for slope > 0)
 __device__ __forceinline__ float lrelu_grad(float out, float slope) { return out > 0.f ? 1.f : slope; }

@@ -63,8 +63,8 @@ __device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* st
   BnCoef k;
   double mean, var;
   if (training) {
-    mean = stats[c] / (double)M;
-    var = stats[C + c] / (double)M - mean * mean;
+    mean = stat_sum(stats, C, 0, c) / (double)M;
+    var = stat_sum(stats, C, 1, c) / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
   } else {
     mean = (double)rmean[c];
@@ -78,6 +78,56 @@ __device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* st
 }
 
 // ---- BN apply --------------------------------------------------------------------
+// V = 4: each thread owns 4 consecutive channels (one 16-byte access per row and tensor);
+// V = 1: scalar fallback for the heads' odd widths (C = 5, 10, ...).
+template <int V> struct Vec;
+template <> struct Vec<4> { using T = float4; };
+template <> struct Vec<1> { using T = float; };
+template <int V> __device__ __forceinline__ float& at(typename Vec<V>::T& v, int j);
+template <> __device__ __forceinline__ float& at<4>(float4& v, int j) { return (&v.x)[j]; }
+template <> __device__ __forceinline__ float& at<1>(float& v, int) { return v; }
+
+template <int V>
+__device__ __forceinline__ ColMap colmap_v(int M, int C, int rpl) {
+  ColMap m;
+  const int cg = C / V;
+  m.cw = cg < 256 ? cg : 256;
+  m.rl = 256 / m.cw;
+  const int tid = threadIdx.x;
+  m.rlane = tid / m.cw;
+  m.c = (blockIdx.y * m.cw + (tid - m.rlane * m.cw)) * V;
+  const int rpb = m.rl * rpl;
+  m.row = blockIdx.x * rpb + m.rlane;
+  m.rstep = m.rl;
+  m.rend = min(M, (int)(blockIdx.x + 1) * rpb);
+  m.active = (m.rlane < m.rl) && (m.c < C);
+  return m;
+}
+template <int V>
+inline dim3 colgrid_v(int M, int C, int rpl) {
+  const int cg = C / V;
+  const int cw = cg < 256 ? cg : 256;
+  return dim3(hp::cdiv(M, (256 / cw) * rpl), hp::cdiv(cg, cw));
+}
+constexpr int rpl_of(int V) { return V == 4 ? 4 : kRowsPerLane; }
+
+// fold NV partials per thread over the row lanes (thread index layout of colmap_v)
+template <int NV>
+__device__ __forceinline__ void fold_rows(const ColMap& m, double (&v)[NV], double* lds /* [NV][256] */) {
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NV; ++k) lds[k * 256 + threadIdx.x] = m.active ? v[k] : 0.0;
+  __syncthreads();
+  if (m.active && m.rlane == 0) {
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      double s = 0.0;
+      for (int r = 0; r < m.rl; ++r) s += lds[k * 256 + r * m.cw + threadIdx.x];
+      v[k] = s;
+    }
+  }
+}
+
 struct BnApplyArgs {
   const float* raw; float* out; const double* stats; const float* gamma; const float* beta;
   float* rmean; float* rvar; float* save;
@@ -96,23 +146,40 @@ __device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, i
   rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
 }
 
+template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
-  const ColMap m = colmap(p.M, p.C);
+  using T = typename Vec<V>::T;
+  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
   if (!m.active) return;
-  const BnCoef k = bn_coef(p.training, p.M, p.stats, p.C, m.c, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
-  BnCoef k2 = k;
-  if (p.res_mode == 2) k2 = bn_coef(p.training, p.M, p.stats2, p.C, m.c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
+  BnCoef k[V], k2[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    k[j] = bn_coef(p.training, p.M, p.stats, p.C, m.c + j, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
+    k2[j] = k[j];
+    if (p.res_mode == 2) k2[j] = bn_coef(p.training, p.M, p.stats2, p.C, m.c + j, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
+  }
   for (int r = m.row; r < m.rend; r += m.rstep) {
     const size_t idx = (size_t)r * p.C + m.c;
-    float v = fmaf(p.raw[idx], k.scale, k.shift);
-    if (p.res_mode == 1) v += p.res[idx];
-    else if (p.res_mode == 2) v += fmaf(p.res[idx], k2.scale, k2.shift);
-    if (p.act) v = lrelu(v, p.slope);
-    p.out[idx] = v;
+    T x = *reinterpret_cast<const T*>(p.raw + idx);
+    T rs = x;
+    if (p.res_mode != 0) rs = *reinterpret_cast<const T*>(p.res + idx);
+    T o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float v = fmaf(at<V>(x, j), k[j].scale, k[j].shift);
+      if (p.res_mode == 1) v += at<V>(rs, j);
+      else if (p.res_mode == 2) v += fmaf(at<V>(rs, j), k2[j].scale, k2[j].shift);
+      if (p.act) v = lrelu(v, p.slope);
+      at<V>(o, j) = v;
+    }
+    *reinterpret_cast<T*>(p.out + idx) = o;
   }
   if (p.training && blockIdx.x == 0 && m.rlane == 0) {
-    bn_side_effects(k, p.M, p.C, m.c, p.save, p.rmean, p.rvar, p.momentum);
-    if (p.res_mode == 2) bn_side_effects(k2, p.M, p.C, m.c, p.save2, p.rmean2, p.rvar2, p.momentum);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      bn_side_effects(k[j], p.M, p.C, m.c + j, p.save, p.rmean, p.rvar, p.momentum);
+      if (p.res_mode == 2) bn_side_effects(k2[j], p.M, p.C, m.c + j, p.save2, p.rmean2, p.rvar2, p.momentum);
+    }
   }
 }
 
@@ -125,33 +192,55 @@ struct BnBwdReduceArgs {
   float slope;
 };
 
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdReduceArgs p) {
-  __shared__ double lds[4 * 256];
-  const ColMap m = colmap(p.M, p.C);
-  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  using T = typename Vec<V>::T;
+  __shared__ double lds[3 * V * 256];
+  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
+  double v[3 * V];
+#pragma unroll
+  for (int j = 0; j < 3 * V; ++j) v[j] = 0.0;
   if (m.active) {
-    const float mean = p.save[m.c], invstd = p.save[p.C + m.c];
-    float mean2 = 0.f, invstd2 = 0.f;
-    if (p.has_second) { mean2 = p.save2[m.c]; invstd2 = p.save2[p.C + m.c]; }
+    float mean[V], invstd[V], mean2[V], invstd2[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      mean[j] = p.save[m.c + j]; invstd[j] = p.save[p.C + m.c + j];
+      mean2[j] = 0.f; invstd2[j] = 0.f;
+      if (p.has_second) { mean2[j] = p.save2[m.c + j]; invstd2[j] = p.save2[p.C + m.c + j]; }
+    }
     for (int r = m.row; r < m.rend; r += m.rstep) {
       const size_t idx = (size_t)r * p.C + m.c;
-      float g = p.g1[idx];
-      if (p.g2 != nullptr) g += p.g2[idx];
-      g *= lrelu_grad(p.act[idx], p.slope);
-      p.gout[idx] = g;
-      v[0] += (double)g;
-      v[1] += (double)g * (double)((p.raw[idx] - mean) * invstd);
-      if (p.has_second) v[3] += (double)g * (double)((p.raw2[idx] - mean2) * invstd2);
+      T g = *reinterpret_cast<const T*>(p.g1 + idx);
+      T a = *reinterpret_cast<const T*>(p.act + idx);
+      T x = *reinterpret_cast<const T*>(p.raw + idx);
+      T gg = g, x2 = x;
+      if (p.g2 != nullptr) gg = *reinterpret_cast<const T*>(p.g2 + idx);
+      if (p.has_second) x2 = *reinterpret_cast<const T*>(p.raw2 + idx);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float gv = at<V>(g, j);
+        if (p.g2 != nullptr) gv += at<V>(gg, j);
+        gv *= lrelu_grad(at<V>(a, j), p.slope);
+        at<V>(g, j) = gv;
+        v[3 * j + 0] += (double)gv;
+        v[3 * j + 1] += (double)gv * (double)((at<V>(x, j) - mean[j]) * invstd[j]);
+        if (p.has_second) v[3 * j + 2] += (double)gv * (double)((at<V>(x2, j) - mean2[j]) * invstd2[j]);
+      }
+      *reinterpret_cast<T*>(p.gout + idx) = g;
     }
-    v[2] = v[0];
   }
-  fold_rowlanes<4>(m, v, lds);
+  fold_rows<3 * V>(m, v, lds);
   if (m.active && m.rlane == 0) {
-    atomic_add_f64(p.bs + m.c, v[0]);
-    atomic_add_f64(p.bs + p.C + m.c, v[1]);
-    if (p.has_second) {
-      atomic_add_f64(p.bs2 + m.c, v[2]);
-      atomic_add_f64(p.bs2 + p.C + m.c, v[3]);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      double* b1 = stat_replica(p.bs, p.C, blockIdx.x);
+      atomic_add_f64(b1 + m.c + j, v[3 * j + 0]);
+      atomic_add_f64(b1 + p.C + m.c + j, v[3 * j + 1]);
+      if (p.has_second) {
+        double* b2 = stat_replica(p.bs2, p.C, blockIdx.x);
+        atomic_add_f64(b2 + m.c + j, v[3 * j + 0]);
+        atomic_add_f64(b2 + p.C + m.c + j, v[3 * j + 2]);
+      }
     }
   }
 }
@@ -162,21 +251,31 @@ struct BnBwdApplyArgs {
   int M, C;
 };
 
+template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs p) {
-  const ColMap m = colmap(p.M, p.C);
+  using T = typename Vec<V>::T;
+  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
   if (!m.active) return;
-  const float mean = p.save[m.c], invstd = p.save[p.C + m.c];
-  const double sg = p.bs[m.c], sgx = p.bs[p.C + m.c];
-  const float c1 = (float)(sg / (double)p.M), c2 = (float)(sgx / (double)p.M);
-  const float sc = p.gamma[m.c] * invstd;
+  float mean[V], invstd[V], c1[V], c2[V], sc[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    mean[j] = p.save[m.c + j]; invstd[j] = p.save[p.C + m.c + j];
+    const double sg = stat_sum(p.bs, p.C, 0, m.c + j), sgx = stat_sum(p.bs, p.C, 1, m.c + j);
+    c1[j] = (float)(sg / (double)p.M); c2[j] = (float)(sgx / (double)p.M);
+    sc[j] = p.gamma[m.c + j] * invstd[j];
+    if (blockIdx.x == 0 && m.rlane == 0) { p.dgamma[m.c + j] = (float)sgx; p.dbeta[m.c + j] = (float)sg; }
+  }
   for (int r = m.row; r < m.rend; r += m.rstep) {
     const size_t idx = (size_t)r * p.C + m.c;
-    const float xh = (p.raw[idx] - mean) * invstd;
-    p.dr[idx] = sc * (p.g[idx] - c1 - xh * c2);
-  }
-  if (blockIdx.x == 0 && m.rlane == 0) {
-    p.dgamma[m.c] = (float)sgx;
-    p.dbeta[m.c] = (float)sg;
+    T x = *reinterpret_cast<const T*>(p.raw + idx);
+    T g = *reinterpret_cast<const T*>(p.g + idx);
+    T o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float xh = (at<V>(x, j) - mean[j]) * invstd[j];
+      at<V>(o, j) = sc[j] * (at<V>(g, j) - c1[j] - xh * c2[j]);
+    }
+    *reinterpret_cast<T*>(p.dr + idx) = o;
   }
 }
 
@@ -205,8 +304,9 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs p) {
   }
   fold_rowlanes<2>(m, v, lds);
   if (p.stats != nullptr && m.active && m.rlane == 0) {
-    atomic_add_f64(p.stats + m.c, v[0]);
-    atomic_add_f64(p.stats + p.C + m.c, v[1]);
+    double* st = stat_replica(p.stats, p.C, blockIdx.x);
+    atomic_add_f64(st + m.c, v[0]);
+    atomic_add_f64(st + p.C + m.c, v[1]);
   }
 }
 
@@ -313,8 +413,9 @@ __global__ void linear_fwd_thread_kernel(LinArgs p) {
   for (int k = 0; k < p.K; ++k) s = fmaf(x[k], w[k], s);
   if (p.Bv != nullptr) s += p.Bv[n];
   if (p.stats != nullptr) {
-    atomic_add_f64(p.stats + n, (double)s);
-    atomic_add_f64(p.stats + p.N + n, (double)s * (double)s);
+    double* st = stat_replica(p.stats, p.N, m);
+    atomic_add_f64(st + n, (double)s);
+    atomic_add_f64(st + p.N + n, (double)s * (double)s);
   }
   if (p.act) s = lrelu(s, p.slope);
   p.Y[(size_t)m * p.ldy + n] = s;
@@ -332,8 +433,9 @@ __global__ __launch_bounds__(256) void linear_fwd_wave_kernel(LinArgs p) {
   if (lane == 0) {
     if (p.Bv != nullptr) s += p.Bv[n];
     if (p.stats != nullptr) {
-      atomic_add_f64(p.stats + n, (double)s);
-      atomic_add_f64(p.stats + p.N + n, (double)s * (double)s);
+      double* st = stat_replica(p.stats, p.N, m);
+      atomic_add_f64(st + n, (double)s);
+      atomic_add_f64(st + p.N + n, (double)s * (double)s);
     }
     if (p.act) s = lrelu(s, p.slope);
     p.Y[(size_t)m * p.ldy + n] = s;
@@ -349,6 +451,21 @@ __global__ void linear_bwd_x_kernel(LinArgs p) {
   if (p.has_mask) s *= lrelu_grad(p.ACT[(size_t)m * p.lda + k], p.slope);
   float* dst = p.DX + (size_t)m * p.ldx + k;
   *dst = p.accumulate ? *dst + s : s;
+}
+// one wave per output when the contraction (N) is long: coalesced DY reads, strided W reads hit L2
+__global__ __launch_bounds__(256) void linear_bwd_x_wave_kernel(LinArgs p) {
+  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (wid >= p.M * p.K) return;
+  const int m = wid / p.K, k = wid - m * p.K;
+  const float* dy = p.DY + (size_t)m * p.ldy;
+  float s = 0.f;
+  for (int n = lane; n < p.N; n += 64) s = fmaf(dy[n], p.W[(size_t)n * p.K + k], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (p.has_mask) s *= lrelu_grad(p.ACT[(size_t)m * p.lda + k], p.slope);
+    float* dst = p.DX + (size_t)m * p.ldx + k;
+    *dst = p.accumulate ? *dst + s : s;
+  }
 }
 // block = (output row n, chunk of <=256 input columns, slice of M); fp32 atomics into zeroed DW/DB
 __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinArgs p, int rows_per_z) {
@@ -582,7 +699,8 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.rmean2 = ptr<float>(op, 12, bases); a.rvar2 = ptr<float>(op, 13, bases); a.save2 = ptr<float>(op, 14, bases);
       a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
       a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
-      hipLaunchKernelGGL(bn_apply_kernel, colgrid(a.M, a.C), dim3(256), 0, s, a);
+      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_apply_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(bn_apply_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_BN_BWD_REDUCE: {
@@ -592,7 +710,8 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.raw = ptr<const float>(op, 4, bases); a.save = ptr<const float>(op, 5, bases); a.bs = ptr<double>(op, 6, bases);
       a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
       a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
-      hipLaunchKernelGGL(bn_bwd_reduce_kernel, colgrid(a.M, a.C), dim3(256), 0, s, a);
+      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_BN_BWD_APPLY: {
@@ -601,7 +720,8 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.bs = ptr<const double>(op, 3, bases); a.gamma = ptr<const float>(op, 4, bases); a.dr = ptr<float>(op, 5, bases);
       a.dgamma = ptr<float>(op, 6, bases); a.dbeta = ptr<float>(op, 7, bases);
       a.M = I[0]; a.C = I[1];
-      hipLaunchKernelGGL(bn_bwd_apply_kernel, colgrid(a.M, a.C), dim3(256), 0, s, a);
+      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_STEM_FWD: {
@@ -665,7 +785,10 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.ACT = ptr<const float>(op, 3, bases);
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4]; a.has_mask = I[5]; a.lda = I[6]; a.accumulate = I[7];
       a.slope = op.f[0];
-      hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(blocks_for((int64_t)a.M * a.K)), dim3(256), 0, s, a);
+      if (a.N >= 128 && (int64_t)a.M * a.K <= (1 << 20))
+        hipLaunchKernelGGL(linear_bwd_x_wave_kernel, dim3(blocks_for((int64_t)a.M * a.K, 4)), dim3(256), 0, s, a);
+      else
+        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(blocks_for((int64_t)a.M * a.K)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_LINEAR_BWD_W: {
@@ -674,8 +797,11 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.DB = ptr<float>(op, 3, bases);
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
       const int kw = a.K < 256 ? a.K : 256;
-      const int rows_per_z = 1024;
-      dim3 grid(a.N, hp::cdiv(a.K, kw), hp::cdiv(a.M, rows_per_z));
+      const int ky = hp::cdiv(a.K, kw);
+      int nz = hp::cdiv(256, a.N * ky);                       // aim at >= 256 workgroups
+      nz = max(1, min(nz, hp::cdiv(a.M, 32)));
+      const int rows_per_z = hp::cdiv(a.M, nz);
+      dim3 grid(a.N, ky, hp::cdiv(a.M, rows_per_z));
       hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(256), 0, s, a, rows_per_z);
       break;
     }
@@ -703,7 +829,7 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
                          ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2]);
       break;
     case HP_OP_TAIL_BWD_W: {
-      const int bper = 8;
+      const int bper = 2;
       hipLaunchKernelGGL(tail_bwd_w_kernel, dim3(hp::cdiv(I[0], bper)), dim3(256), 0, s, ptr<const float>(op, 0, bases),
                          ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], bper);
       break;
@@ -713,7 +839,7 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
                          ptr<float>(op, 1, bases), I[0], I[1], I[2], op.f[0], op.f[1], op.f[2]);
       break;
     case HP_OP_GRADNORM:
-      hipLaunchKernelGGL(gradnorm_kernel, dim3(min(1024, max(1, blocks_for(I[0] >> 2)))), dim3(256), 0, s,
+      hipLaunchKernelGGL(gradnorm_kernel, dim3(min(256, max(1, blocks_for(I[0] >> 2)))), dim3(256), 0, s,
                          ptr<const float>(op, 0, bases), ptr<double>(op, 1, bases), I[0]);
       break;
     case HP_OP_ADAMW: {

@@ -26,6 +26,7 @@ SLOPE_HEADS = 0.2
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 ALIGN = 256
+STAT_REPL = 16          # HP_STAT_REPL
 
 
 @dataclass
@@ -131,8 +132,11 @@ class Plan:
     def f32(self, n, name=None, shape=None):
         return self.ws(4 * n, name, shape if shape is not None else (n,), "f4")
 
-    def stat(self, ndoubles):
-        """fp64 accumulator slots inside the zeroed-every-step statistics region."""
+    def stat(self, ndoubles, replicated=True):
+        """fp64 accumulator slots inside the zeroed-every-step statistics region; per-channel slots
+        are replicated STAT_REPL times (double[STAT_REPL][2][C])."""
+        if replicated:
+            ndoubles *= STAT_REPL
         off = _round_up(self.stats_bytes, 64)
         self.stats_bytes = off + 8 * ndoubles
         assert self.stats_bytes <= self.stats_cap, "statistics region overflow"
@@ -153,7 +157,7 @@ class Plan:
 
 # ======================================================================================
 class Lowering:
-    def __init__(self, cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, wgrad_target_blocks=512):
+    def __init__(self, cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, wgrad_target_blocks=256):
         self.cfg, self.B = cfg, batch
         self.train = train or TrainCfg()
         self.with_class = with_class
@@ -538,7 +542,7 @@ class Lowering:
         # the floats between n_active and cemb.offset (alignment gap) are zero padding
 
         # ---------------- workspace: persistent + I/O ----------------
-        pl.stats_cap = 4 << 20
+        pl.stats_cap = 32 << 20
         pl.stats_base = pl.ws(pl.stats_cap).offset
         self.step_ref = pl.ws(64, "adam_step", (1,), "i8")
         lens = [cfg.output_size] if not multi else [cfg.output_size, cfg.output_size2]
@@ -548,8 +552,8 @@ class Lowering:
         eps = pl.f32(B * z, "eps", (B, z))
         scal = pl.f32(4, "scalars", (4,))
         self.slab = pl.ws(0)                 # sized at the end (placed last)
-        loss = pl.stat(4)
-        norm2 = pl.stat(1)
+        loss = pl.stat(4, replicated=False)
+        norm2 = pl.stat(1, replicated=False)
 
         segs = {}
         for mode in ("train", "eval"):

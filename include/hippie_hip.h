@@ -44,6 +44,11 @@ enum {
 };
 #define HP_NULL ((int64_t)-1)
 #define HP_MAX_TAPS 6
+/* Every per-channel statistics slot ("STATS", "BS": sum / sum-of-squares style fp64 accumulators) is
+ * replicated HP_STAT_REPL times: double[HP_STAT_REPL][2][C].  Producers add into any replica (they pick
+ * one by block index, so concurrent atomics spread over 16x more cache lines); consumers use the sum over
+ * replicas.  The whole statistics region is zeroed at the start of every forward. */
+#define HP_STAT_REPL 16
 #define HP_OP_NI 28
 #define HP_OP_NF 8
 #define HP_OP_NB 16

@@ -12,6 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 NULL = -1
+STAT_REPL = 16    # HP_STAT_REPL: per-channel fp64 slots are double[STAT_REPL][2][C]; this interpreter adds into replica 0
 MASK = (1 << 56) - 1
 
 
@@ -65,7 +66,7 @@ def _lrelu_grad(out, s):
 
 def _bn_coef(A, training, M, C, stats, gamma, beta, rmean, rvar, eps):
     if training:
-        st = A.f64(stats, 2 * C)
+        st = A.f64(stats, STAT_REPL * 2 * C).reshape(STAT_REPL, 2 * C).sum(0)
         mean = st[:C] / M
         var = np.maximum(st[C:] / M - mean * mean, 0.0)
     else:
@@ -174,7 +175,7 @@ def run(ops, A: Arenas, first=0, count=None):
             g = A.f32(b[0], M * C).reshape(M, C)
             raw = A.f32(b[1], M * C).reshape(M, C)
             sv = A.f32(b[2], 2 * C)
-            bs = A.f64(b[3], 2 * C)
+            bs = A.f64(b[3], STAT_REPL * 2 * C).reshape(STAT_REPL, 2 * C).sum(0)
             gamma = A.f32(b[4], C)
             xh = (raw - sv[None, :C]) * sv[None, C:]
             c1 = (bs[:C] / M).astype(np.float32)

@@ -78,6 +78,18 @@ def check(gpu, cpu, ref, n, dtype=np.float32, rel=2e-5, what=""):
     assert np.isfinite(g).all() and err <= rel, f"{what}: rel err {err:.3e} (scale {scale:.3e})"
 
 
+R = interp.STAT_REPL
+
+
+def check_stats(gpu, cpu, ref, C, rel=1e-5, what=""):
+    """replicated fp64 statistics slot double[R][2][C]: only the sum over replicas is defined"""
+    g = view(gpu, ref, np.float64, R * 2 * C).reshape(R, 2 * C).sum(0)
+    c = view(cpu, ref, np.float64, R * 2 * C).reshape(R, 2 * C).sum(0)
+    scale = max(np.abs(c).max(), 1e-20)
+    err = np.abs(g - c).max() / scale
+    assert np.isfinite(g).all() and err <= rel, f"{what}: rel err {err:.3e}"
+
+
 B = 3
 CONV_CASES = {
     # name: (tapmap builder, w_kn, bias, rows_in)
@@ -104,12 +116,12 @@ def test_conv_taps(name):
     w = img.f32(nslab * tm.N * tm.K, scale=0.1)
     out = img.f32(tm.M * tm.N, zero=True)
     bv = img.f32(tm.N) if bias else None
-    st = img.f64(2 * tm.N)
+    st = img.f64(R * 2 * tm.N)
     flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_STATS
     recs = rec_of(P.CONV_TAPS, flags, tm.ints(), (), [a, w, out, bv, st])
     gpu, cpu = run_both(img, recs)
     check(gpu, cpu, out, tm.M * tm.N, what=name + " out")
-    check(gpu, cpu, st, 2 * tm.N, np.float64, rel=1e-5, what=name + " stats")
+    check_stats(gpu, cpu, st, tm.N, what=name + " stats")
 
 
 def test_conv_mfma_layout_identity():
@@ -182,7 +194,7 @@ def test_bn_apply_and_backward(C, M, res_mode):
     rm, rm2 = img.f32(C, 0.1), img.f32(C, 0.1)
     rv, rv2 = img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5), img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5)
     save, save2 = img.f32(2 * C, zero=True), img.f32(2 * C, zero=True)
-    st, st2 = img.f64(2 * C), img.f64(2 * C)
+    st, st2 = img.f64(R * 2 * C), img.f64(R * 2 * C)
     # statistics as the producing conv would have accumulated them (patched into the fp64 chunks)
     def chunk_array(ref):
         o = 0
@@ -195,10 +207,10 @@ def test_bn_apply_and_backward(C, M, res_mode):
     for s_ref, r_ref in ((st, raw), (st2, raw2)):
         r = chunk_array(r_ref).reshape(M, C).astype(np.float64)
         chunk_array(s_ref)[:C] = r.sum(0)
-        chunk_array(s_ref)[C:] = (r * r).sum(0)
+        chunk_array(s_ref)[C: 2 * C] = (r * r).sum(0)
     g1, g2 = img.f32(M * C), img.f32(M * C)
     gout, dr, dr2 = img.f32(M * C, zero=True), img.f32(M * C, zero=True), img.f32(M * C, zero=True)
-    bs, bs2 = img.f64(2 * C), img.f64(2 * C)
+    bs, bs2 = img.f64(R * 2 * C), img.f64(R * 2 * C)
     dgam, dbet, dgam2, dbet2 = (img.f32(C, zero=True) for _ in range(4))
     ol = P.OpList()
     bufs = [raw, out, st, gamma, beta, rm, rv, save]
@@ -217,7 +229,7 @@ def test_bn_apply_and_backward(C, M, res_mode):
     for ref, n, nm in ((out, M * C, "out"), (save, 2 * C, "save"), (rm, C, "rmean"), (rv, C, "rvar"), (gout, M * C, "g"),
                        (dr, M * C, "dr"), (dgam, C, "dgamma"), (dbet, C, "dbeta")):
         check(gpu, cpu, ref, n, rel=3e-5, what=f"bn {nm}")
-    check(gpu, cpu, bs, 2 * C, np.float64, rel=1e-5, what="bn bs")
+    check_stats(gpu, cpu, bs, C, what="bn bs")
     if res_mode == 2:
         check(gpu, cpu, dr2, M * C, rel=3e-5, what="bn dr2")
         check(gpu, cpu, rv2, C, rel=3e-5, what="bn rvar2")
@@ -241,14 +253,14 @@ def test_stem(Bn, Lin):
     Lout = (Lin - 1) // 2 + 1
     img = Img(7)
     x, w = img.f32(Bn * Lin), img.f32(64 * 3)
-    out, st = img.f32(Bn * Lout * 64, zero=True), img.f64(128)
+    out, st = img.f32(Bn * Lout * 64, zero=True), img.f64(R * 128)
     dr, dw = img.f32(Bn * Lout * 64), img.f32(192, zero=True)
     ol = P.OpList()
     ol.add(P.STEM_FWD, 0, [Bn, Lin, Lout, 64], (), [x, w, out, st])
     ol.add(P.STEM_WGRAD, 0, [Bn, Lin, Lout, 64], (), [dr, x, dw])
     gpu, cpu = run_both(img, ol.array())
     check(gpu, cpu, out, Bn * Lout * 64, what="stem out")
-    check(gpu, cpu, st, 128, np.float64, rel=1e-5, what="stem stats")
+    check_stats(gpu, cpu, st, 64, what="stem stats")
     check(gpu, cpu, dw, 192, rel=3e-5, what="stem dW")
 
 
@@ -283,7 +295,7 @@ def test_linear_family(M, N, K):
     ldx, ldy = K + 3, N + 2
     x, w, bv = img.f32(M * ldx), img.f32(N * K, 0.2), img.f32(N)
     y = img.f32(M * ldy, zero=True)
-    st = img.f64(2 * N)
+    st = img.f64(R * 2 * N)
     dy = img.f32(M * ldy)
     dx = img.f32(M * ldx, zero=True)
     dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
@@ -294,7 +306,7 @@ def test_linear_family(M, N, K):
     ol.add(P.LINEAR_BWD_W, 0, [M, N, K, ldy, ldx], (), [dy, x, dw, db])
     gpu, cpu = run_both(img, ol.array())
     check(gpu, cpu, y, M * ldy, rel=3e-5, what="linear y")
-    check(gpu, cpu, st, 2 * N, np.float64, rel=1e-5, what="linear stats")
+    check_stats(gpu, cpu, st, N, what="linear stats")
     check(gpu, cpu, dx, M * ldx, rel=3e-5, what="linear dx")
     check(gpu, cpu, dw, N * K, rel=3e-5, what="linear dw")
     check(gpu, cpu, db, N, rel=3e-5, what="linear db")
