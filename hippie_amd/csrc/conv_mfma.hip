@@ -199,6 +199,7 @@ struct WgradArgs {
   const float* DY; const float* X; float* slab;
   TapMap t;
   int nsplit, rows_per_split, slab_stride;
+  int atomic;   // 1: accumulate into `slab` (= the zeroed gradient tensor) with fp32 atomics, no slabs
 };
 
 template <int NT>
@@ -278,11 +279,15 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
   if (c < t.K) {
 #pragma unroll
     for (int tau = 0; tau < NT; ++tau) {
-      float* dst = p.slab + (size_t)split * p.slab_stride + (size_t)t.tap_w[tau] * t.N * t.K;
+      float* dst = p.slab + (p.atomic ? (size_t)0 : (size_t)split * p.slab_stride) + (size_t)t.tap_w[tau] * t.N * t.K;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < t.N) dst[(size_t)n * t.K + c] = acc[tau][r];
+        if (n < t.N) {
+          // a half-wave writes/adds one 128-byte row segment: the full-rate shape for float atomics
+          if (p.atomic) atomic_add_f32(dst + (size_t)n * t.K + c, acc[tau][r]);
+          else dst[(size_t)n * t.K + c] = acc[tau][r];
+        }
       }
     }
   }
@@ -297,6 +302,7 @@ hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t
   a.nsplit = op.i[22];
   a.rows_per_split = op.i[23];
   a.slab_stride = op.i[24];
+  a.atomic = op.flags & 1;
   dim3 grid(hp::cdiv(a.t.N, 64) * hp::cdiv(a.t.K, 64), a.nsplit);
   if (a.t.ntaps == 1)      hipLaunchKernelGGL(wgrad_taps_kernel<1>, grid, dim3(256), 0, s, a);
   else if (a.t.ntaps == 3) hipLaunchKernelGGL(wgrad_taps_kernel<3>, grid, dim3(256), 0, s, a);

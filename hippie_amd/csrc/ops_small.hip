@@ -149,14 +149,32 @@ __device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, i
 template <int V>
 __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
   using T = typename Vec<V>::T;
+  __shared__ float s_coef[4][256 * V];     // scale, shift, scale2, shift2 of this block's channels
   const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
+  // each channel's (replicated) statistics are summed ONCE per block, not once per thread
+  for (int ci = threadIdx.x; ci < m.cw * V; ci += 256) {
+    const int c = blockIdx.y * m.cw * V + ci;
+    if (c >= p.C) continue;
+    const BnCoef k = bn_coef(p.training, p.M, p.stats, p.C, c, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
+    s_coef[0][ci] = k.scale; s_coef[1][ci] = k.shift;
+    BnCoef k2 = k;
+    if (p.res_mode == 2) {
+      k2 = bn_coef(p.training, p.M, p.stats2, p.C, c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
+      s_coef[2][ci] = k2.scale; s_coef[3][ci] = k2.shift;
+    }
+    if (p.training && blockIdx.x == 0) {
+      bn_side_effects(k, p.M, p.C, c, p.save, p.rmean, p.rvar, p.momentum);
+      if (p.res_mode == 2) bn_side_effects(k2, p.M, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
+    }
+  }
+  __syncthreads();
   if (!m.active) return;
-  BnCoef k[V], k2[V];
+  const int ci0 = (threadIdx.x - m.rlane * m.cw) * V;
+  float sc[V], sh[V], sc2[V], sh2[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    k[j] = bn_coef(p.training, p.M, p.stats, p.C, m.c + j, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
-    k2[j] = k[j];
-    if (p.res_mode == 2) k2[j] = bn_coef(p.training, p.M, p.stats2, p.C, m.c + j, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
+    sc[j] = s_coef[0][ci0 + j]; sh[j] = s_coef[1][ci0 + j];
+    sc2[j] = p.res_mode == 2 ? s_coef[2][ci0 + j] : 0.f; sh2[j] = p.res_mode == 2 ? s_coef[3][ci0 + j] : 0.f;
   }
   for (int r = m.row; r < m.rend; r += m.rstep) {
     const size_t idx = (size_t)r * p.C + m.c;
@@ -166,20 +184,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
     T o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      float v = fmaf(at<V>(x, j), k[j].scale, k[j].shift);
+      float v = fmaf(at<V>(x, j), sc[j], sh[j]);
       if (p.res_mode == 1) v += at<V>(rs, j);
-      else if (p.res_mode == 2) v += fmaf(at<V>(rs, j), k2[j].scale, k2[j].shift);
+      else if (p.res_mode == 2) v += fmaf(at<V>(rs, j), sc2[j], sh2[j]);
       if (p.act) v = lrelu(v, p.slope);
       at<V>(o, j) = v;
     }
     *reinterpret_cast<T*>(p.out + idx) = o;
-  }
-  if (p.training && blockIdx.x == 0 && m.rlane == 0) {
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      bn_side_effects(k[j], p.M, p.C, m.c + j, p.save, p.rmean, p.rvar, p.momentum);
-      if (p.res_mode == 2) bn_side_effects(k2[j], p.M, p.C, m.c + j, p.save2, p.rmean2, p.rvar2, p.momentum);
-    }
   }
 }
 
@@ -254,16 +265,26 @@ struct BnBwdApplyArgs {
 template <int V>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs p) {
   using T = typename Vec<V>::T;
+  __shared__ float s_coef[5][256 * V];     // mean, invstd, c1, c2, gamma*invstd
   const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
+  for (int ci = threadIdx.x; ci < m.cw * V; ci += 256) {
+    const int c = blockIdx.y * m.cw * V + ci;
+    if (c >= p.C) continue;
+    const float mean = p.save[c], invstd = p.save[p.C + c];
+    const double sg = stat_sum(p.bs, p.C, 0, c), sgx = stat_sum(p.bs, p.C, 1, c);
+    s_coef[0][ci] = mean; s_coef[1][ci] = invstd;
+    s_coef[2][ci] = (float)(sg / (double)p.M); s_coef[3][ci] = (float)(sgx / (double)p.M);
+    s_coef[4][ci] = p.gamma[c] * invstd;
+    if (blockIdx.x == 0) { p.dgamma[c] = (float)sgx; p.dbeta[c] = (float)sg; }
+  }
+  __syncthreads();
   if (!m.active) return;
+  const int ci0 = (threadIdx.x - m.rlane * m.cw) * V;
   float mean[V], invstd[V], c1[V], c2[V], sc[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
-    mean[j] = p.save[m.c + j]; invstd[j] = p.save[p.C + m.c + j];
-    const double sg = stat_sum(p.bs, p.C, 0, m.c + j), sgx = stat_sum(p.bs, p.C, 1, m.c + j);
-    c1[j] = (float)(sg / (double)p.M); c2[j] = (float)(sgx / (double)p.M);
-    sc[j] = p.gamma[m.c + j] * invstd[j];
-    if (blockIdx.x == 0 && m.rlane == 0) { p.dgamma[m.c + j] = (float)sgx; p.dbeta[m.c + j] = (float)sg; }
+    mean[j] = s_coef[0][ci0 + j]; invstd[j] = s_coef[1][ci0 + j];
+    c1[j] = s_coef[2][ci0 + j]; c2[j] = s_coef[3][ci0 + j]; sc[j] = s_coef[4][ci0 + j];
   }
   for (int r = m.row; r < m.rend; r += m.rstep) {
     const size_t idx = (size_t)r * p.C + m.c;

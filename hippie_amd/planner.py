@@ -51,6 +51,7 @@ class TrainCfg:
     beta1: float = 0.9
     beta2: float = 0.999
     adam_eps: float = 1e-8
+    deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
 
 
 @dataclass
@@ -248,6 +249,9 @@ class Lowering:
         nsplit = max(1, min(self.target_blocks // tiles, -(-tm.M // 64)))
         rps = _round_up(-(-tm.M // nsplit), 32)
         nsplit = -(-tm.M // rps)
+        if not self.train.deterministic_wgrad:
+            self.o.add(P.WGRAD_TAPS, 1, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
+            return
         self.pl.slab_need = max(self.pl.slab_need, nsplit * w.numel)
         self.o.add(P.WGRAD_TAPS, 0, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, self.slab], note=note)
         self.o.add(P.SLAB_REDUCE, 0, i=[w.numel, nsplit, w.numel], buf=[self.slab, w.gref], note=note + " reduce")
@@ -679,7 +683,7 @@ class Lowering:
             self.o.recs[segs[key]]["i"][1] = 0
         slab = pl.ws(4 * max(pl.slab_need, 4))
         for r in self.o.recs:
-            if int(r["op"]) == P.WGRAD_TAPS:
+            if int(r["op"]) == P.WGRAD_TAPS and not (int(r["flags"]) & 1):
                 r["buf"][2] = slab.encode()
             elif int(r["op"]) == P.SLAB_REDUCE:
                 r["buf"][0] = slab.encode()

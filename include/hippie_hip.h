@@ -82,7 +82,9 @@ enum {
   /* slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]; f32 MFMA.
    * Replaces the weight-gradient half of ATen convolution_backward.
    * i[22]=nsplit i[23]=rows_per_split (multiple of 32) i[24]=slab stride per split (floats).
-   * buf: 0 DY, 1 X, 2 SLAB */
+   * flags: 1 = no slabs: every split adds its tile into buf[2] (the zeroed gradient tensor
+   * [tap_w][N][K]) with fp32 atomics (faster, summation order not reproducible bit for bit).
+   * buf: 0 DY, 1 X, 2 SLAB (or gradient) */
   HP_OP_WGRAD_TAPS = 2,
   /* out[j] = sum_s slab[s*stride + j], j < n.  i[0]=n i[1]=nsplit i[2]=stride. buf: 0 SLAB 1 OUT */
   HP_OP_SLAB_REDUCE = 3,

@@ -121,15 +121,20 @@ def run(ops, A: Arenas, first=0, count=None):
             nin = (M // Lout) * Lin
             DY = A.f32(b[0], M * N).reshape(M, N).astype(np.float64)
             X = A.f32(b[1], nin * K).reshape(nin, K)
-            slab = A.f32(b[2], nsplit * stride)
-            slab[:] = 0  # the kernel writes every tile of every split it owns
+            atomic = flags & 1
+            slab = A.f32(b[2], stride if atomic else nsplit * stride)
+            if not atomic:
+                slab[:] = 0  # the kernel writes every tile of every split it owns
             for s in range(nsplit):
                 lo, hi = s * rps, min(M, (s + 1) * rps)
                 for off, w in taps:
                     src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, even, off)
                     Xg = np.where(ok[:, None], X[src], 0).astype(np.float64)
                     part = DY[lo:hi].T @ Xg[lo:hi]
-                    slab[s * stride + w * N * K: s * stride + (w + 1) * N * K] = part.astype(np.float32).reshape(-1)
+                    if atomic:
+                        slab[w * N * K: (w + 1) * N * K] += part.astype(np.float32).reshape(-1)
+                    else:
+                        slab[s * stride + w * N * K: s * stride + (w + 1) * N * K] = part.astype(np.float32).reshape(-1)
         elif op == 3:    # SLAB_REDUCE
             n, nsplit, stride = int(i[0]), int(i[1]), int(i[2])
             slab = A.f32(b[0], nsplit * stride)

@@ -151,6 +151,24 @@ WGRAD_CASES = {
 
 
 @pytest.mark.parametrize("name", list(WGRAD_CASES))
+@pytest.mark.parametrize("nsplit", [1, 4])
+def test_wgrad_taps_atomic(name, nsplit):
+    """flags=1: splits accumulate straight into the (pre-zeroed, here pre-filled) gradient tensor."""
+    tm = WGRAD_CASES[name]()
+    img = Img(13)
+    nb = tm.M // tm.Lout
+    dy = img.f32(tm.M * tm.N)
+    x = img.f32(nb * tm.Lin * tm.K)
+    numel = len(tm.taps) * tm.N * tm.K
+    rps = -(-(-(-tm.M // nsplit)) // 32) * 32
+    ns = -(-tm.M // rps)
+    grad = img.f32(numel, scale=0.5)          # accumulates on top of what is there
+    recs = rec_of(P.WGRAD_TAPS, 1, tm.ints() + [ns, rps, numel], (), [dy, x, grad])
+    gpu, cpu = run_both(img, recs)
+    check(gpu, cpu, grad, numel, rel=3e-5, what=f"wgrad atomic {name}")
+
+
+@pytest.mark.parametrize("name", list(WGRAD_CASES))
 @pytest.mark.parametrize("nsplit", [1, 3])
 def test_wgrad_taps(name, nsplit):
     tm = WGRAD_CASES[name]()

@@ -14,9 +14,9 @@ from tests import helpers as H
 torch.set_num_threads(4)
 
 
-def run_case(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0):
+def run_case(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, deterministic=False):
     cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=L, output_size2=L2 or 100)
-    tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2)
+    tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2, deterministic_wgrad=deterministic)
     plan = planner.lower(cfg, B, tc, with_class=with_class)
     ops = plan.ops.array()
     A = H.make_arenas(plan)
@@ -123,6 +123,11 @@ def test_unimodal_time_step_with_clip_and_class_labels():
 
 def test_unimodal_odd_length():
     run_case("unimodal", 10, 32, 5, False, 1.0, None, 1e-3, 6)
+
+
+def test_unimodal_deterministic_wgrad_slabs():
+    plan = run_case("unimodal", 10, 50, 4, False, 1.0, None, 1e-3, 2, deterministic=True)
+    assert any(int(r["op"]) == P.SLAB_REDUCE for r in plan.ops.recs)
 
 
 def test_multimodal_step():
