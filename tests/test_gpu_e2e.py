@@ -246,8 +246,9 @@ def test_graph_replay_equals_eager_and_is_repeatable():
     a, b = eng.state_dict(), eng2.state_dict()
     for k in a:
         if a[k].dtype.is_floating_point:
-            # fp64 atomics make the statistics order-dependent in the last bits only
-            H.assert_adam_close(n(b[k]), n(a[k]), c["lr"], k, steps=3)
+            # atomics (fp64 statistics, fp32 wgrad accumulation) make sums order-dependent in the last
+            # bits; Adam turns that into +-lr moves on noise-gradient elements only
+            H.assert_adam_close(n(b[k]), n(a[k]), c["lr"], k, steps=3, frac=5e-2)
     np.testing.assert_allclose(eng.scalars(), eng2.scalars(), rtol=1e-4)
     assert eng2.adam_step == 3
 
