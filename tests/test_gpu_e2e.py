@@ -246,6 +246,9 @@ def test_graph_replay_equals_eager_and_is_repeatable():
     a, b = eng.state_dict(), eng2.state_dict()
     for k in a:
         if a[k].dtype.is_floating_point:
+            if re.search(H.ZERO_GRAD_RE, k):
+                assert np.abs(n(a[k]) - n(b[k])).max() <= 3 * 2.2 * c["lr"], k
+                continue
             # atomics (fp64 statistics, fp32 wgrad accumulation) make sums order-dependent in the last
             # bits; Adam turns that into +-lr moves on noise-gradient elements only
             H.assert_adam_close(n(b[k]), n(a[k]), c["lr"], k, steps=3, frac=5e-2)
