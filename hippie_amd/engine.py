@@ -60,7 +60,8 @@ class Engine:
         ref, shape, dt = self.plan.io[name]
         tdt = torch.float32 if dt == "f4" else torch.int64
         nb = int(np.prod(shape)) * (4 if dt == "f4" else 8)
-        return self.ws[ref.offset: ref.offset + nb].view(tdt).view(*shape)
+        arena = self.ws if ref.space == P.WS else self.bufs.view(torch.uint8)
+        return arena[ref.offset: ref.offset + nb].view(tdt).view(*shape)
 
     def ws_f32(self, ref, n):
         return self.ws[ref.offset: ref.offset + 4 * n].view(torch.float32)

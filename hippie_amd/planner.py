@@ -548,7 +548,11 @@ class Lowering:
         # ---------------- workspace: persistent + I/O ----------------
         pl.stats_cap = 32 << 20
         pl.stats_base = pl.ws(pl.stats_cap).offset
-        self.step_ref = pl.ws(64, "adam_step", (1,), "i8")
+        # AdamW step counter: in the BUF arena, so that engines lowered for other batch sizes share it
+        step_off = _round_up(pl._boff, 4)
+        pl._boff = step_off + 4
+        self.step_ref = Ref(P.BUF, step_off * 4)
+        pl.io["adam_step"] = (self.step_ref, (1,), "i8")
         lens = [cfg.output_size] if not multi else [cfg.output_size, cfg.output_size2]
         xs = [pl.f32(B * L, "x" if i == 0 else "x2", (B, 1, L)) for i, L in enumerate(lens)]
         self.src = pl.ws(8 * B, "src", (B,), "i8")
