@@ -219,8 +219,8 @@ class _Optimizer:
         step = 0
         for i, k in enumerate(names):
             st = sd["state"].get(i)
-            if st is None or k not in eng.plan.params:
-                continue
+            if st is None or k not in eng.plan.params or tuple(st["exp_avg"].shape) != tuple(eng.plan.params[k].shape):
+                continue                      # e.g. a class_embedding re-created with another num_classes
             eng.param_view(k, eng.m).copy_(st["exp_avg"].to(eng.device))
             eng.param_view(k, eng.v).copy_(st["exp_avg_sq"].to(eng.device))
             step = max(step, int(st["step"]))
