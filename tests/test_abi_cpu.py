@@ -1,0 +1,72 @@
+"""CPU: the C-ABI library loads and exports every symbol include/hippie_hip.h declares; program
+validation (no GPU needed) accepts the planner's output and rejects malformed records."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hippie_amd import planner, program as P
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "hippie_hip.h")).read()
+    declared = set(re.findall(r"\b(hp_[a-z_]+)\s*\(", hdr))
+    assert declared == set(P.EXPORTS), declared ^ set(P.EXPORTS)
+    lib = P.load_library()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.hp_abi_version() == 1
+
+
+def test_op_record_layout_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "hippie_hip.h")).read()
+    ni = int(re.search(r"#define HP_OP_NI (\d+)", hdr).group(1))
+    nf = int(re.search(r"#define HP_OP_NF (\d+)", hdr).group(1))
+    nb = int(re.search(r"#define HP_OP_NB (\d+)", hdr).group(1))
+    assert (ni, nf, nb) == (P.NI, P.NF, P.NB)
+    assert P.OP_DTYPE.itemsize == 8 + 4 * ni + 4 * nf + 8 * nb
+    assert int(re.search(r"#define HP_STAT_REPL (\d+)", hdr).group(1)) == planner.STAT_REPL
+    for name, val in re.findall(r"HP_OP_([A-Z_]+) = (\d+)", hdr):
+        assert getattr(P, name) == int(val), name
+
+
+def _create(ops, sizes):
+    lib = P.load_library()
+    bases = (ctypes.c_void_p * 6)(*[ctypes.c_void_p(0x1000)] * 6)     # never dereferenced by create/validate
+    sz = (ctypes.c_int64 * 6)(*sizes)
+    h = ctypes.c_void_p()
+    rc = lib.hp_program_create(ops.ctypes.data_as(ctypes.c_void_p), len(ops), bases, sz, ctypes.byref(h))
+    msg = lib.hp_last_error().decode()
+    if rc == 0:
+        lib.hp_program_destroy(h)
+    return rc, msg
+
+
+@pytest.mark.parametrize("kind", ["unimodal", "multimodal"])
+def test_planner_programs_validate_without_gpu(kind):
+    plan = planner.lower(planner.ModelCfg(kind=kind, z_dim=10, output_size=50, output_size2=100), 512,
+                         planner.TrainCfg(lr=1e-3, clip=1.0))
+    ops = plan.ops.array()
+    n = plan.n_param_floats * 4
+    sizes = [plan.ws_bytes, n, n, plan.n_buf_floats * 4, n, n]
+    rc, msg = _create(ops, sizes)
+    assert rc == 0, msg
+    # an arena that is too small, an unknown opcode and a bad tap map are all refused with a message
+    rc, msg = _create(ops, [plan.ws_bytes // 2] + sizes[1:])
+    assert rc != 0 and "out of range" in msg
+    bad = ops.copy()
+    bad[3]["op"] = 99
+    rc, msg = _create(bad, sizes)
+    assert rc != 0 and "unknown opcode" in msg
+    bad = ops.copy()
+    k = [i for i, r in enumerate(bad) if int(r["op"]) == P.CONV_TAPS][0]
+    bad[k]["i"][2] = 30          # K not a multiple of 4
+    rc, msg = _create(bad, sizes)
+    assert rc != 0 and "tap-map" in msg
+    segs = plan.ops.segments
+    assert set(segs) == {"fwd_train", "bwd", "opt", "fwd_eval"}
+    assert sum(c for _, c in segs.values()) == len(ops)
