@@ -113,7 +113,7 @@ class Pair:
             cur.wait_stream(s)
 
 
-def conv_roofline(pair, data, idx, reps=3):
+def conv_roofline(pair, data, idx, reps=3, detail=None):
     """Per-launch HIP-event timing of every CONV_TAPS op (eager replay of the same programs)."""
     tot_ms, tot_flop, launches = 0.0, 0.0, 0
     per_kernel = {}
@@ -138,6 +138,10 @@ def conv_roofline(pair, data, idx, reps=3):
                     tot_flop += 2.0 * M * N * K * nt
                     tot_ms += acc[j]
                     launches += 1
+                if detail is not None and int(r["op"]) in (P.CONV_TAPS, P.WGRAD_TAPS):
+                    M, N, K, nt = int(r["i"][0]), int(r["i"][1]), int(r["i"][2]), int(r["i"][9])
+                    fl = 2.0 * M * N * K * nt
+                    detail.append((name, e.plan.ops.notes[first + j], M, N, K, nt, int(r["flags"]), acc[j] * 1e3, fl / (acc[j] * 1e-3) / 1e12))
     return tot_ms, tot_flop, launches, per_kernel
 
 
@@ -219,13 +223,16 @@ def main():
     loss = [e.scalars()[0] for e in pair.eng]
 
     if rank == 0:
-        conv_ms, conv_flop, launches, per_kernel = conv_roofline(pair, data, batch_idx(0))
+        detail = [] if args.per_op else None
+        conv_ms, conv_flop, launches, per_kernel = conv_roofline(pair, data, batch_idx(0), detail=detail)
         achieved = conv_flop / (conv_ms * 1e-3) / 1e12
         if args.per_op:
             tot = sum(v[0] for v in per_kernel.values())
             for name, (ms, cnt) in sorted(per_kernel.items(), key=lambda kv: -kv[1][0]):
                 print(f"{name:18s} {cnt:4d} launches {ms:8.3f} ms {100*ms/tot:5.1f} %", file=sys.stderr)
             print(f"{'TOTAL (eager, serial)':18s} {tot:8.3f} ms", file=sys.stderr)
+            for d in detail:
+                print("%-11s %-46s M=%6d N=%4d K=%4d taps=%d fl=%d %8.1f us %6.1f TF" % d, file=sys.stderr)
         out = {
             "metric": "pretrain samples/sec (waveform+time cVAE, batch 512)",
             "value": BATCH * world * args.steps / dt,

@@ -77,11 +77,15 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
   const size_t wslab = (size_t)t.N * t.K;
 
   float4 ra[2], rb[2];
-  auto load_regs = [&](int step) {
-    const int tap = step / kper;
-    const int c0 = (step - tap * kper) << 5;
-    const int to = t.tap_o[tap];
-    const float* wp = p.W + (size_t)t.tap_w[tap] * wslab;
+  // (tap, k-slice) of the NEXT slice to fetch, advanced incrementally: no division and no scalar
+  // kernarg load inside the K loop except at tap boundaries (scalar loads share lgkmcnt with LDS ops)
+  int n_tap = 0, n_c0 = 0;
+  int cur_to = t.tap_o[0];
+  const float* cur_wp = p.W + (size_t)t.tap_w[0] * wslab;
+  auto load_regs = [&]() {
+    const int c0 = n_c0;
+    const int to = cur_to;
+    const float* wp = cur_wp;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int pos = rl[j] + to;
@@ -95,6 +99,15 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
       } else {
         const int k = c0 + kr + 16 * j, n = n0 + nq;
         if (k < t.K && n < t.N) rb[j] = *reinterpret_cast<const float4*>(wp + (size_t)k * t.N + n);
+      }
+    }
+    n_c0 += 32;
+    if (n_c0 >= t.K) {
+      n_c0 = 0;
+      ++n_tap;
+      if (n_tap < t.ntaps) {
+        cur_to = t.tap_o[n_tap];
+        cur_wp = p.W + (size_t)t.tap_w[n_tap] * wslab;
       }
     }
   };
@@ -117,32 +130,39 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
 
-  load_regs(0);
+  load_regs();
   store_lds(0);
   __syncthreads();
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nsteps) load_regs(s + 1);
     const float* As = smem + buf * TILE + (wm * 32 + li) * LDA + lh * 4;
     const float* Bs = smem + 2 * TILE + buf * TILE;
+    // (1) all LDS fragment reads of this slice go out first, into distinct registers, so that their
+    //     latency overlaps the address arithmetic below and the first MFMAs.
+    //     lane (i,h) takes k = 8kk+4h .. +3 of its row; MFMA jj pairs element jj of both operands,
+    //     i.e. a K permutation applied identically to A and B.
+    float4 a4[4], b4[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      // lane (i,h) takes k = 8kk+4h .. +3 of its row; MFMA jj pairs element jj of both
-      // operands, i.e. a K permutation applied identically to A and B.
-      const float4 a4 = *reinterpret_cast<const float4*>(As + kk * 8);
-      float4 b4;
+      a4[kk] = *reinterpret_cast<const float4*>(As + kk * 8);
       if (!W_KN) {
-        b4 = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDA + kk * 8 + lh * 4);
+        b4[kk] = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDA + kk * 8 + lh * 4);
       } else {
         const float* bk = Bs + (kk * 8 + lh * 4) * LDBK + wn * 32 + li;
-        b4 = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);
+        b4[kk] = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);
       }
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc4[kk], 0, 0, 0);
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc4[kk], 0, 0, 0);
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc4[kk], 0, 0, 0);
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc4[kk], 0, 0, 0);
     }
-    if (s + 1 < nsteps) store_lds(buf ^ 1);
+    // (2) global loads of the next slice are in flight under the whole MFMA block
+    if (s + 1 < nsteps) load_regs();
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      // (3) the LDS stores of the next slice (other buffer) sit before the last MFMA group
+      if (kk == 3 && s + 1 < nsteps) store_lds(buf ^ 1);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].x, b4[kk].x, acc4[kk], 0, 0, 0);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].y, b4[kk].y, acc4[kk], 0, 0, 0);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].z, b4[kk].z, acc4[kk], 0, 0, 0);
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].w, b4[kk].w, acc4[kk], 0, 0, 0);
+    }
     __syncthreads();
   }
 
@@ -217,6 +237,15 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
 
   const int lr = tid >> 4, cq = (tid & 15) << 2;
   float4 rdy[2], rx[NT][2];
+  // (sample, position) of this thread's two rows, advanced by 32 rows per slice without divisions
+  int rb_[2], rl_[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = mbeg + lr + 16 * j;
+    rb_[j] = m / t.Lout;
+    rl_[j] = m - rb_[j] * t.Lout;
+  }
+  const int q32 = 32 / t.Lout, r32 = 32 - q32 * t.Lout;
   auto load_regs = [&](int mb) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -224,8 +253,10 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
       const bool mv = m < mend;
       rdy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (mv && n0 + cq < t.N) rdy[j] = *reinterpret_cast<const float4*>(p.DY + (size_t)m * t.N + n0 + cq);
-      const int b = m / t.Lout;
-      const int al = t.a * (m - b * t.Lout);
+      const int b = rb_[j];
+      const int al = t.a * rl_[j];
+      rl_[j] += r32; rb_[j] += q32;
+      if (rl_[j] >= t.Lout) { rl_[j] -= t.Lout; ++rb_[j]; }
 #pragma unroll
       for (int tau = 0; tau < NT; ++tau) {
         const int pos = al + t.tap_o[tau];
@@ -260,12 +291,20 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
       if (more) load_regs(mb + 32);
       const float* dys = smem + lh * 64 + wn * 32 + li;
       const float* xs = smem + T + lh * 64 + wc * 32 + li;
+      // all operand reads of the slice go out before the MFMA block (distinct registers), so the
+      // matrix pipe never waits on an LDS round trip inside the slice
+      float av[16], bv[NT][16];
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
-        const float a = dys[kk * 128];
+        av[kk] = dys[kk * 128];
+#pragma unroll
+        for (int tau = 0; tau < NT; ++tau) bv[tau][kk] = xs[tau * T + kk * 128];
+      }
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
 #pragma unroll
         for (int tau = 0; tau < NT; ++tau)
-          acc[tau] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xs[tau * T + kk * 128], acc[tau], 0, 0, 0);
+          acc[tau] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[tau][kk], acc[tau], 0, 0, 0);
       }
       __syncthreads();
       if (more) {

@@ -246,7 +246,9 @@ class Lowering:
 
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note=""):
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
-        nsplit = max(1, min(self.target_blocks // tiles, -(-tm.M // 64)))
+        # enough workgroups to fill 256 CUs, but at least 256 rows (8 K-slices) per split so that the
+        # tile's atomics / slab traffic stays small next to its MFMA work
+        nsplit = max(1, min(self.target_blocks // tiles, -(-tm.M // 256)))
         rps = _round_up(-(-tm.M // nsplit), 32)
         nsplit = -(-tm.M // rps)
         if not self.train.deterministic_wgrad:
