@@ -25,6 +25,11 @@ static TapMap tapmap_from(const HpOp& op) {
   return t;
 }
 
+// per-component select (v_cndmask): a ternary on a whole float4 is lowered to a stack-array select
+__device__ __forceinline__ float4 mask4(const float4 v, bool ok) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+
 // blockIdx -> tile id such that each XCD (blocks are dealt round-robin over the 8 XCDs)
 // owns one contiguous run of tile ids: the N-tiles that share an A row-panel then hit the
 // same L2.  Bijective for any nblk.  Speed only; correctness never depends on it.
@@ -76,31 +81,45 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
   const int nsteps = t.ntaps * kper;
   const size_t wslab = (size_t)t.N * t.K;
 
-  float4 ra[2], rb[2];
+  // Two register sets (plain structs of scalars so they stay in VGPRs): slice s+1 waits in one while
+  // slice s+2 is being fetched into the other, so a global load has ~1.75 K-steps (~1800 MFMA cycles)
+  // to land — with one workgroup per CU (batch 512) nothing else hides the L2 / Infinity-Cache round trip.
+  // Loads are UNCONDITIONAL (a padded / out-of-range row reads a harmless valid address and is zeroed
+  // when written to LDS): branch-free loads let the compiler wait with counted vmcnt(N), so the older
+  // set can be consumed while the younger one is still in flight.
+  struct Pref { float4 a0, a1, b0, b1; unsigned ok; };
   // (tap, k-slice) of the NEXT slice to fetch, advanced incrementally: no division and no scalar
   // kernarg load inside the K loop except at tap boundaries (scalar loads share lgkmcnt with LDS ops)
   int n_tap = 0, n_c0 = 0;
   int cur_to = t.tap_o[0];
   const float* cur_wp = p.W + (size_t)t.tap_w[0] * wslab;
-  auto load_regs = [&]() {
-    const int c0 = n_c0;
-    const int to = cur_to;
-    const float* wp = cur_wp;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int pos = rl[j] + to;
-      const bool ok = rvalid[j] && pos >= 0 && pos < t.P && (!t.even || !(pos & 1)) && (c0 + aq < t.K);
-      ra[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) ra[j] = *reinterpret_cast<const float4*>(p.A + (size_t)(rbase[j] + (pos >> t.sh)) * t.K + c0 + aq);
-      rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!W_KN) {
-        const int n = n0 + ar + 32 * j;
-        if (n < t.N && c0 + aq < t.K) rb[j] = *reinterpret_cast<const float4*>(wp + (size_t)n * t.K + c0 + aq);
-      } else {
-        const int k = c0 + kr + 16 * j, n = n0 + nq;
-        if (k < t.K && n < t.N) rb[j] = *reinterpret_cast<const float4*>(wp + (size_t)k * t.N + n);
-      }
+  auto a_ptr = [&](int j, int c0, int to, bool& ok) -> const float* {
+    const int pos = rl[j] + to;
+    ok = rvalid[j] && pos >= 0 && pos < t.P && (!t.even || !(pos & 1)) && (c0 + aq < t.K);
+    return ok ? p.A + (size_t)(rbase[j] + (pos >> t.sh)) * t.K + c0 + aq : p.A;
+  };
+  auto b_ptr = [&](int j, int c0, const float* wp, bool& ok) -> const float* {
+    if (!W_KN) {
+      const int n = n0 + ar + 32 * j;
+      ok = n < t.N && c0 + aq < t.K;
+      return ok ? wp + (size_t)n * t.K + c0 + aq : p.W;
     }
+    const int k = c0 + kr + 16 * j, n = n0 + nq;
+    ok = k < t.K && n < t.N;
+    return ok ? wp + (size_t)k * t.N + n : p.W;
+  };
+  auto fetch = [&]() -> Pref {
+    Pref r;
+    bool o0, o1, o2, o3;
+    const float* pa0 = a_ptr(0, n_c0, cur_to, o0);
+    const float* pa1 = a_ptr(1, n_c0, cur_to, o1);
+    const float* pb0 = b_ptr(0, n_c0, cur_wp, o2);
+    const float* pb1 = b_ptr(1, n_c0, cur_wp, o3);
+    r.a0 = *reinterpret_cast<const float4*>(pa0);
+    r.a1 = *reinterpret_cast<const float4*>(pa1);
+    r.b0 = *reinterpret_cast<const float4*>(pb0);
+    r.b1 = *reinterpret_cast<const float4*>(pb1);
+    r.ok = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u);
     n_c0 += 32;
     if (n_c0 >= t.K) {
       n_c0 = 0;
@@ -110,15 +129,20 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
         cur_wp = p.W + (size_t)t.tap_w[n_tap] * wslab;
       }
     }
+    return r;
   };
-  auto store_lds = [&](int buf) {
+  auto stash = [&](int buf, const Pref r) {
     float* As = smem + buf * TILE;
     float* Bs = smem + 2 * TILE + buf * TILE;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      *reinterpret_cast<float4*>(As + (ar + 32 * j) * LDA + aq) = ra[j];
-      if (!W_KN) *reinterpret_cast<float4*>(Bs + (ar + 32 * j) * LDA + aq) = rb[j];
-      else       *reinterpret_cast<float4*>(Bs + (kr + 16 * j) * LDBK + nq) = rb[j];
+    *reinterpret_cast<float4*>(As + ar * LDA + aq) = mask4(r.a0, r.ok & 1u);
+    *reinterpret_cast<float4*>(As + (ar + 32) * LDA + aq) = mask4(r.a1, r.ok & 2u);
+    const float4 v0 = mask4(r.b0, r.ok & 4u), v1 = mask4(r.b1, r.ok & 8u);
+    if (!W_KN) {
+      *reinterpret_cast<float4*>(Bs + ar * LDA + aq) = v0;
+      *reinterpret_cast<float4*>(Bs + (ar + 32) * LDA + aq) = v1;
+    } else {
+      *reinterpret_cast<float4*>(Bs + kr * LDBK + nq) = v0;
+      *reinterpret_cast<float4*>(Bs + (kr + 16) * LDBK + nq) = v1;
     }
   };
 
@@ -130,41 +154,60 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
 
-  load_regs();
-  store_lds(0);
-  __syncthreads();
-  for (int s = 0; s < nsteps; ++s) {
-    const int buf = s & 1;
-    const float* As = smem + buf * TILE + (wm * 32 + li) * LDA + lh * 4;
-    const float* Bs = smem + 2 * TILE + buf * TILE;
-    // (1) all LDS fragment reads of this slice go out first, into distinct registers, so that their
-    //     latency overlaps the address arithmetic below and the first MFMAs.
-    //     lane (i,h) takes k = 8kk+4h .. +3 of its row; MFMA jj pairs element jj of both operands,
-    //     i.e. a K permutation applied identically to A and B.
-    float4 a4[4], b4[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      a4[kk] = *reinterpret_cast<const float4*>(As + kk * 8);
-      if (!W_KN) {
-        b4[kk] = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDA + kk * 8 + lh * 4);
-      } else {
-        const float* bk = Bs + (kk * 8 + lh * 4) * LDBK + wn * 32 + li;
-        b4[kk] = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);
-      }
-    }
-    // (2) global loads of the next slice are in flight under the whole MFMA block
-    if (s + 1 < nsteps) load_regs();
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      // (3) the LDS stores of the next slice (other buffer) sit before the last MFMA group
-      if (kk == 3 && s + 1 < nsteps) store_lds(buf ^ 1);
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].x, b4[kk].x, acc4[kk], 0, 0, 0);
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].y, b4[kk].y, acc4[kk], 0, 0, 0);
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].z, b4[kk].z, acc4[kk], 0, 0, 0);
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].w, b4[kk].w, acc4[kk], 0, 0, 0);
-    }
-    __syncthreads();
+  // One K-step.  LDS[BUF] holds the current slice; ST holds the next one (stored to the other buffer
+  // before the last MFMA group); LD receives the slice after that.  (1) all LDS fragment reads first, into
+  // distinct registers: lane (i,h) takes k = 8kk+4h..+3 of its row and MFMA jj pairs element jj of both
+  // operands — a K permutation applied identically to A and B; (2) the global loads; (3) MFMAs with the
+  // LDS stores slotted in.  FETCH / STASH are compile-time: the steady-state loop has no conditions, so
+  // the compiler's vmcnt bookkeeping stays exact (a merged "maybe pending" path costs a full drain).
+#define HP_KSTEP(BUF, ST, LD, FETCH, STASH)                                                             \
+  {                                                                                                     \
+    const float* As = smem + (BUF) * TILE + (wm * 32 + li) * LDA + lh * 4;                              \
+    const float* Bs = smem + 2 * TILE + (BUF) * TILE;                                                   \
+    float4 a4[4], b4[4];                                                                                \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+      a4[kk] = *reinterpret_cast<const float4*>(As + kk * 8);                                           \
+      if (!W_KN) {                                                                                      \
+        b4[kk] = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDA + kk * 8 + lh * 4);        \
+      } else {                                                                                          \
+        const float* bk = Bs + (kk * 8 + lh * 4) * LDBK + wn * 32 + li;                                 \
+        b4[kk] = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);                              \
+      }                                                                                                 \
+    }                                                                                                   \
+    if (FETCH) LD = fetch();                                                                            \
+    __builtin_amdgcn_sched_barrier(0); /* keep the loads ABOVE the MFMA block and the older set's waits */ \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+      if (kk == 3 && (STASH)) stash((BUF) ^ 1, ST);                                                     \
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].x, b4[kk].x, acc4[kk], 0, 0, 0);           \
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].y, b4[kk].y, acc4[kk], 0, 0, 0);           \
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].z, b4[kk].z, acc4[kk], 0, 0, 0);           \
+      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].w, b4[kk].w, acc4[kk], 0, 0, 0);           \
+    }                                                                                                   \
+    __syncthreads();                                                                                    \
   }
+
+  Pref setA = fetch();                       // slice 0
+  stash(0, setA);
+  if (nsteps > 1) setA = fetch();            // slice 1 waits in set A
+  Pref setB = setA;
+  __syncthreads();
+  int s = 0;
+  for (; s + 3 < nsteps; s += 2) {           // steady state: both steps fetch and stash
+    HP_KSTEP(0, setA, setB, true, true)
+    HP_KSTEP(1, setB, setA, true, true)
+  }
+  const int rem = nsteps - s;                // 1 (only when nsteps == 1), 2 or 3
+  if (rem == 3) {
+    HP_KSTEP(0, setA, setB, true, true)
+    HP_KSTEP(1, setB, setA, false, true)
+    HP_KSTEP(0, setA, setB, false, false)
+  } else if (rem == 2) {
+    HP_KSTEP(0, setA, setB, false, true)
+    HP_KSTEP(1, setB, setA, false, false)
+  } else {
+    HP_KSTEP(0, setA, setB, false, false)
+  }
+#undef HP_KSTEP
 
   f32x16 acc;
 #pragma unroll
