@@ -88,46 +88,51 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
   // when written to LDS): branch-free loads let the compiler wait with counted vmcnt(N), so the older
   // set can be consumed while the younger one is still in flight.
   struct Pref { float4 a0, a1, b0, b1; unsigned ok; };
-  // (tap, k-slice) of the NEXT slice to fetch, advanced incrementally: no division and no scalar
-  // kernarg load inside the K loop except at tap boundaries (scalar loads share lgkmcnt with LDS ops)
-  int n_tap = 0, n_c0 = 0;
-  int cur_to = t.tap_o[0];
-  const float* cur_wp = p.W + (size_t)t.tap_w[0] * wslab;
-  auto a_ptr = [&](int j, int c0, int to, bool& ok) -> const float* {
-    const int pos = rl[j] + to;
-    ok = rvalid[j] && pos >= 0 && pos < t.P && (!t.even || !(pos & 1)) && (c0 + aq < t.K);
-    return ok ? p.A + (size_t)(rbase[j] + (pos >> t.sh)) * t.K + c0 + aq : p.A;
-  };
-  auto b_ptr = [&](int j, int c0, const float* wp, bool& ok) -> const float* {
+  // Per-tap load state: four pointers advanced by a constant per K-slice (K is a multiple of 32 here),
+  // recomputed only at tap boundaries — a slice costs four loads and four pointer adds, no index
+  // arithmetic, no division, no scalar kernarg load (those share lgkmcnt with the LDS traffic).
+  const float* pa0; const float* pa1; const float* pb0; const float* pb1;
+  int ia0, ia1, ib0, ib1;
+  unsigned okmask = 0;
+  int n_tap = 0, kc = 0;
+  auto set_tap = [&](int tap) {
+    const int to = t.tap_o[tap];
+    const float* wp = p.W + (size_t)t.tap_w[tap] * wslab;
+    const int pos0 = rl[0] + to, pos1 = rl[1] + to;
+    const bool o0 = rvalid[0] && pos0 >= 0 && pos0 < t.P && (!t.even || !(pos0 & 1));
+    const bool o1 = rvalid[1] && pos1 >= 0 && pos1 < t.P && (!t.even || !(pos1 & 1));
+    pa0 = o0 ? p.A + (size_t)(rbase[0] + (pos0 >> t.sh)) * t.K + aq : p.A;
+    pa1 = o1 ? p.A + (size_t)(rbase[1] + (pos1 >> t.sh)) * t.K + aq : p.A;
+    ia0 = o0 ? 32 : 0;
+    ia1 = o1 ? 32 : 0;
+    bool o2, o3;
     if (!W_KN) {
-      const int n = n0 + ar + 32 * j;
-      ok = n < t.N && c0 + aq < t.K;
-      return ok ? wp + (size_t)n * t.K + c0 + aq : p.W;
+      o2 = n0 + ar < t.N;
+      o3 = n0 + ar + 32 < t.N;
+      pb0 = o2 ? wp + (size_t)(n0 + ar) * t.K + aq : p.W;
+      pb1 = o3 ? wp + (size_t)(n0 + ar + 32) * t.K + aq : p.W;
+      ib0 = o2 ? 32 : 0;
+      ib1 = o3 ? 32 : 0;
+    } else {
+      o2 = o3 = n0 + nq < t.N;
+      pb0 = o2 ? wp + (size_t)kr * t.N + n0 + nq : p.W;
+      pb1 = o3 ? wp + (size_t)(kr + 16) * t.N + n0 + nq : p.W;
+      ib0 = ib1 = o2 ? 32 * t.N : 0;
     }
-    const int k = c0 + kr + 16 * j, n = n0 + nq;
-    ok = k < t.K && n < t.N;
-    return ok ? wp + (size_t)k * t.N + n : p.W;
+    okmask = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u);
   };
+  set_tap(0);
   auto fetch = [&]() -> Pref {
     Pref r;
-    bool o0, o1, o2, o3;
-    const float* pa0 = a_ptr(0, n_c0, cur_to, o0);
-    const float* pa1 = a_ptr(1, n_c0, cur_to, o1);
-    const float* pb0 = b_ptr(0, n_c0, cur_wp, o2);
-    const float* pb1 = b_ptr(1, n_c0, cur_wp, o3);
     r.a0 = *reinterpret_cast<const float4*>(pa0);
     r.a1 = *reinterpret_cast<const float4*>(pa1);
     r.b0 = *reinterpret_cast<const float4*>(pb0);
     r.b1 = *reinterpret_cast<const float4*>(pb1);
-    r.ok = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u);
-    n_c0 += 32;
-    if (n_c0 >= t.K) {
-      n_c0 = 0;
-      ++n_tap;
-      if (n_tap < t.ntaps) {
-        cur_to = t.tap_o[n_tap];
-        cur_wp = p.W + (size_t)t.tap_w[n_tap] * wslab;
-      }
+    r.ok = okmask;
+    pa0 += ia0; pa1 += ia1; pb0 += ib0; pb1 += ib1;
+    if (++kc == kper) {
+      kc = 0;
+      if (++n_tap < t.ntaps) set_tap(n_tap);
     }
     return r;
   };

@@ -59,6 +59,7 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
     const int M = op.i[0], N = op.i[1], K = op.i[2], nt = op.i[9];
     bool ok = M > 0 && N > 0 && K > 0 && (K % 4) == 0 && (N % 4) == 0 && op.i[3] > 0 && op.i[4] > 0 && nt >= 1 &&
               nt <= HP_MAX_TAPS && op.i[6] >= 1 && op.i[7] >= 0 && op.i[7] <= 1;
+    if (op.op == HP_OP_CONV_TAPS) ok = ok && (K % 32) == 0;
     if (op.op == HP_OP_WGRAD_TAPS)
       ok = ok && (nt == 1 || nt == 3) && op.i[22] >= 1 && op.i[23] > 0 && (op.i[23] % 32) == 0 &&
            (int64_t)op.i[22] * op.i[23] >= M;

@@ -77,7 +77,8 @@ enum {
    * the row mapping, and their input-gradients (ATen convolution_backward) with
    * transposed weights.  flags: 1 = weight slab is [K][N] (else [N][K]); 2 = bias;
    * 4 = accumulate per-column sum / sum of squares (fp64 atomics) into buf[4] for the
-   * following BatchNorm.   buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[2][N]) */
+   * following BatchNorm.  Requires K % 32 == 0 and N % 4 == 0 (every conv of the backbones: 64..512).
+   * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[HP_STAT_REPL][2][N]) */
   HP_OP_CONV_TAPS = 1,
   /* slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]; f32 MFMA.
    * Replaces the weight-gradient half of ATen convolution_backward.

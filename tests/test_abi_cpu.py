@@ -64,7 +64,7 @@ def test_planner_programs_validate_without_gpu(kind):
     assert rc != 0 and "unknown opcode" in msg
     bad = ops.copy()
     k = [i for i, r in enumerate(bad) if int(r["op"]) == P.CONV_TAPS][0]
-    bad[k]["i"][2] = 30          # K not a multiple of 4
+    bad[k]["i"][2] = 30          # K not a multiple of 32
     rc, msg = _create(bad, sizes)
     assert rc != 0 and "tap-map" in msg
     segs = plan.ops.segments
