@@ -13,6 +13,8 @@ struct HpProgram {
   std::vector<hipGraphExec_t> segs;
   std::vector<hipGraph_t> graphs;
   hipStream_t capture_stream = nullptr;
+  hipStream_t side_streams[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> events;
 };
 
 namespace {
@@ -115,6 +117,8 @@ int hp_program_destroy(HpProgram* p) {
   if (!p) return 0;
   for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
   for (auto g : p->graphs) if (g) hipGraphDestroy(g);
+  for (auto e : p->events) if (e) hipEventDestroy(e);
+  for (auto s : p->side_streams) if (s) hipStreamDestroy(s);
   if (p->capture_stream) hipStreamDestroy(p->capture_stream);
   delete p;
   return 0;
@@ -151,9 +155,44 @@ int hp_program_capture(HpProgram* p, int first, int count, int* seg) {
     e = hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail_hip("hipStreamCreate", e);
   }
+  for (auto& ss : p->side_streams)
+    if (!ss) {
+      e = hipStreamCreateWithFlags(&ss, hipStreamNonBlocking);
+      if (e != hipSuccess) return fail_hip("hipStreamCreate", e);
+    }
+  auto new_event = [&]() -> hipEvent_t {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
+    p->events.push_back(ev);
+    return ev;
+  };
   e = hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return fail_hip("hipStreamBeginCapture", e);
-  int rc = hp_program_run(p, first, count, p->capture_stream);
+  // fork/join: ops flagged HP_FLAG_SIDE go to side branches that depend on everything captured so far
+  int rc = 0, nside = 0;
+  bool used[2] = {false, false};
+  for (int k = first; k < first + count && rc == 0; ++k) {
+    const HpOp& op = p->ops[k];
+    hipStream_t s = p->capture_stream;
+    if (op.flags & HP_FLAG_SIDE) {
+      const int w = nside++ & 1;
+      hipEvent_t ev = new_event();
+      if (!ev || hipEventRecord(ev, p->capture_stream) != hipSuccess || hipStreamWaitEvent(p->side_streams[w], ev, 0) != hipSuccess) {
+        rc = fail("hp_program_capture: fork failed");
+        break;
+      }
+      used[w] = true;
+      s = p->side_streams[w];
+    }
+    hipError_t le = dispatch(op, p->bases, s);
+    if (le != hipSuccess) rc = fail_hip("capture launch", le);
+  }
+  for (int w = 0; w < 2; ++w)
+    if (used[w]) {
+      hipEvent_t ev = new_event();
+      if (!ev || hipEventRecord(ev, p->side_streams[w]) != hipSuccess || hipStreamWaitEvent(p->capture_stream, ev, 0) != hipSuccess)
+        rc = fail("hp_program_capture: join failed");
+    }
   hipGraph_t graph = nullptr;
   e = hipStreamEndCapture(p->capture_stream, &graph);
   if (rc != 0) { if (graph) hipGraphDestroy(graph); return 1; }

@@ -252,7 +252,7 @@ class Lowering:
         rps = _round_up(-(-tm.M // nsplit), 32)
         nsplit = -(-tm.M // rps)
         if not self.train.deterministic_wgrad:
-            self.o.add(P.WGRAD_TAPS, 1, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
+            self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_SIDE, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
             return
         self.pl.slab_need = max(self.pl.slab_need, nsplit * w.numel)
         self.o.add(P.WGRAD_TAPS, 0, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, self.slab], note=note)
@@ -299,7 +299,7 @@ class Lowering:
         self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
 
     def linear_bwd(self, M, lin, dy, ldy, x, ldx, dx=None, lddx=None, mask=None, ldmask=0, accumulate=False, note=""):
-        self.o.add(P.LINEAR_BWD_W, 0, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
+        self.o.add(P.LINEAR_BWD_W, P.FLAG_SIDE, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
         if dx is not None:
             self.o.add(P.LINEAR_BWD_X, 0, i=[M, lin["N"], lin["K"], ldy, lddx, 1 if mask is not None else 0, ldmask, 1 if accumulate else 0],
                        f=[SLOPE_HEADS], buf=[dy, lin["w"].ref, dx, mask], note=note + " dX")
@@ -402,7 +402,7 @@ class Lowering:
                 G1, G2 = dxa, dxs
         M = B * e["L1"]
         _, dr0, _ = self.bn_bwd(M, e["bn1"], G1, G2, e["a0"], e["raw0"], SLOPE_BACKBONE)
-        self.o.add(P.STEM_WGRAD, 0, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
+        self.o.add(P.STEM_WGRAD, P.FLAG_SIDE, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
 
     # ---- decoder ------------------------------------------------------------------
     def decoder_fwd(self, d, din, training):
@@ -461,7 +461,7 @@ class Lowering:
         pl, B, z = self.pl, self.B, self.cfg.z_dim
         dt = pl.f32(B * 64)
         self.linear_bwd(B, d["lo"], drec, d["output_size"], d["t"], 64, dt, 64, note=d["prefix"] + "linear_out")
-        self.o.add(P.TAIL_BWD_W, 0, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
+        self.o.add(P.TAIL_BWD_W, P.FLAG_SIDE, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
         G1 = pl.f32(B * 32 * 64)
         self.o.add(P.TAIL_BWD_X, 0, i=[B, 32, 64], buf=[dt, d["tail_w"].ref, G1], note=d["prefix"] + "tail dX")
         G2 = None
