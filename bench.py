@@ -138,10 +138,14 @@ def conv_roofline(pair, data, idx, reps=3, detail=None):
                     tot_flop += 2.0 * M * N * K * nt
                     tot_ms += acc[j]
                     launches += 1
-                if detail is not None and int(r["op"]) in (P.CONV_TAPS, P.WGRAD_TAPS):
+                if detail is not None and int(r["op"]) in (P.CONV_TAPS, P.WGRAD_TAPS) and not (int(r["flags"]) & P.FLAG_MEMBER):
                     M, N, K, nt = int(r["i"][0]), int(r["i"][1]), int(r["i"][2]), int(r["i"][9])
                     fl = 2.0 * M * N * K * nt
                     detail.append((name, e.plan.ops.notes[first + j], M, N, K, nt, int(r["flags"]), acc[j] * 1e3, fl / (acc[j] * 1e-3) / 1e12))
+                if detail is not None and int(r["op"]) == P.WGRAD_GROUP:
+                    mem = e.ops[int(r["i"][0]): int(r["i"][0]) + int(r["i"][1])]
+                    fl = sum(2.0 * int(m["i"][0]) * int(m["i"][1]) * int(m["i"][2]) * int(m["i"][9]) for m in mem)
+                    detail.append((name, e.plan.ops.notes[first + j], len(mem), 0, 0, int(r["i"][2]), 0, acc[j] * 1e3, fl / (acc[j] * 1e-3) / 1e12))
     return tot_ms, tot_flop, launches, per_kernel
 
 

@@ -9,6 +9,8 @@
 // [B*L][C], so a GEMM row is one contiguous channel vector.
 #include "hp_common.h"
 
+#include <vector>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct TapMap {
@@ -271,15 +273,13 @@ struct WgradArgs {
 };
 
 template <int NT>
-__global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, const int split, float* smem) {
   constexpr int T = 32 * 64;   // one [32 rows][64 cols] image
-  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * T];
   const TapMap& t = p.t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
   const int ntc = (t.K + 63) >> 6;
-  const int n0 = (blockIdx.x / ntc) << 6, c0 = (blockIdx.x % ntc) << 6;
-  const int split = blockIdx.y;
+  const int n0 = (tile / ntc) << 6, c0 = (tile % ntc) << 6;
   const int mbeg = split * p.rows_per_split;
   const int mend = min(t.M, mbeg + p.rows_per_split);
 
@@ -380,7 +380,26 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
   }
 }
 
-hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t s) {
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64];
+  wgrad_body<NT>(p, blockIdx.x, blockIdx.y, smem);
+}
+
+// Grouped form: ONE launch runs every weight-gradient GEMM of a backward pass.  They are independent
+// leaves whose inputs persist, so their tiles fill the chip together (no per-layer tail, fewer K-splits
+// and atomics, one launch instead of ~38).  blocks[b] = (problem, tile, split, -).
+template <int NT>
+__global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __restrict__ probs, const int4* __restrict__ blocks) {
+  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64];
+  const int4 bi = blocks[blockIdx.x];
+  const int pj = __builtin_amdgcn_readfirstlane(bi.x);
+  const int tile = __builtin_amdgcn_readfirstlane(bi.y);
+  const int split = __builtin_amdgcn_readfirstlane(bi.z);
+  wgrad_body<NT>(probs[pj], tile, split, smem);
+}
+
+static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {
   WgradArgs a;
   a.t = tapmap_from(op);
   a.DY = hp::ptr<const float>(op, 0, bases);
@@ -390,6 +409,41 @@ hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t
   a.rows_per_split = op.i[23];
   a.slab_stride = op.i[24];
   a.atomic = op.flags & 1;
+  return a;
+}
+
+// Build the device tables of one WGRAD_GROUP op from its member records ops[first .. first+count).
+hipError_t hp::build_wgrad_group(const HpOp* members, int count, void* const* bases, void** d_probs, void** d_blocks, int* nblocks) {
+  std::vector<WgradArgs> probs(count);
+  std::vector<int4> blocks;
+  for (int j = 0; j < count; ++j) {
+    probs[j] = wgrad_args_from(members[j], bases);
+    const int tiles = hp::cdiv(probs[j].t.N, 64) * hp::cdiv(probs[j].t.K, 64);
+    for (int sp = 0; sp < probs[j].nsplit; ++sp)
+      for (int tl = 0; tl < tiles; ++tl) blocks.push_back(make_int4(j, tl, sp, 0));
+  }
+  hipError_t e = hipMalloc(d_probs, probs.size() * sizeof(WgradArgs));
+  if (e != hipSuccess) return e;
+  e = hipMalloc(d_blocks, blocks.size() * sizeof(int4));
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(*d_probs, probs.data(), probs.size() * sizeof(WgradArgs), hipMemcpyHostToDevice);
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(*d_blocks, blocks.data(), blocks.size() * sizeof(int4), hipMemcpyHostToDevice);
+  *nblocks = (int)blocks.size();
+  return e;
+}
+
+hipError_t hp::launch_wgrad_group(int ntaps, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s) {
+  if (ntaps == 1)
+    hipLaunchKernelGGL(wgrad_group_kernel<1>, dim3(nblocks), dim3(256), 0, s, (const WgradArgs*)d_probs, (const int4*)d_blocks);
+  else if (ntaps == 3)
+    hipLaunchKernelGGL(wgrad_group_kernel<3>, dim3(nblocks), dim3(256), 0, s, (const WgradArgs*)d_probs, (const int4*)d_blocks);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t s) {
+  WgradArgs a = wgrad_args_from(op, bases);
   dim3 grid(hp::cdiv(a.t.N, 64) * hp::cdiv(a.t.K, 64), a.nsplit);
   if (a.t.ntaps == 1)      hipLaunchKernelGGL(wgrad_taps_kernel<1>, grid, dim3(256), 0, s, a);
   else if (a.t.ntaps == 3) hipLaunchKernelGGL(wgrad_taps_kernel<3>, grid, dim3(256), 0, s, a);

@@ -15,6 +15,9 @@ struct HpProgram {
   hipStream_t capture_stream = nullptr;
   hipStream_t side_streams[2] = {nullptr, nullptr};
   std::vector<hipEvent_t> events;
+  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; };
+  std::vector<Group> groups;          // indexed by op index (empty entries for non-group ops)
+  bool groups_ready = false;
 };
 
 namespace {
@@ -29,12 +32,38 @@ int fail_hip(const char* what, hipError_t e) {
   return 1;
 }
 
+// device tables of every WGRAD_GROUP op (lazily: program creation / validation must work without a GPU)
+int ensure_groups(HpProgram* p) {
+  if (p->groups_ready) return 0;
+  p->groups.assign(p->ops.size(), HpProgram::Group());
+  for (size_t k = 0; k < p->ops.size(); ++k) {
+    const HpOp& op = p->ops[k];
+    if (op.op != HP_OP_WGRAD_GROUP) continue;
+    HpProgram::Group& g = p->groups[k];
+    g.ntaps = op.i[2];
+    hipError_t e = hp::build_wgrad_group(&p->ops[op.i[0]], op.i[1], p->bases, &g.probs, &g.blocks, &g.nblocks);
+    if (e != hipSuccess) return fail_hip("building wgrad group tables", e);
+  }
+  p->groups_ready = true;
+  return 0;
+}
+
 hipError_t dispatch(const HpOp& op, void* const* bases, hipStream_t s) {
   switch (op.op) {
     case HP_OP_CONV_TAPS: return hp::launch_conv_taps(op, bases, s);
     case HP_OP_WGRAD_TAPS: return hp::launch_wgrad_taps(op, bases, s);
     default: return hp::launch_small(op, bases, s);
   }
+}
+
+hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
+  const HpOp& op = p->ops[k];
+  if (op.flags & HP_FLAG_MEMBER) return hipSuccess;            // done by its group launch
+  if (op.op == HP_OP_WGRAD_GROUP) {
+    const HpProgram::Group& g = p->groups[k];
+    return hp::launch_wgrad_group(g.ntaps, g.probs, g.blocks, g.nblocks, s);
+  }
+  return dispatch(op, p->bases, s);
 }
 
 // number of buffer slots each op may reference (for validation)
@@ -70,6 +99,11 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
       why = buf;
       return 1;
     }
+  }
+  if (op.op == HP_OP_WGRAD_GROUP && (op.i[0] < 0 || op.i[1] <= 0 || op.i[0] + op.i[1] > index || (op.i[2] != 1 && op.i[2] != 3))) {
+    snprintf(buf, sizeof buf, "op %d: bad wgrad group range [%d, +%d) taps %d", index, op.i[0], op.i[1], op.i[2]);
+    why = buf;
+    return 1;
   }
   if ((op.op == HP_OP_BN_APPLY || op.op == HP_OP_BN_BWD_REDUCE || op.op == HP_OP_BN_BWD_APPLY) &&
       (op.i[0] <= 0 || op.i[1] <= 0)) {
@@ -118,6 +152,7 @@ int hp_program_destroy(HpProgram* p) {
   for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
   for (auto g : p->graphs) if (g) hipGraphDestroy(g);
   for (auto e : p->events) if (e) hipEventDestroy(e);
+  for (auto& g : p->groups) { if (g.probs) hipFree(g.probs); if (g.blocks) hipFree(g.blocks); }
   for (auto s : p->side_streams) if (s) hipStreamDestroy(s);
   if (p->capture_stream) hipStreamDestroy(p->capture_stream);
   delete p;
@@ -127,8 +162,17 @@ int hp_program_destroy(HpProgram* p) {
 int hp_program_validate(const HpProgram* p) {
   if (!p) return fail("hp_program_validate: null program");
   std::string why;
-  for (size_t k = 0; k < p->ops.size(); ++k)
+  for (size_t k = 0; k < p->ops.size(); ++k) {
     if (validate_op(p->ops[k], p->sizes, (int)k, why)) return fail(why);
+    if (p->ops[k].op == HP_OP_WGRAD_GROUP) {
+      const HpOp& g = p->ops[k];
+      for (int j = g.i[0]; j < g.i[0] + g.i[1]; ++j) {
+        const HpOp& m = p->ops[j];
+        if (m.op != HP_OP_WGRAD_TAPS || !(m.flags & HP_FLAG_MEMBER) || !(m.flags & 1) || m.i[9] != g.i[2])
+          return fail("wgrad group member " + std::to_string(j) + " is not an atomic WGRAD_TAPS member with matching taps");
+      }
+    }
+  }
   return 0;
 }
 
@@ -136,8 +180,9 @@ int hp_program_run(HpProgram* p, int first, int count, void* stream) {
   if (!p) return fail("hp_program_run: null program");
   if (first < 0 || count < 0 || first + count > (int)p->ops.size()) return fail("hp_program_run: range out of bounds");
   hipStream_t s = (hipStream_t)stream;
+  if (ensure_groups(p)) return 1;
   for (int k = first; k < first + count; ++k) {
-    hipError_t e = dispatch(p->ops[k], p->bases, s);
+    hipError_t e = run_one(p, k, s);
     if (e != hipSuccess) {
       char buf[96];
       snprintf(buf, sizeof buf, "launch of op %d (opcode %d)", k, p->ops[k].op);
@@ -166,6 +211,7 @@ int hp_program_capture(HpProgram* p, int first, int count, int* seg) {
     p->events.push_back(ev);
     return ev;
   };
+  if (ensure_groups(p)) return 1;
   e = hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return fail_hip("hipStreamBeginCapture", e);
   // fork/join: ops flagged HP_FLAG_SIDE go to side branches that depend on everything captured so far
@@ -184,7 +230,7 @@ int hp_program_capture(HpProgram* p, int first, int count, int* seg) {
       used[w] = true;
       s = p->side_streams[w];
     }
-    hipError_t le = dispatch(op, p->bases, s);
+    hipError_t le = run_one(p, k, s);
     if (le != hipSuccess) rc = fail_hip("capture launch", le);
   }
   for (int w = 0; w < 2; ++w)
@@ -219,9 +265,10 @@ int hp_program_profile(HpProgram* p, int first, int count, void* stream, float* 
   hipStream_t s = (hipStream_t)stream;
   std::vector<hipEvent_t> ev(count + 1);
   for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return fail("hipEventCreate failed");
+  if (ensure_groups(p)) return 1;
   hipEventRecord(ev[0], s);
   for (int k = 0; k < count; ++k) {
-    hipError_t e = dispatch(p->ops[first + k], p->bases, s);
+    hipError_t e = run_one(p, first + k, s);
     if (e != hipSuccess) return fail_hip("profile launch", e);
     hipEventRecord(ev[k + 1], s);
   }

@@ -52,6 +52,7 @@ class TrainCfg:
     beta2: float = 0.999
     adam_eps: float = 1e-8
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
+    grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
 
 
 @dataclass
@@ -165,6 +166,7 @@ class Lowering:
         self.target_blocks = wgrad_target_blocks
         self.pl = Plan(cfg, batch, self.train, with_class)
         self.o = self.pl.ops
+        self.pending_wgrads = []
 
     # ---- parameter declaration (own order; class_embedding last so that AdamW can skip it) ----
     def declare_encoder(self, pre):
@@ -246,13 +248,21 @@ class Lowering:
 
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note=""):
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
+        if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
+            # deferred: all wgrads of the backward pass run in one grouped launch at its end.  With the
+            # whole chip shared, ~64 workgroups per problem suffice: big-weight layers are not split at all.
+            nsplit = max(1, min(64 // tiles, -(-tm.M // 256)))
+            rps = _round_up(-(-tm.M // nsplit), 32)
+            nsplit = -(-tm.M // rps)
+            self.pending_wgrads.append((tm, nsplit, rps, dy, x, w, note))
+            return
         # enough workgroups to fill 256 CUs, but at least 256 rows (8 K-slices) per split so that the
         # tile's atomics / slab traffic stays small next to its MFMA work
         nsplit = max(1, min(self.target_blocks // tiles, -(-tm.M // 256)))
         rps = _round_up(-(-tm.M // nsplit), 32)
         nsplit = -(-tm.M // rps)
         if not self.train.deterministic_wgrad:
-            self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_SIDE, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
+            self.o.add(P.WGRAD_TAPS, 1, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
             return
         self.pl.slab_need = max(self.pl.slab_need, nsplit * w.numel)
         self.o.add(P.WGRAD_TAPS, 0, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, self.slab], note=note)
@@ -299,7 +309,7 @@ class Lowering:
         self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
 
     def linear_bwd(self, M, lin, dy, ldy, x, ldx, dx=None, lddx=None, mask=None, ldmask=0, accumulate=False, note=""):
-        self.o.add(P.LINEAR_BWD_W, P.FLAG_SIDE, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
+        self.o.add(P.LINEAR_BWD_W, 0, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
         if dx is not None:
             self.o.add(P.LINEAR_BWD_X, 0, i=[M, lin["N"], lin["K"], ldy, lddx, 1 if mask is not None else 0, ldmask, 1 if accumulate else 0],
                        f=[SLOPE_HEADS], buf=[dy, lin["w"].ref, dx, mask], note=note + " dX")
@@ -402,7 +412,7 @@ class Lowering:
                 G1, G2 = dxa, dxs
         M = B * e["L1"]
         _, dr0, _ = self.bn_bwd(M, e["bn1"], G1, G2, e["a0"], e["raw0"], SLOPE_BACKBONE)
-        self.o.add(P.STEM_WGRAD, P.FLAG_SIDE, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
+        self.o.add(P.STEM_WGRAD, 0, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
 
     # ---- decoder ------------------------------------------------------------------
     def decoder_fwd(self, d, din, training):
@@ -461,7 +471,7 @@ class Lowering:
         pl, B, z = self.pl, self.B, self.cfg.z_dim
         dt = pl.f32(B * 64)
         self.linear_bwd(B, d["lo"], drec, d["output_size"], d["t"], 64, dt, 64, note=d["prefix"] + "linear_out")
-        self.o.add(P.TAIL_BWD_W, P.FLAG_SIDE, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
+        self.o.add(P.TAIL_BWD_W, 0, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
         G1 = pl.f32(B * 32 * 64)
         self.o.add(P.TAIL_BWD_X, 0, i=[B, 32, 64], buf=[dt, d["tail_w"].ref, G1], note=d["prefix"] + "tail dX")
         G2 = None
@@ -668,6 +678,15 @@ class Lowering:
                 dh = dc0 + 4 * (2 * z * k)      # column window of dc0, leading dimension ncat
                 self.linear_bwd(B, lin, dh, ncat, e["pooled"], 512, dpooled, 512, note=e["prefix"] + "linear")
                 self.encoder_bwd(e, dpooled)
+            for ntaps in (3, 1):
+                mem = [w_ for w_ in self.pending_wgrads if len(w_[0].taps) == ntaps]
+                if not mem:
+                    continue
+                first = len(self.o.recs)
+                for (tm, nsplit, rps, dy, x, w, note) in mem:
+                    self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
+                self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
+            self.pending_wgrads = []
             self.o.end()
 
             # ---------------- optimiser ----------------

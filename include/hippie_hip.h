@@ -59,6 +59,9 @@ enum {
  * op, join at the end of the segment) so they overlap the main dependency chain; hp_program_run
  * executes them in order. */
 #define HP_FLAG_SIDE 0x100
+/* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP op: the program executor skips it
+ * (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
+#define HP_FLAG_MEMBER 0x200
 
 /* One op record (POD, 8-byte aligned; numpy dtype mirror in hippie_amd/program.py). */
 typedef struct HpOp {
@@ -184,6 +187,10 @@ enum {
   HP_OP_STEP_INC = 27,
   /* memset(dst, 0, i[0] bytes).  buf: 0 DST */
   HP_OP_ZERO = 28,
+  /* One launch for i[1] HP_OP_WGRAD_TAPS member records (all with i[2] taps, atomic accumulation) that
+   * sit at program indices i[0] .. i[0]+i[1]-1, flagged HP_FLAG_MEMBER.  The library builds the device-side
+   * problem and block tables from the member records on first use.  i[0]=first i[1]=count i[2]=ntaps */
+  HP_OP_WGRAD_GROUP = 29,
   HP_OP__COUNT
 };
 
