@@ -57,16 +57,21 @@ def synth_dataset(n, device, seed=42):
 
 
 class Pair:
-    """wave + time engines, each on its own HIP stream, stepped with hipGraph replay."""
+    """wave + time models.  Default: ONE zipped program (hippie_amd.pair.PairEngine: every heavy op of the
+    two models in one launch) replayed as three hipGraphs on one stream.  --no-pair: two engines, each on
+    its own HIP stream."""
 
-    def __init__(self, device, world, lr=1e-3):
-        self.device, self.world = device, world
-        self.eng = [
-            Engine(planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=50), BATCH,
-                   planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0), device=device),
-            Engine(planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=100), BATCH,
-                   planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0), device=device),
-        ]
+    def __init__(self, device, world, lr=1e-3, paired=True):
+        self.device, self.world, self.paired = device, world, paired
+        cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=50), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=100)]
+        tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0), planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0)]
+        if paired:
+            from hippie_amd.pair import PairEngine
+            self.pe = PairEngine(cfgs[0], cfgs[1], BATCH, tcs[0], tcs[1], device=device)
+            self.eng = self.pe.models
+        else:
+            self.pe = None
+            self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
         self.groups = None
         if world > 1:
@@ -97,6 +102,18 @@ class Pair:
 
     def step(self, data, idx, use_graph=True):
         import torch.distributed as dist
+        if self.paired:
+            src = data[2].index_select(0, idx)
+            for k, e in enumerate(self.eng):
+                e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
+                e.io("src").copy_(src, non_blocking=True)
+                e.io("eps").normal_()
+            self.pe.forward(True, use_graph)
+            self.pe.backward(use_graph)
+            if self.groups is not None:
+                dist.all_reduce(self.pe.grads, op=dist.ReduceOp.AVG, group=self.groups[0])   # both models: one 64 MB buffer
+            self.pe.optimizer_step(use_graph)
+            return
         cur = torch.cuda.current_stream(self.device)
         for k, (e, s) in enumerate(zip(self.eng, self.streams)):
             s.wait_stream(cur)
@@ -117,6 +134,46 @@ def conv_roofline(pair, data, idx, reps=3, detail=None):
     """Per-launch HIP-event timing of every CONV_TAPS op (eager replay of the same programs)."""
     tot_ms, tot_flop, launches = 0.0, 0.0, 0
     per_kernel = {}
+    if pair.paired:
+        pe = pair.pe
+        src = data[2].index_select(0, idx)
+        for k, e in enumerate(pair.eng):
+            e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1))
+            e.io("src").copy_(src)
+            e.io("eps").normal_()
+        for seg in ("fwd_train", "bwd", "opt"):
+            first, count = pe.segments[seg]
+            acc = np.zeros(count)
+            for _ in range(reps):
+                acc += pe.profile(seg)
+            acc /= reps
+            for j in range(count):
+                r = pe.ops[first + j]
+                opc, fl = int(r["op"]), int(r["flags"])
+                if fl & P.FLAG_MEMBER:
+                    continue
+                name = P.OP_NAMES[opc]
+                members = [r]
+                if opc == P.PAIR:
+                    members = [pe.ops[int(r["i"][0])], pe.ops[int(r["i"][1])]]
+                    name = "PAIR:" + P.OP_NAMES[int(members[0]["op"])]
+                elif opc == P.WGRAD_GROUP:
+                    members = list(pe.ops[int(r["i"][0]): int(r["i"][0]) + int(r["i"][1])])
+                d = per_kernel.setdefault(name, [0.0, 0])
+                d[0] += acc[j]
+                d[1] += 1
+                mop = int(members[0]["op"])
+                if mop in (P.CONV_TAPS, P.WGRAD_TAPS):
+                    flop = sum(2.0 * int(m["i"][0]) * int(m["i"][1]) * int(m["i"][2]) * int(m["i"][9]) for m in members)
+                    if mop == P.CONV_TAPS:
+                        tot_flop += flop
+                        tot_ms += acc[j]
+                        launches += 1
+                    if detail is not None:
+                        m0 = members[0]
+                        detail.append((name, pe.notes[first + j], int(m0["i"][0]), int(m0["i"][1]), int(m0["i"][2]), int(m0["i"][9]),
+                                       len(members), acc[j] * 1e3, flop / (acc[j] * 1e-3) / 1e12))
+        return tot_ms, tot_flop, launches, per_kernel
     for k, e in enumerate(pair.eng):
         e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1))
         e.io("src").copy_(data[2].index_select(0, idx))
@@ -180,6 +237,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-pair", action="store_true", help="two engines on two streams instead of one zipped program")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     args = ap.parse_args()
 
@@ -196,7 +254,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     data = synth_dataset(N_UNITS, device)
-    pair = Pair(device, world)
+    pair = Pair(device, world, paired=not args.no_pair)
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -236,7 +294,7 @@ def main():
                 print(f"{name:18s} {cnt:4d} launches {ms:8.3f} ms {100*ms/tot:5.1f} %", file=sys.stderr)
             print(f"{'TOTAL (eager, serial)':18s} {tot:8.3f} ms", file=sys.stderr)
             for d in detail:
-                print("%-11s %-46s M=%6d N=%4d K=%4d taps=%d fl=%d %8.1f us %6.1f TF" % d, file=sys.stderr)
+                print("%-16s %-50s M=%6d N=%4d K=%4d taps=%d n=%d %8.1f us %6.1f TF" % d, file=sys.stderr)
         out = {
             "metric": "pretrain samples/sec (waveform+time cVAE, batch 512)",
             "value": BATCH * world * args.steps / dt,
@@ -248,11 +306,11 @@ def main():
             "config": {"workload": "BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
                                    "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "
                                    "fp32 arithmetic on f32 MFMA (parity path; bf16 not used)",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                         "kernel": "conv_taps_kernel (fwd conv + dgrad, f32 MFMA 32x32x2)",
+                         "kernel": ("conv_taps_pair_kernel" if pair.paired else "conv_taps_kernel") + " (fwd conv + dgrad, f32 MFMA 32x32x2)",
                          "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
                          "algorithmic_gflop_per_step": conv_flop / 1e9},
         }

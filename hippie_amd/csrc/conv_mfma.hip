@@ -51,18 +51,19 @@ struct ConvArgs {
   TapMap t;
 };
 
+constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
+
 template <bool W_KN>
-__global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
+__device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
   constexpr int LDBK = 68;   // [k][n] image row stride
   constexpr int TILE = 64 * LDA;   // 2304 floats; the [32][68] image (2176) fits too
-  __shared__ __attribute__((aligned(16))) float smem[4 * TILE];
 
   const TapMap& t = p.t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
   const int nt = (t.N + 63) >> 6, mt = (t.M + 63) >> 6;
-  const int tile = xcd_remap(blockIdx.x, mt * nt);
+  const int tile = xcd_remap(bid, mt * nt);
   const int m0 = (tile / nt) << 6, n0 = (tile % nt) << 6;
 
   // fixed per-thread load slots: rows ar, ar+32 of the A tile; 16-byte column aq
@@ -239,14 +240,30 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
     s1 += __shfl_xor(s1, 32, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lh == 0 && nok) {
-      double* st = stat_replica(p.stats, t.N, blockIdx.x);
+      double* st = stat_replica(p.stats, t.N, bid);
       atomic_add_f64(st + n, s1);
       atomic_add_f64(st + t.N + n, s2);
     }
   }
 }
 
-hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
+template <bool W_KN>
+__global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[kConvLds];
+  conv_body<W_KN>(p, blockIdx.x, smem);
+}
+
+// HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, or a
+// block's conv1 and its shortcut) in ONE launch: twice the workgroups per launch at batch 512, where a
+// single layer only fills each CU with one workgroup.
+template <bool W_KN>
+__global__ __launch_bounds__(256) void conv_taps_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
+  __shared__ __attribute__((aligned(16))) float smem[kConvLds];
+  if ((int)blockIdx.x < nblk_a) conv_body<W_KN>(a, blockIdx.x, smem);
+  else conv_body<W_KN>(b, blockIdx.x - nblk_a, smem);
+}
+
+static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   ConvArgs a;
   a.t = tapmap_from(op);
   a.A = hp::ptr<const float>(op, 0, bases);
@@ -254,6 +271,20 @@ hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t 
   a.out = hp::ptr<float>(op, 2, bases);
   a.bias = (op.flags & 2) ? hp::ptr<const float>(op, 3, bases) : nullptr;
   a.stats = (op.flags & 4) ? hp::ptr<double>(op, 4, bases) : nullptr;
+  return a;
+}
+
+hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* bases, hipStream_t s) {
+  if ((opa.flags & 1) != (opb.flags & 1)) return hipErrorInvalidValue;
+  const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
+  const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
+  if (opa.flags & 1) hipLaunchKernelGGL(conv_taps_pair_kernel<true>, dim3(na + nb), dim3(256), 0, s, a, b, na);
+  else               hipLaunchKernelGGL(conv_taps_pair_kernel<false>, dim3(na + nb), dim3(256), 0, s, a, b, na);
+  return hipGetLastError();
+}
+
+hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
+  const ConvArgs a = conv_args_from(op, bases);
   const int nblk = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64);
   if (op.flags & 1) hipLaunchKernelGGL(conv_taps_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
   else              hipLaunchKernelGGL(conv_taps_kernel<false>, dim3(nblk), dim3(256), 0, s, a);

@@ -22,6 +22,8 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 hipError_t launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s);
 hipError_t launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t s);
 hipError_t launch_small(const HpOp& op, void* const* bases, hipStream_t s);
+hipError_t launch_conv_pair(const HpOp& a, const HpOp& b, void* const* bases, hipStream_t s);
+hipError_t launch_small_pair(const HpOp& a, const HpOp& b, void* const* bases, hipStream_t s);   // BN family
 hipError_t build_wgrad_group(const HpOp* members, int count, void* const* bases, void** d_probs, void** d_blocks, int* nblocks);
 hipError_t launch_wgrad_group(int ntaps, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s);
 

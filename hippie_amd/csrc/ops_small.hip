@@ -88,18 +88,18 @@ template <> __device__ __forceinline__ float& at<4>(float4& v, int j) { return (
 template <> __device__ __forceinline__ float& at<1>(float& v, int) { return v; }
 
 template <int V>
-__device__ __forceinline__ ColMap colmap_v(int M, int C, int rpl) {
+__device__ __forceinline__ ColMap colmap_v(int M, int C, int rpl, int bx, int by) {
   ColMap m;
   const int cg = C / V;
   m.cw = cg < 256 ? cg : 256;
   m.rl = 256 / m.cw;
   const int tid = threadIdx.x;
   m.rlane = tid / m.cw;
-  m.c = (blockIdx.y * m.cw + (tid - m.rlane * m.cw)) * V;
+  m.c = (by * m.cw + (tid - m.rlane * m.cw)) * V;
   const int rpb = m.rl * rpl;
-  m.row = blockIdx.x * rpb + m.rlane;
+  m.row = bx * rpb + m.rlane;
   m.rstep = m.rl;
-  m.rend = min(M, (int)(blockIdx.x + 1) * rpb);
+  m.rend = min(M, (bx + 1) * rpb);
   m.active = (m.rlane < m.rl) && (m.c < C);
   return m;
 }
@@ -147,13 +147,12 @@ __device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, i
 }
 
 template <int V>
-__global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
+__device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
-  __shared__ float s_coef[4][256 * V];     // scale, shift, scale2, shift2 of this block's channels
-  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
+  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
   // each channel's (replicated) statistics are summed ONCE per block, not once per thread
   for (int ci = threadIdx.x; ci < m.cw * V; ci += 256) {
-    const int c = blockIdx.y * m.cw * V + ci;
+    const int c = by * m.cw * V + ci;
     if (c >= p.C) continue;
     const BnCoef k = bn_coef(p.training, p.M, p.stats, p.C, c, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
     s_coef[0][ci] = k.scale; s_coef[1][ci] = k.shift;
@@ -162,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
       k2 = bn_coef(p.training, p.M, p.stats2, p.C, c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
       s_coef[2][ci] = k2.scale; s_coef[3][ci] = k2.shift;
     }
-    if (p.training && blockIdx.x == 0) {
+    if (p.training && bx == 0) {
       bn_side_effects(k, p.M, p.C, c, p.save, p.rmean, p.rvar, p.momentum);
       if (p.res_mode == 2) bn_side_effects(k2, p.M, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
     }
@@ -193,6 +192,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnApplyArgs p) {
     *reinterpret_cast<T*>(p.out + idx) = o;
   }
 }
+// single and paired launch forms (HP_OP_PAIR: two independent ops, one launch, flattened 2-D grids)
+#define HP_BN_KERNELS(NAME, ARGS, SHARED_DECL, SHARED_ARG)                                                        \
+  template <int V> __global__ __launch_bounds__(256) void NAME##_kernel(ARGS p) {                                 \
+    SHARED_DECL;                                                                                                  \
+    NAME##_body<V>(p, blockIdx.x, blockIdx.y, SHARED_ARG);                                                        \
+  }                                                                                                               \
+  template <int V> __global__ __launch_bounds__(256) void NAME##_pair_kernel(ARGS a, ARGS b, int gxa, int na, int gxb) { \
+    SHARED_DECL;                                                                                                  \
+    int id = blockIdx.x;                                                                                          \
+    if (id < na) NAME##_body<V>(a, id % gxa, id / gxa, SHARED_ARG);                                               \
+    else { id -= na; NAME##_body<V>(b, id % gxb, id / gxb, SHARED_ARG); }                                         \
+  }
+HP_BN_KERNELS(bn_apply, BnApplyArgs, __shared__ float s_coef[4][256 * V], s_coef)
 
 // ---- BN backward -----------------------------------------------------------------
 struct BnBwdReduceArgs {
@@ -204,10 +216,9 @@ struct BnBwdReduceArgs {
 };
 
 template <int V>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdReduceArgs p) {
+__device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, const int bx, const int by, double* lds) {
   using T = typename Vec<V>::T;
-  __shared__ double lds[3 * V * 256];
-  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
+  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
   double v[3 * V];
 #pragma unroll
   for (int j = 0; j < 3 * V; ++j) v[j] = 0.0;
@@ -244,17 +255,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(BnBwdReduceArgs p) {
   if (m.active && m.rlane == 0) {
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      double* b1 = stat_replica(p.bs, p.C, blockIdx.x);
+      double* b1 = stat_replica(p.bs, p.C, bx);
       atomic_add_f64(b1 + m.c + j, v[3 * j + 0]);
       atomic_add_f64(b1 + p.C + m.c + j, v[3 * j + 1]);
       if (p.has_second) {
-        double* b2 = stat_replica(p.bs2, p.C, blockIdx.x);
+        double* b2 = stat_replica(p.bs2, p.C, bx);
         atomic_add_f64(b2 + m.c + j, v[3 * j + 0]);
         atomic_add_f64(b2 + p.C + m.c + j, v[3 * j + 2]);
       }
     }
   }
 }
+
+HP_BN_KERNELS(bn_bwd_reduce, BnBwdReduceArgs, __shared__ double lds[3 * V * 256], lds)
 
 struct BnBwdApplyArgs {
   const float* g; const float* raw; const float* save; const double* bs; const float* gamma;
@@ -263,19 +276,18 @@ struct BnBwdApplyArgs {
 };
 
 template <int V>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs p) {
+__device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
-  __shared__ float s_coef[5][256 * V];     // mean, invstd, c1, c2, gamma*invstd
-  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V));
+  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
   for (int ci = threadIdx.x; ci < m.cw * V; ci += 256) {
-    const int c = blockIdx.y * m.cw * V + ci;
+    const int c = by * m.cw * V + ci;
     if (c >= p.C) continue;
     const float mean = p.save[c], invstd = p.save[p.C + c];
     const double sg = stat_sum(p.bs, p.C, 0, c), sgx = stat_sum(p.bs, p.C, 1, c);
     s_coef[0][ci] = mean; s_coef[1][ci] = invstd;
     s_coef[2][ci] = (float)(sg / (double)p.M); s_coef[3][ci] = (float)(sgx / (double)p.M);
     s_coef[4][ci] = p.gamma[c] * invstd;
-    if (blockIdx.x == 0) { p.dgamma[c] = (float)sgx; p.dbeta[c] = (float)sg; }
+    if (bx == 0) { p.dgamma[c] = (float)sgx; p.dbeta[c] = (float)sg; }
   }
   __syncthreads();
   if (!m.active) return;
@@ -299,6 +311,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(BnBwdApplyArgs p) {
     *reinterpret_cast<T*>(p.dr + idx) = o;
   }
 }
+
+HP_BN_KERNELS(bn_bwd_apply, BnBwdApplyArgs, __shared__ float s_coef[5][256 * V], s_coef)   // mean, invstd, c1, c2, gamma*invstd
 
 // ---- stem conv (C_in = 1) --------------------------------------------------------
 struct StemArgs { const float* x; const float* w; float* out; double* stats; const float* dr; float* dw; int B, Lin, Lout, C; };
@@ -698,7 +712,71 @@ __global__ void step_inc_kernel(int64_t* step) { if (threadIdx.x == 0 && blockId
 
 inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / per); }
 
+BnApplyArgs bn_apply_args(const HpOp& op, void* const* bases) {
+  using hp::ptr;
+  const int32_t* I = op.i;
+  BnApplyArgs a;
+  a.raw = ptr<const float>(op, 0, bases); a.out = ptr<float>(op, 1, bases); a.stats = ptr<const double>(op, 2, bases);
+  a.gamma = ptr<const float>(op, 3, bases); a.beta = ptr<const float>(op, 4, bases);
+  a.rmean = ptr<float>(op, 5, bases); a.rvar = ptr<float>(op, 6, bases); a.save = ptr<float>(op, 7, bases);
+  a.res = ptr<const float>(op, 8, bases); a.stats2 = ptr<const double>(op, 9, bases);
+  a.gamma2 = ptr<const float>(op, 10, bases); a.beta2 = ptr<const float>(op, 11, bases);
+  a.rmean2 = ptr<float>(op, 12, bases); a.rvar2 = ptr<float>(op, 13, bases); a.save2 = ptr<float>(op, 14, bases);
+  a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
+  a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
+  return a;
+}
+BnBwdReduceArgs bn_bwd_reduce_args(const HpOp& op, void* const* bases) {
+  using hp::ptr;
+  const int32_t* I = op.i;
+  BnBwdReduceArgs a;
+  a.g1 = ptr<const float>(op, 0, bases); a.g2 = I[2] ? ptr<const float>(op, 1, bases) : nullptr;
+  a.act = ptr<const float>(op, 2, bases); a.gout = ptr<float>(op, 3, bases);
+  a.raw = ptr<const float>(op, 4, bases); a.save = ptr<const float>(op, 5, bases); a.bs = ptr<double>(op, 6, bases);
+  a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
+  a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
+  return a;
+}
+BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
+  using hp::ptr;
+  BnBwdApplyArgs a;
+  a.g = ptr<const float>(op, 0, bases); a.raw = ptr<const float>(op, 1, bases); a.save = ptr<const float>(op, 2, bases);
+  a.bs = ptr<const double>(op, 3, bases); a.gamma = ptr<const float>(op, 4, bases); a.dr = ptr<float>(op, 5, bases);
+  a.dgamma = ptr<float>(op, 6, bases); a.dbeta = ptr<float>(op, 7, bases);
+  a.M = op.i[0]; a.C = op.i[1];
+  return a;
+}
+
 }  // namespace
+
+// one launch for two independent BatchNorm-family ops of the same opcode and vector width
+#define HP_PAIR_CASE(OPCODE, NAME, ARGFN)                                                                       \
+  case OPCODE: {                                                                                                \
+    const auto a = ARGFN(opa, bases);                                                                           \
+    const auto b = ARGFN(opb, bases);                                                                           \
+    if ((a.C % 4 == 0) != (b.C % 4 == 0)) return hipErrorInvalidValue;                                          \
+    if (a.C % 4 == 0) {                                                                                         \
+      const dim3 ga = colgrid_v<4>(a.M, a.C, rpl_of(4)), gb = colgrid_v<4>(b.M, b.C, rpl_of(4));                \
+      hipLaunchKernelGGL(NAME##_pair_kernel<4>, dim3(ga.x * ga.y + gb.x * gb.y), dim3(256), 0, s, a, b,         \
+                         (int)ga.x, (int)(ga.x * ga.y), (int)gb.x);                                             \
+    } else {                                                                                                    \
+      const dim3 ga = colgrid_v<1>(a.M, a.C, rpl_of(1)), gb = colgrid_v<1>(b.M, b.C, rpl_of(1));                \
+      hipLaunchKernelGGL(NAME##_pair_kernel<1>, dim3(ga.x * ga.y + gb.x * gb.y), dim3(256), 0, s, a, b,         \
+                         (int)ga.x, (int)(ga.x * ga.y), (int)gb.x);                                             \
+    }                                                                                                           \
+    break;                                                                                                      \
+  }
+hipError_t hp::launch_small_pair(const HpOp& opa, const HpOp& opb, void* const* bases, hipStream_t s) {
+  if (opa.op != opb.op) return hipErrorInvalidValue;
+  switch (opa.op) {
+    HP_PAIR_CASE(HP_OP_BN_APPLY, bn_apply, bn_apply_args)
+    HP_PAIR_CASE(HP_OP_BN_BWD_REDUCE, bn_bwd_reduce, bn_bwd_reduce_args)
+    HP_PAIR_CASE(HP_OP_BN_BWD_APPLY, bn_bwd_apply, bn_bwd_apply_args)
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+#undef HP_PAIR_CASE
 
 hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
   using hp::ptr;
@@ -711,36 +789,19 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       break;
     }
     case HP_OP_BN_APPLY: {
-      BnApplyArgs a;
-      a.raw = ptr<const float>(op, 0, bases); a.out = ptr<float>(op, 1, bases); a.stats = ptr<const double>(op, 2, bases);
-      a.gamma = ptr<const float>(op, 3, bases); a.beta = ptr<const float>(op, 4, bases);
-      a.rmean = ptr<float>(op, 5, bases); a.rvar = ptr<float>(op, 6, bases); a.save = ptr<float>(op, 7, bases);
-      a.res = ptr<const float>(op, 8, bases); a.stats2 = ptr<const double>(op, 9, bases);
-      a.gamma2 = ptr<const float>(op, 10, bases); a.beta2 = ptr<const float>(op, 11, bases);
-      a.rmean2 = ptr<float>(op, 12, bases); a.rvar2 = ptr<float>(op, 13, bases); a.save2 = ptr<float>(op, 14, bases);
-      a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
-      a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
+      const BnApplyArgs a = bn_apply_args(op, bases);
       if (a.C % 4 == 0) hipLaunchKernelGGL(bn_apply_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
       else hipLaunchKernelGGL(bn_apply_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_BN_BWD_REDUCE: {
-      BnBwdReduceArgs a;
-      a.g1 = ptr<const float>(op, 0, bases); a.g2 = I[2] ? ptr<const float>(op, 1, bases) : nullptr;
-      a.act = ptr<const float>(op, 2, bases); a.gout = ptr<float>(op, 3, bases);
-      a.raw = ptr<const float>(op, 4, bases); a.save = ptr<const float>(op, 5, bases); a.bs = ptr<double>(op, 6, bases);
-      a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
-      a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
+      const BnBwdReduceArgs a = bn_bwd_reduce_args(op, bases);
       if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
       else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_BN_BWD_APPLY: {
-      BnBwdApplyArgs a;
-      a.g = ptr<const float>(op, 0, bases); a.raw = ptr<const float>(op, 1, bases); a.save = ptr<const float>(op, 2, bases);
-      a.bs = ptr<const double>(op, 3, bases); a.gamma = ptr<const float>(op, 4, bases); a.dr = ptr<float>(op, 5, bases);
-      a.dgamma = ptr<float>(op, 6, bases); a.dbeta = ptr<float>(op, 7, bases);
-      a.M = I[0]; a.C = I[1];
+      const BnBwdApplyArgs a = bn_bwd_apply_args(op, bases);
       if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
       else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
       break;

@@ -63,6 +63,11 @@ hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
     const HpProgram::Group& g = p->groups[k];
     return hp::launch_wgrad_group(g.ntaps, g.probs, g.blocks, g.nblocks, s);
   }
+  if (op.op == HP_OP_PAIR) {
+    const HpOp& a = p->ops[op.i[0]];
+    const HpOp& b = p->ops[op.i[1]];
+    return a.op == HP_OP_CONV_TAPS ? hp::launch_conv_pair(a, b, p->bases, s) : hp::launch_small_pair(a, b, p->bases, s);
+  }
   return dispatch(op, p->bases, s);
 }
 
@@ -164,6 +169,18 @@ int hp_program_validate(const HpProgram* p) {
   std::string why;
   for (size_t k = 0; k < p->ops.size(); ++k) {
     if (validate_op(p->ops[k], p->sizes, (int)k, why)) return fail(why);
+    if (p->ops[k].op == HP_OP_PAIR) {
+      const HpOp& g = p->ops[k];
+      const bool in_range = g.i[0] >= 0 && g.i[1] >= 0 && g.i[0] < (int)k && g.i[1] < (int)k && g.i[0] != g.i[1];
+      if (!in_range) return fail("pair op " + std::to_string(k) + ": member index out of range");
+      const HpOp& a = p->ops[g.i[0]];
+      const HpOp& b = p->ops[g.i[1]];
+      const bool kind_ok = a.op == b.op && (a.flags & HP_FLAG_MEMBER) && (b.flags & HP_FLAG_MEMBER) &&
+                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1)) ||
+                            ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
+                             (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
+      if (!kind_ok) return fail("pair op " + std::to_string(k) + ": members are not two pairable ops of one kind");
+    }
     if (p->ops[k].op == HP_OP_WGRAD_GROUP) {
       const HpOp& g = p->ops[k];
       for (int j = g.i[0]; j < g.i[0] + g.i[1]; ++j) {

@@ -19,13 +19,22 @@ from .program import DeviceProgram, HipEngineError
 
 class Engine:
     def __init__(self, cfg: planner.ModelCfg, batch: int, train: planner.TrainCfg = None, with_class=False,
-                 device=None, share_params_from: "Engine" = None):
+                 device=None, share_params_from: "Engine" = None, _view=None):
         if not torch.cuda.is_available():
             raise HipEngineError("hippie_amd.Engine needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
         P.load_library()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.cfg, self.B, self.with_class = cfg, batch, with_class
         self.train_cfg = train or planner.TrainCfg()
+        self._graphs = {}
+        if _view is not None:
+            # a view over one model's slice of joint arenas owned by a PairEngine (which runs the program)
+            self.plan, (self.ws, self.params, self.grads, self.bufs, self.m, self.v) = _view
+            self.ops = self.plan.ops.array()
+            self.prog = None
+            self.num_batches_tracked = {k: 0 for k in self.plan.bn_keys}
+            self._init_bn_defaults()
+            return
         self.plan = planner.lower(cfg, batch, self.train_cfg, with_class)
         self.ops = self.plan.ops.array()
         n = self.plan.n_param_floats
@@ -45,7 +54,6 @@ class Engine:
             self.ws = torch.zeros(self.plan.ws_bytes, dtype=torch.uint8, device=self.device)
         arenas = [self.ws, self.params, self.grads, self.bufs, self.m, self.v]
         self.prog = DeviceProgram(self.ops, [a.data_ptr() for a in arenas], [a.numel() * a.element_size() for a in arenas])
-        self._graphs = {}
         if share_params_from is None:
             self._init_bn_defaults()
 

@@ -59,7 +59,7 @@ enum {
  * op, join at the end of the segment) so they overlap the main dependency chain; hp_program_run
  * executes them in order. */
 #define HP_FLAG_SIDE 0x100
-/* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP op: the program executor skips it
+/* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op: the program executor skips it
  * (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
 #define HP_FLAG_MEMBER 0x200
 
@@ -191,6 +191,11 @@ enum {
    * sit at program indices i[0] .. i[0]+i[1]-1, flagged HP_FLAG_MEMBER.  The library builds the device-side
    * problem and block tables from the member records on first use.  i[0]=first i[1]=count i[2]=ntaps */
   HP_OP_WGRAD_GROUP = 29,
+  /* One launch for two independent ops of the same opcode (CONV_TAPS with equal weight-layout flag, or the
+   * BatchNorm family BN_APPLY / BN_BWD_REDUCE / BN_BWD_APPLY) at program indices i[0] and i[1], both flagged
+   * HP_FLAG_MEMBER: twice the workgroups per launch.  Used to run the same layer of the wave and the time
+   * model together. */
+  HP_OP_PAIR = 30,
   HP_OP__COUNT
 };
 

@@ -356,7 +356,7 @@ def run(ops, A: Arenas, first=0, count=None):
         elif op == 28:   # ZERO
             nb = int(np.uint32(i[0])) + (int(np.uint32(i[1])) << 32)
             A.view(b[0], np.uint8, nb)[:] = 0
-        elif op == 29:   # WGRAD_GROUP: its member WGRAD_TAPS records (just before it) were executed in place
+        elif op in (29, 30):   # WGRAD_GROUP / PAIR: its member WGRAD_TAPS records (just before it) were executed in place
             pass
         else:
             raise ValueError(f"unknown opcode {op}")

@@ -277,3 +277,37 @@ def test_state_dict_roundtrip_and_reference_keys():
     cfgm = planner.ModelCfg(kind="multimodal", z_dim=10, output_size=50, output_size2=100)
     engm = Engine(cfgm, 4)
     assert sorted(engm.state_dict().keys()) == sorted(k for k, _, _ in man["multimodal_z10_o50_100"])
+
+
+def test_pair_engine_equals_two_engines():
+    """The zipped wave+time program (paired launches, one grouped wgrad) against two separate engines."""
+    from hippie_amd.pair import PairEngine
+    z, B = 10, 24
+    cfgs = [planner.ModelCfg("unimodal", z, 50), planner.ModelCfg("unimodal", z, 100)]
+    tcs = [planner.TrainCfg(lr=1e-6, clip=0.0), planner.TrainCfg(lr=1e-6, clip=1.0)]
+    pe = PairEngine(cfgs[0], cfgs[1], B, tcs[0], tcs[1])
+    singles = [Engine(c, B, t) for c, t in zip(cfgs, tcs)]
+    for k, L in enumerate((50, 100)):
+        om = O.OracleModel("unimodal", z, L, salt=20 + k)
+        sd = {kk: v.detach() for kk, v in om.state.items()}
+        x, src, cls, eps = O.synth_inputs(B, L, z, salt=20 + k)
+        for e in (pe.models[k], singles[k]):
+            e.load_state_dict(sd)
+            e.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+    for use_graph in (False, True, True):
+        pe.train_step(use_graph=use_graph)
+        for e in singles:
+            e.train_step(use_graph=False)
+        torch.cuda.synchronize()
+        for k in range(2):
+            np.testing.assert_allclose(pe.models[k].scalars(), singles[k].scalars(), rtol=2e-5)
+    for k in range(2):
+        assert pe.models[k].adam_step == 3
+        a, b = pe.models[k].state_dict(), singles[k].state_dict()
+        for kk in a:
+            if a[kk].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, kk):
+                H.assert_adam_close(n(a[kk]), n(b[kk]), 1e-6, kk, steps=3, frac=5e-2)
+        ga, gb = pe.models[k].grad_dict(), singles[k].grad_dict()
+        for kk in ga:
+            if not re.search(H.ZERO_GRAD_RE, kk):
+                H.assert_close(n(ga[kk]), n(gb[kk]), 2e-3, "pair grad " + kk)

@@ -391,3 +391,73 @@ def test_adamw_gradnorm_steps(n, clip):
         opt.step()
     got = view(gpu, p, np.float32, n)
     np.testing.assert_allclose(got, tp.detach().numpy(), rtol=2e-5, atol=2e-6)
+
+
+def run_program_both(img, recs):
+    """like run_both but through hp_program_create/run (needed for PAIR / WGRAD_GROUP, which reference
+    other records by program index)."""
+    image = img.image()
+    A = interp.Arenas([image.size, 4, 4, 4, 4, 4])
+    A.mem[0][:] = image
+    interp.run(recs, A)
+    dev = torch.from_numpy(image.copy()).cuda()
+    dummy = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    prog = P.DeviceProgram(recs, [dev.data_ptr()] + [dummy.data_ptr()] * 5, [dev.numel()] + [64] * 5)
+    prog.run(0, len(recs), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return dev.cpu().numpy(), A.mem[0]
+
+
+@pytest.mark.parametrize("w_kn", [False, True])
+def test_pair_conv_and_bn(w_kn):
+    """HP_OP_PAIR: two different-shaped convs / BatchNorm passes in one launch each."""
+    img = Img(21)
+    tms = [TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)]),
+           TapMap(5 * 50, 128, 64, 50, 50, 50, 1, 0, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)])]
+    ol = P.OpList()
+    outs = []
+    for tm in tms:
+        a = img.f32((tm.M // tm.Lout) * tm.Lin * tm.K)
+        w = img.f32(3 * tm.N * tm.K, scale=0.1)
+        out = img.f32(tm.M * tm.N, zero=True)
+        st = img.f64(R * 2 * tm.N)
+        ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | P.CONV_STATS | P.FLAG_MEMBER, tm.ints(), (), [a, w, out, None, st])
+        outs.append((tm, out, st))
+    ol.add(P.PAIR, 0, [0, 1])
+    # BN apply on both conv outputs, paired
+    bn = []
+    for k, (tm, out, st) in enumerate(outs):
+        C, M = tm.N, tm.M
+        gamma, beta, rm = img.f32(C), img.f32(C), img.f32(C, 0.1)
+        rv = img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5)
+        save, y = img.f32(2 * C, zero=True), img.f32(M * C, zero=True)
+        ol.add(P.BN_APPLY, P.FLAG_MEMBER, [M, C, 0, 1, 1], [0.01, 1e-5, 0.1], [out, y, st, gamma, beta, rm, rv, save])
+        bn.append((M, C, y, save, rm))
+    ol.add(P.PAIR, 0, [3, 4])
+    gpu, cpu = run_program_both(img, ol.array())
+    for tm, out, st in outs:
+        check(gpu, cpu, out, tm.M * tm.N, what="pair conv out")
+        check_stats(gpu, cpu, st, tm.N, what="pair conv stats")
+    for M, C, y, save, rm in bn:
+        check(gpu, cpu, y, M * C, rel=3e-5, what="pair bn out")
+        check(gpu, cpu, save, 2 * C, rel=3e-5, what="pair bn save")
+        check(gpu, cpu, rm, C, rel=3e-5, what="pair bn running mean")
+
+
+def test_wgrad_group_two_problems():
+    img = Img(22)
+    ol = P.OpList()
+    grads = []
+    for tm, nsplit in ((WGRAD_CASES["s1"](), 2), (WGRAD_CASES["up"](), 1), (WGRAD_CASES["big"](), 3)):
+        nb = tm.M // tm.Lout
+        dy, x = img.f32(tm.M * tm.N), img.f32(nb * tm.Lin * tm.K)
+        numel = 3 * tm.N * tm.K
+        rps = -(-(-(-tm.M // nsplit)) // 32) * 32
+        ns = -(-tm.M // rps)
+        g = img.f32(numel, zero=True)
+        ol.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER, tm.ints() + [ns, rps, numel], (), [dy, x, g])
+        grads.append((g, numel))
+    ol.add(P.WGRAD_GROUP, 0, [0, 3, 3])
+    gpu, cpu = run_program_both(img, ol.array())
+    for g, numel in grads:
+        check(gpu, cpu, g, numel, rel=3e-5, what="grouped wgrad")
