@@ -27,6 +27,9 @@ static TapMap tapmap_from(const HpOp& op) {
   return t;
 }
 
+// 16 bytes of zeros in device memory: padded / out-of-range rows load from here, so no select is needed
+__device__ __attribute__((aligned(16))) const float hp_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
 // per-component select (v_cndmask): a ternary on a whole float4 is lowered to a stack-array select
 __device__ __forceinline__ float4 mask4(const float4 v, bool ok) {
   return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
@@ -90,13 +93,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   // Loads are UNCONDITIONAL (a padded / out-of-range row reads a harmless valid address and is zeroed
   // when written to LDS): branch-free loads let the compiler wait with counted vmcnt(N), so the older
   // set can be consumed while the younger one is still in flight.
-  struct Pref { float4 a0, a1, b0, b1; unsigned ok; };
+  struct Pref { float4 a0, a1, b0, b1; };
   // Per-tap load state: four pointers advanced by a constant per K-slice (K is a multiple of 32 here),
   // recomputed only at tap boundaries — a slice costs four loads and four pointer adds, no index
   // arithmetic, no division, no scalar kernarg load (those share lgkmcnt with the LDS traffic).
   const float* pa0; const float* pa1; const float* pb0; const float* pb1;
   int ia0, ia1, ib0, ib1;
-  unsigned okmask = 0;
   int n_tap = 0, kc = 0;
   auto set_tap = [&](int tap) {
     const int to = t.tap_o[tap];
@@ -104,47 +106,48 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     const int pos0 = rl[0] + to, pos1 = rl[1] + to;
     const bool o0 = rvalid[0] && pos0 >= 0 && pos0 < t.P && (!t.even || !(pos0 & 1));
     const bool o1 = rvalid[1] && pos1 >= 0 && pos1 < t.P && (!t.even || !(pos1 & 1));
-    pa0 = o0 ? p.A + (size_t)(rbase[0] + (pos0 >> t.sh)) * t.K + aq : p.A;
-    pa1 = o1 ? p.A + (size_t)(rbase[1] + (pos1 >> t.sh)) * t.K + aq : p.A;
+    pa0 = o0 ? p.A + (size_t)(rbase[0] + (pos0 >> t.sh)) * t.K + aq : hp_zero16;
+    pa1 = o1 ? p.A + (size_t)(rbase[1] + (pos1 >> t.sh)) * t.K + aq : hp_zero16;
     ia0 = o0 ? 32 : 0;
     ia1 = o1 ? 32 : 0;
     bool o2, o3;
     if (!W_KN) {
       o2 = n0 + ar < t.N;
       o3 = n0 + ar + 32 < t.N;
-      pb0 = o2 ? wp + (size_t)(n0 + ar) * t.K + aq : p.W;
-      pb1 = o3 ? wp + (size_t)(n0 + ar + 32) * t.K + aq : p.W;
+      pb0 = o2 ? wp + (size_t)(n0 + ar) * t.K + aq : hp_zero16;
+      pb1 = o3 ? wp + (size_t)(n0 + ar + 32) * t.K + aq : hp_zero16;
       ib0 = o2 ? 32 : 0;
       ib1 = o3 ? 32 : 0;
     } else {
       o2 = o3 = n0 + nq < t.N;
-      pb0 = o2 ? wp + (size_t)kr * t.N + n0 + nq : p.W;
-      pb1 = o3 ? wp + (size_t)(kr + 16) * t.N + n0 + nq : p.W;
+      pb0 = o2 ? wp + (size_t)kr * t.N + n0 + nq : hp_zero16;
+      pb1 = o3 ? wp + (size_t)(kr + 16) * t.N + n0 + nq : hp_zero16;
       ib0 = ib1 = o2 ? 32 * t.N : 0;
     }
-    okmask = (o0 ? 1u : 0u) | (o1 ? 2u : 0u) | (o2 ? 4u : 0u) | (o3 ? 8u : 0u);
   };
   set_tap(0);
+  auto advance = [&]() {
+    pa0 += ia0; pa1 += ia1; pb0 += ib0; pb1 += ib1;
+    if (++kc == kper) {
+      kc = 0;
+      if (++n_tap < t.ntaps) set_tap(n_tap);
+    }
+  };
   auto fetch = [&]() -> Pref {
     Pref r;
     r.a0 = *reinterpret_cast<const float4*>(pa0);
     r.a1 = *reinterpret_cast<const float4*>(pa1);
     r.b0 = *reinterpret_cast<const float4*>(pb0);
     r.b1 = *reinterpret_cast<const float4*>(pb1);
-    r.ok = okmask;
-    pa0 += ia0; pa1 += ia1; pb0 += ib0; pb1 += ib1;
-    if (++kc == kper) {
-      kc = 0;
-      if (++n_tap < t.ntaps) set_tap(n_tap);
-    }
+    advance();
     return r;
   };
   auto stash = [&](int buf, const Pref r) {
     float* As = smem + buf * TILE;
     float* Bs = smem + 2 * TILE + buf * TILE;
-    *reinterpret_cast<float4*>(As + ar * LDA + aq) = mask4(r.a0, r.ok & 1u);
-    *reinterpret_cast<float4*>(As + (ar + 32) * LDA + aq) = mask4(r.a1, r.ok & 2u);
-    const float4 v0 = mask4(r.b0, r.ok & 4u), v1 = mask4(r.b1, r.ok & 8u);
+    *reinterpret_cast<float4*>(As + ar * LDA + aq) = r.a0;
+    *reinterpret_cast<float4*>(As + (ar + 32) * LDA + aq) = r.a1;
+    const float4 v0 = r.b0, v1 = r.b1;
     if (!W_KN) {
       *reinterpret_cast<float4*>(Bs + ar * LDA + aq) = v0;
       *reinterpret_cast<float4*>(Bs + (ar + 32) * LDA + aq) = v1;
@@ -182,10 +185,19 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
         b4[kk] = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);                              \
       }                                                                                                 \
     }                                                                                                   \
-    if (FETCH) LD = fetch();                                                                            \
-    __builtin_amdgcn_sched_barrier(0); /* keep the loads ABOVE the MFMA block and the older set's waits */ \
+    /* the non-MFMA work is spread over the MFMA groups (each v_mfma_f32_32x32x2 occupies the matrix pipe   \
+       for 64 cycles, during which the wave can issue other instructions): loads after group 0, pointer   \
+       bookkeeping after group 1, LDS stores of the next slice after group 2 */                            \
     _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
-      if (kk == 3 && (STASH)) stash((BUF) ^ 1, ST);                                                     \
+      if (kk == 1 && (FETCH)) {                                                                         \
+        LD.a0 = *reinterpret_cast<const float4*>(pa0);                                                  \
+        LD.a1 = *reinterpret_cast<const float4*>(pa1);                                                  \
+        LD.b0 = *reinterpret_cast<const float4*>(pb0);                                                  \
+        LD.b1 = *reinterpret_cast<const float4*>(pb1);                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+      }                                                                                                 \
+      if (kk == 2 && (FETCH)) { advance(); __builtin_amdgcn_sched_barrier(0); }                         \
+      if (kk == 3 && (STASH)) { stash((BUF) ^ 1, ST); __builtin_amdgcn_sched_barrier(0); }              \
       acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].x, b4[kk].x, acc4[kk], 0, 0, 0);           \
       acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].y, b4[kk].y, acc4[kk], 0, 0, 0);           \
       acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].z, b4[kk].z, acc4[kk], 0, 0, 0);           \
