@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 from hippie_amd import planner, program as P          # noqa: E402
 from hippie_amd.engine import Engine                   # noqa: E402
 
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 N_UNITS = 15631                   # cellexplorer-celltype pretrain pool, 80 % split
 BATCH = 512
@@ -57,11 +58,11 @@ def synth_dataset(n, device, seed=42):
 
 
 class Pair:
-    """wave + time models.  Default: ONE zipped program (hippie_amd.pair.PairEngine: every heavy op of the
-    two models in one launch) replayed as three hipGraphs on one stream.  --no-pair: two engines, each on
-    its own HIP stream."""
+    """wave + time models.  Default: two engines, each replaying its three hipGraphs on its own HIP stream
+    (the GPU overlaps the two models' kernels).  --pair: ONE zipped program (hippie_amd.pair.PairEngine:
+    every heavy op of the two models in one launch) on one stream."""
 
-    def __init__(self, device, world, lr=1e-3, paired=True):
+    def __init__(self, device, world, lr=1e-3, paired=False):
         self.device, self.world, self.paired = device, world, paired
         cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=50), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=100)]
         tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0), planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0)]
@@ -206,6 +207,16 @@ def conv_roofline(pair, data, idx, reps=3, detail=None):
     return tot_ms, tot_flop, launches, per_kernel
 
 
+def traffic_from_pmc():
+    """HBM bytes per conv launch from the committed rocprofv3 --pmc passes of this same command
+    (FETCH_SIZE doubled as the gfx950 guide prescribes + WRITE_SIZE, KB -> bytes); None if absent."""
+    try:
+        with open(PMC_SUMMARY) as f:
+            return json.load(f)["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(steps=3):
     """The torch-CPU oracle (kind 'port': a restatement of the reference's PyTorch path, pinned to it
     by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512."""
@@ -237,7 +248,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-pair", action="store_true", help="two engines on two streams instead of one zipped program")
+    ap.add_argument("--pair", action="store_true", help="one zipped wave+time program (paired launches) instead of two engines on two streams")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     args = ap.parse_args()
 
@@ -254,7 +265,7 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     data = synth_dataset(N_UNITS, device)
-    pair = Pair(device, world, paired=not args.no_pair)
+    pair = Pair(device, world, paired=args.pair)
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -309,7 +320,7 @@ def main():
                        "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_from_pmc(),
                          "kernel": ("conv_taps_pair_kernel" if pair.paired else "conv_taps_kernel") + " (fwd conv + dgrad, f32 MFMA 32x32x2)",
                          "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
                          "algorithmic_gflop_per_step": conv_flop / 1e9},
