@@ -708,6 +708,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     adam1(a.p[i], a.g[i], a.m[i], a.v[i], a, coef, step_size, bc2s);
   }
 }
+// F.interpolate(mode="linear", align_corners=False) per row (+ optional log(x+1)): dataloading.py:78,93,96
+__global__ void resample_linear_kernel(const float* in, float* out, int N, int W, int L, int log1) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= N * L) return;
+  const int n = id / L, i = id - n * L;
+  const float scale = (float)W / (float)L;
+  float src = scale * ((float)i + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  int x0 = (int)src;
+  x0 = x0 < W - 1 ? x0 : W - 1;
+  const int x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+  const float w1 = src - (float)x0, w0 = 1.f - w1;
+  float a = in[(size_t)n * W + x0], b = in[(size_t)n * W + x1];
+  if (log1) { a = logf(a + 1.f); b = logf(b + 1.f); }
+  out[id] = w0 * a + w1 * b;
+}
 __global__ void step_inc_kernel(int64_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
 
 inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / per); }
@@ -932,6 +948,10 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       hipLaunchKernelGGL(adamw_kernel, dim3(min(2048, max(1, blocks_for(a.n >> 2)))), dim3(256), 0, s, a);
       break;
     }
+    case HP_OP_RESAMPLE_LINEAR:
+      hipLaunchKernelGGL(resample_linear_kernel, dim3(blocks_for((int64_t)I[0] * I[2])), dim3(256), 0, s,
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2], op.flags & 1);
+      break;
     case HP_OP_STEP_INC:
       hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, ptr<int64_t>(op, 0, bases));
       break;

@@ -1,0 +1,22 @@
+"""get_embeddings of the reference (scripts/utils.py:75-101) for GPU modules."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+
+def get_embeddings(dataloader_wave, dataloader_time, wave_model, time_model):
+    """zip the two loaders, forward both modules, keep `enc` (output[0]), row-standardise with the
+    unbiased std (torch.std, ddof=1), concatenate wave | time.  Returns three numpy arrays."""
+    emb_w, emb_t = [], []
+    for (wave, label_wave), (time, label_time) in zip(dataloader_wave, dataloader_time):
+        assert (label_wave == label_time).all()
+        e_wave = wave_model((wave, label_wave))[0].clone()
+        e_time = time_model((time, label_time))[0].clone()
+        e_wave = (e_wave - e_wave.mean(dim=1)[:, None]) / e_wave.std(dim=1)[:, None]
+        e_time = (e_time - e_time.mean(dim=1)[:, None]) / e_time.std(dim=1)[:, None]
+        emb_w.append(e_wave)
+        emb_t.append(e_time)
+    ew = torch.cat(emb_w, dim=0).detach().cpu().numpy()
+    et = torch.cat(emb_t, dim=0).detach().cpu().numpy()
+    return ew, et, np.concatenate([ew, et], axis=1)

@@ -196,6 +196,12 @@ enum {
    * HP_FLAG_MEMBER: twice the workgroups per launch.  Used to run the same layer of the wave and the time
    * model together. */
   HP_OP_PAIR = 30,
+  /* EphysDatasetLabeled.__getitem__ preprocessing, batched (hippie/dataloading.py:74-96): optional
+   * log(x + 1), then F.interpolate(size=L, mode="linear", align_corners=False) of each row.
+   * out[n][i] = lerp(in[n][x0], in[n][x1], w) with src = max((i + 0.5) * W / L - 0.5, 0), x0 = floor(src),
+   * x1 = min(x0 + 1, W - 1), w = src - x0.  i[0]=N i[1]=W i[2]=L  flags: 1 = log(x+1) first
+   * buf: 0 IN[N][W] 1 OUT[N][L] */
+  HP_OP_RESAMPLE_LINEAR = 31,
   HP_OP__COUNT
 };
 

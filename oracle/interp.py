@@ -356,6 +356,13 @@ def run(ops, A: Arenas, first=0, count=None):
         elif op == 28:   # ZERO
             nb = int(np.uint32(i[0])) + (int(np.uint32(i[1])) << 32)
             A.view(b[0], np.uint8, nb)[:] = 0
+        elif op == 31:   # RESAMPLE_LINEAR
+            from oracle.preproc import resample_linear
+            N, W, L = int(i[0]), int(i[1]), int(i[2])
+            x = A.f32(b[0], N * W).reshape(N, W)
+            if flags & 1:
+                x = np.log(x + np.float32(1)).astype(np.float32)
+            A.f32(b[1], N * L)[:] = resample_linear(x, L).reshape(-1)
         elif op in (29, 30):   # WGRAD_GROUP / PAIR: its member WGRAD_TAPS records (just before it) were executed in place
             pass
         else:
