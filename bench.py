@@ -29,7 +29,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from hippie_amd import planner, program as P          # noqa: E402
+from hippie_amd import parallel, planner, program as P          # noqa: E402
 from hippie_amd.engine import Engine                   # noqa: E402
 
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_conv_pmc.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
@@ -112,7 +112,7 @@ class Pair:
             self.pe.forward(True, use_graph)
             self.pe.backward(use_graph)
             if self.groups is not None:
-                dist.all_reduce(self.pe.grads, op=dist.ReduceOp.AVG, group=self.groups[0])   # both models: one 64 MB buffer
+                parallel.allreduce_mean_(self.pe.grads, self.groups[0])   # both models: one 64 MB buffer
             self.pe.optimizer_step(use_graph)
             return
         cur = torch.cuda.current_stream(self.device)
@@ -125,7 +125,7 @@ class Pair:
                 e.forward(True, use_graph)
                 e.backward(use_graph)
                 if self.groups is not None:
-                    dist.all_reduce(e.grads, op=dist.ReduceOp.AVG, group=self.groups[k])
+                    parallel.allreduce_mean_(e.grads, self.groups[k])
                 e.optimizer_step(use_graph)
         for s in self.streams:
             cur.wait_stream(s)
@@ -254,6 +254,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("HIPPIE_SINGLE_DEVICE"):                       # rehearsal: every rank on GPU 0
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
@@ -262,7 +264,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        backend = os.environ.get("HIPPIE_DIST_BACKEND", "nccl")      # nccl = RCCL on ROCm; gloo only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     data = synth_dataset(N_UNITS, device)
     pair = Pair(device, world, paired=args.pair)
