@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Counterpart of the reference's scripts/train_model_with_multimodal.py (unimodal branch, :36-347):
+pretrain the wave and time cVAEs on every *other* dataset -> label-free fine-tune on the target dataset
+(lr/10, 10 %/90 % split) -> `pretraining_{dataset}_{waveform,isi,joint}_embeddings.csv`.
+
+Kept from the reference: the 22 CLI flags and defaults (:40-67), the dataset -> source-id map and pool
+exclusion rules including the "justacellular" typo that never matches (:81-101), `pd.read_csv` WITHOUT
+index_col (:117-121, the index column of some CSVs becomes feature 0), `dropna(axis=1)` on the fine-tune
+tables (:234-236), `torch.manual_seed(42)` then `random_split` of the index list (:78,136-147), loaders
+shuffle=True for pretrain / False for fine-tune, the wave trainer without and the time trainer with
+gradient clipping (:200-224), `val_loss`-monitored top-1 checkpoints reloaded before fine-tuning
+(:227-230), embeddings = row-standardised `enc` of the *train* fine-tune subset (:313-315), CSV layout
+(:329-343).  wandb is replaced by JSONL logs.  The supervised stage (:349-616) needs a `label` column
+that none of the shipped labels.csv has, and is not reproduced here.
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import torch
+from torch.utils.data import random_split
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from hippie_amd.dataloading import EphysDatasetLabeled                     # noqa: E402
+from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE   # noqa: E402
+from hippie_amd.trainer import Trainer                                       # noqa: E402
+from hippie_amd.utils import get_embeddings                                 # noqa: E402
+
+DATASET_FILES = {
+    "extracellular-mouse-a1": 1,
+    "cellexplorer-celltype": 3,
+    "cellexplorer-area": 3,
+    "juxtacellular-mouse-s1-celltype": 4,
+    "juxtacellular-mouse-s1-area": 4,
+    "allenscope-neuropixel": 3,
+    "neonatal-mouse-brain-slice": 2,
+}
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--z_dim", type=int, default=5)
+    p.add_argument("--weight-decay", type=float, default=0.01)
+    p.add_argument("--learning-rate", type=float, default=0.001)
+    p.add_argument("--beta", type=float, default=1)
+    p.add_argument("--dataset", type=str, default="cellexplorer-celltype")
+    p.add_argument("--upload-model", action="store_true")
+    p.add_argument("--wandb-tag", type=str, default="no_curr_sup_pretrain_data")
+    p.add_argument("--project", type=str, default="HIPPIE")
+    p.add_argument("--finetune-without-labels", type=bool, default=True)
+    p.add_argument("--pretrain-max-epochs", type=int, default=1)
+    p.add_argument("--finetune-max-epochs", type=int, default=1)
+    p.add_argument("--supervised-max-epochs", type=int, default=1)
+    p.add_argument("--batch-size", type=int, default=512)
+    p.add_argument("--supervised-batch-size", type=int, default=64)
+    p.add_argument("--early-stopping-patience", type=int, default=30)
+    p.add_argument("--gradient-clip-val", type=float, default=1.0)
+    p.add_argument("--train-val-split", type=float, default=0.8)
+    p.add_argument("--finetune-split", type=float, default=0.1)
+    p.add_argument("--limit-train-batches", type=float, default=None)
+    p.add_argument("--limit-val-batches", type=float, default=None)
+    p.add_argument("--model-type", type=str, choices=["unimodal", "multimodal"], default="unimodal")
+    p.add_argument("--mod1-weight", type=float, default=1.0)
+    p.add_argument("--mod2-weight", type=float, default=1.0)
+    # additions of this build
+    p.add_argument("--data-root", type=str, default="datasets")
+    p.add_argument("--output-dir", type=str, default=".")
+    return p
+
+
+def pretrain_pool(dataset):
+    files = dict(DATASET_FILES)
+    if "justacellular" in dataset:      # sic: the reference's typo, never true for the shipped names
+        files.pop("justacellular-mouse-s1-celltype", None)
+        files.pop("juxtacellular-mouse-s1-area", None)
+    if "cellexplorer" in dataset:
+        files.pop("cellexplorer-celltype", None)
+        files.pop("cellexplorer-area", None)
+    return {k: v for k, v in files.items() if k != dataset}
+
+
+class _Concat:
+    """torch.utils.data.ConcatDataset of preprocessed GPU tables, addressed by global index lists."""
+
+    def __init__(self, parts):
+        self.data = torch.cat([p.data for p in parts], dim=0)
+        self.labels = torch.cat([p.labels for p in parts], dim=0)
+
+    def loader(self, indices, batch_size, shuffle):
+        idx = torch.as_tensor(list(indices))
+
+        class _L:
+            def __iter__(s):
+                order = idx[torch.randperm(len(idx))] if shuffle else idx      # consumes the global RNG like DataLoader(shuffle=True)
+                order = order.to(self.data.device)
+                for i in range(0, len(order), batch_size):
+                    j = order[i: i + batch_size]
+                    yield self.data.index_select(0, j).unsqueeze(1), self.labels.index_select(0, j)
+
+            def __len__(s):
+                return -(-len(idx) // batch_size)
+        return _L()
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.model_type != "unimodal":
+        raise SystemExit("the reference's multimodal script branch builds EphysDatasetLabeled(mode='both'), which its own "
+                         "dataset class rejects (dataloading.py:67); only the unimodal pipeline is reproduced")
+    os.makedirs(args.output_dir, exist_ok=True)
+    torch.manual_seed(42)
+    num_sources = max(DATASET_FILES.values()) + 1
+    wave_parts, time_parts = [], []
+    for folder, sid in pretrain_pool(args.dataset).items():
+        wf = pd.read_csv(os.path.join(args.data_root, folder, "waveforms.csv")).to_numpy()
+        isi = pd.read_csv(os.path.join(args.data_root, folder, "isi_dist.csv")).to_numpy()
+        source = np.full((wf.shape[0]), sid)
+        print(f"Folder {folder} has shapes {wf.shape} and {isi.shape}")
+        wave_parts.append(EphysDatasetLabeled(wf, isi, source, mode="wave", normalize=False))
+        time_parts.append(EphysDatasetLabeled(wf, isi, source, mode="time", normalize=False))
+    all_wave, all_time = _Concat(wave_parts), _Concat(time_parts)
+    n = len(all_wave.labels)
+    print(f"Total waveforms {n} and total isi {len(all_time.labels)}")
+    prop = args.train_val_split
+    train_idx, test_idx = random_split(list(range(n)), [int(prop * n), n - int(prop * n)])
+    bs = args.batch_size
+
+    def fit(kind, module, train_loader, val_loader, epochs, clip, tag):
+        tr = Trainer(max_epochs=epochs, gradient_clip_val=clip, patience=args.early_stopping_patience,
+                     default_root_dir=os.path.join(args.output_dir, "checkpoints", f"{kind}_{tag}"),
+                     logger_path=os.path.join(args.output_dir, f"{kind}_{tag}_log.jsonl"))
+        tr.fit(module, train_loader, val_loader)
+        return tr
+
+    wave_net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=50, class_hidden_dim=5, num_sources=num_sources, num_classes=5)
+    time_net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=100, class_hidden_dim=5, num_sources=num_sources, num_classes=5)
+    # the unimodal branch builds its modules WITHOUT beta= (scripts/...:178-183), so --beta is ignored here too
+    wave_mod = hippieUnimodalEmbeddingModelCVAE(wave_net, learning_rate=args.learning_rate, weight_decay=args.weight_decay)
+    time_mod = hippieUnimodalEmbeddingModelCVAE(time_net, learning_rate=args.learning_rate, weight_decay=args.weight_decay)
+    trw = fit("wave", wave_mod, all_wave.loader(train_idx, bs, True), all_wave.loader(test_idx, bs, False), args.pretrain_max_epochs, None, "pretrain")
+    trt = fit("time", time_mod, all_time.loader(train_idx, bs, True), all_time.loader(test_idx, bs, False), args.pretrain_max_epochs, args.gradient_clip_val, "pretrain")
+    if trw.best_model_path:
+        wave_mod.load_state_dict(torch.load(trw.best_model_path, weights_only=False)["state_dict"])
+    if trt.best_model_path:
+        time_mod.load_state_dict(torch.load(trt.best_model_path, weights_only=False)["state_dict"])
+
+    # ---- label-free fine-tuning on the target dataset ----
+    wf_ft = pd.read_csv(os.path.join(args.data_root, args.dataset, "waveforms.csv")).dropna(axis=1).to_numpy()
+    isi_ft = pd.read_csv(os.path.join(args.data_root, args.dataset, "isi_dist.csv")).dropna(axis=1).to_numpy()
+    label_ft = np.full((wf_ft.shape[0]), DATASET_FILES[args.dataset])
+    ft_wave = _Concat([EphysDatasetLabeled(wf_ft, isi_ft, label_ft, mode="wave", normalize=False)])
+    ft_time = _Concat([EphysDatasetLabeled(wf_ft, isi_ft, label_ft, mode="time", normalize=False)])
+    m = len(label_ft)
+    if args.finetune_without_labels:
+        p2 = args.finetune_split
+        tr_i, te_i = random_split(list(range(m)), [int(p2 * m), m - int(p2 * m)])
+        wave_mod = hippieUnimodalEmbeddingModelCVAE(wave_mod.model, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay)
+        time_mod = hippieUnimodalEmbeddingModelCVAE(time_mod.model, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay)
+        lw, lt = ft_wave.loader(tr_i, bs, False), ft_time.loader(tr_i, bs, False)
+        fit("wave", wave_mod, lw, ft_wave.loader(te_i, bs, False), args.finetune_max_epochs, None, "finetune")
+        fit("time", time_mod, lt, ft_time.loader(te_i, bs, False), args.finetune_max_epochs, args.gradient_clip_val, "finetune")
+    else:
+        lw, lt = ft_wave.loader(range(m), bs, False), ft_time.loader(range(m), bs, False)
+    wave_mod.eval()
+    time_mod.eval()
+    ew, et, joint = get_embeddings(lw, lt, wave_mod, time_mod)
+    paths = {}
+    for name, emb in (("waveform", ew), ("isi", et), ("joint", joint)):
+        path = os.path.join(args.output_dir, f"pretraining_{args.dataset}_{name}_embeddings.csv")
+        pd.DataFrame({"embeddings": list(emb)}).to_csv(path)
+        paths[name] = path
+    with open(os.path.join(args.output_dir, "run_config.json"), "w") as f:
+        json.dump(vars(args), f)
+    return paths
+
+
+if __name__ == "__main__":
+    main()

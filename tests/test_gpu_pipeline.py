@@ -1,0 +1,61 @@
+"""GPU: the pipeline script counterpart on a synthetic data root (same folder / CSV conventions as the
+reference's datasets/, incl. a CSV with an unnamed index column)."""
+import os
+import sys
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_root(tmp, rng):
+    spec = {"extracellular-mouse-a1": (60, 40, 51, False), "neonatal-mouse-brain-slice": (90, 50, 100, False),
+            "cellexplorer-celltype": (50, 46, 100, True), "cellexplorer-area": (40, 46, 100, False),
+            "juxtacellular-mouse-s1-celltype": (30, 351, 100, False), "juxtacellular-mouse-s1-area": (30, 351, 100, True),
+            "allenscope-neuropixel": (70, 60, 100, False)}
+    for name, (n, w, h, with_index) in spec.items():
+        d = tmp / name
+        d.mkdir()
+        wf = pd.DataFrame(rng.standard_normal((n, w)))
+        isi = pd.DataFrame(np.abs(rng.standard_normal((n, h))) * 0.01)
+        wf.to_csv(d / "waveforms.csv", index=with_index)
+        isi.to_csv(d / "isi_dist.csv", index=with_index)
+    return spec
+
+
+def test_pipeline_end_to_end(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pretrain_pipeline as pp
+    assert set(pp.pretrain_pool("cellexplorer-celltype")) == {"extracellular-mouse-a1", "juxtacellular-mouse-s1-celltype",
+                                                               "juxtacellular-mouse-s1-area", "allenscope-neuropixel",
+                                                               "neonatal-mouse-brain-slice"}
+    # the reference's typo: a juxtacellular target only removes itself from the pool
+    assert "juxtacellular-mouse-s1-area" in pp.pretrain_pool("juxtacellular-mouse-s1-celltype")
+    a = pp.build_parser().parse_args([])
+    assert (a.z_dim, a.batch_size, a.learning_rate, a.gradient_clip_val, a.finetune_split) == (5, 512, 0.001, 1.0, 0.1)
+    rng = np.random.default_rng(0)
+    data = tmp_path / "datasets"
+    data.mkdir()
+    spec = make_root(data, rng)
+    out = tmp_path / "out"
+    paths = pp.main(["--dataset", "cellexplorer-celltype", "--data-root", str(data), "--output-dir", str(out),
+                     "--batch-size", "64", "--pretrain-max-epochs", "2", "--z_dim", "5"])
+    n_ft = int(0.1 * spec["cellexplorer-celltype"][0])
+    for name, width in (("waveform", 5), ("isi", 5), ("joint", 10)):
+        df = pd.read_csv(paths[name])
+        assert list(df.columns) == ["Unnamed: 0", "embeddings"] and len(df) == n_ft
+        vec = np.array(df["embeddings"][0].strip("[]").split(), dtype=float)
+        assert vec.shape == (width,) and np.isfinite(vec).all()
+    logs = [l for l in os.listdir(out) if l.endswith("_log.jsonl")]
+    assert sorted(logs) == ["time_finetune_log.jsonl", "time_pretrain_log.jsonl", "wave_finetune_log.jsonl", "wave_pretrain_log.jsonl"]
+    assert any(f.endswith(".ckpt") for f in os.listdir(out / "checkpoints" / "wave_pretrain"))
+    # random_split right after manual_seed(42) is the reference's split (same torch function, same seed)
+    torch.manual_seed(42)
+    from torch.utils.data import random_split
+    n = sum(v[0] for k, v in spec.items() if k in pp.pretrain_pool("cellexplorer-celltype"))
+    tr, te = random_split(list(range(n)), [int(0.8 * n), n - int(0.8 * n)])
+    assert len(tr) == int(0.8 * n) and len(set(tr.indices) & set(te.indices)) == 0
