@@ -116,7 +116,11 @@ class PairEngine:
         P.load_library()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.B = batch
-        plans = [planner.lower(cfg_a, batch, train_a or planner.TrainCfg()), planner.lower(cfg_b, batch, train_b or planner.TrainCfg())]
+        import dataclasses
+        # the zipped program pairs A with B; pairs inside one model would nest
+        ta = dataclasses.replace(train_a or planner.TrainCfg(), intra_pair=False)
+        tb = dataclasses.replace(train_b or planner.TrainCfg(), intra_pair=False)
+        plans = [planner.lower(cfg_a, batch, ta), planner.lower(cfg_b, batch, tb)]
         self.ops, self.segments, self.notes, bases_b = zip_programs(*plans)
         sa, sb = arena_sizes(plans[0]), arena_sizes(plans[1])
         with torch.cuda.device(self.device):

@@ -53,6 +53,7 @@ class TrainCfg:
     adam_eps: float = 1e-8
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
+    intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
 
 
 @dataclass
@@ -246,6 +247,19 @@ class Lowering:
         self.o.add(P.CONV_TAPS, flags, i=tm.ints(), buf=[a, w.ref, out, bias.ref if bias is not None else None, stats], note=note)
         self.pl.flops_fwd += 2 * tm.M * tm.N * tm.K * len(tm.taps) if not w_kn else 0
 
+    def pair_last_two(self, note="pair"):
+        """Launch the two most recently emitted ops (independent, same opcode) as one HP_OP_PAIR."""
+        if not self.train.intra_pair:
+            return
+        a, b = len(self.o.recs) - 2, len(self.o.recs) - 1
+        ra, rb = self.o.recs[a], self.o.recs[b]
+        assert int(ra["op"]) == int(rb["op"])
+        if int(ra["op"]) == P.CONV_TAPS and (int(ra["flags"]) & 1) != (int(rb["flags"]) & 1):
+            return
+        ra["flags"] = int(ra["flags"]) | P.FLAG_MEMBER
+        rb["flags"] = int(rb["flags"]) | P.FLAG_MEMBER
+        self.o.add(P.PAIR, 0, i=[a, b], note=note)
+
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note=""):
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
         if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
@@ -301,6 +315,7 @@ class Lowering:
             dr_b = self.pl.f32(M * C)
             self.o.add(P.BN_BWD_APPLY, 0, i=[M, C], buf=[g, raw_b, bn_b["save"], bs_b, bn_b["gamma"].ref, dr_b,
                                                          bn_b["gamma"].gref, bn_b["beta"].gref], note=bn_b["prefix"] + " bwd-apply")
+            self.pair_last_two("pair " + bn["prefix"] + " + shortcut bwd-apply")
         return g, dr, dr_b
 
     def linear_fwd(self, M, lin, x, ldx, y, ldy, act=False, stats=None, note=""):
@@ -358,6 +373,12 @@ class Lowering:
             r1 = pl.f32(Mo * cout)
             st1 = pl.stat(2 * cout) if training else None
             self.conv(tm1, cur, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1")
+            if s != 1:
+                tms, _ = self.map_fwd(Lc, cin, cout, s, k=1)
+                rs = pl.f32(Mo * cout)
+                sts = pl.stat(2 * cout) if training else None
+                self.conv(tms, cur, blk["sc"], rs, stats=sts, note=blk["prefix"] + "shortcut.0")
+                self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut.0")
             a1 = pl.f32(Mo * cout)
             self.bn_apply(Mo, blk["bn1"], r1, a1, st1, training, True, SLOPE_BACKBONE)
             tm2, _ = self.map_fwd(Lo, cout, cout, 1)
@@ -369,10 +390,6 @@ class Lowering:
             if s == 1:
                 self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 1, cur)
             else:
-                tms, _ = self.map_fwd(Lc, cin, cout, s, k=1)
-                rs = pl.f32(Mo * cout)
-                sts = pl.stat(2 * cout) if training else None
-                self.conv(tms, cur, blk["sc"], rs, stats=sts, note=blk["prefix"] + "shortcut.0")
                 self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
                 blk.update(rs=rs, tms=tms)
             cur, Lc = out, Lo
@@ -402,13 +419,16 @@ class Lowering:
             _, dr1, _ = self.bn_bwd(Mo, blk["bn1"], da1, None, blk["a1"], blk["r1"], SLOPE_BACKBONE)
             self.wgrad(blk["tm1"], dr1, blk["x"], blk["conv1"], note=blk["prefix"] + "conv1 wgrad")
             dxa = pl.f32(Mi * cin)
+            if s != 1:
+                self.wgrad(blk["tms"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut wgrad")
             self.conv(self.map_dgrad(Li, Lo, cin, cout, s), dr1, blk["conv1"], dxa, w_kn=True, note=blk["prefix"] + "conv1 dgrad")
             if s == 1:
                 G1, G2 = dxa, g
             else:
-                self.wgrad(blk["tms"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut wgrad")
                 dxs = pl.f32(Mi * cin)
                 self.conv(self.map_dgrad(Li, Lo, cin, cout, s, k=1), drs, blk["sc"], dxs, w_kn=True, note=blk["prefix"] + "shortcut dgrad")
+                if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
+                    self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut dgrad")
                 G1, G2 = dxa, dxs
         M = B * e["L1"]
         _, dr0, _ = self.bn_bwd(M, e["bn1"], G1, G2, e["a0"], e["raw0"], SLOPE_BACKBONE)
@@ -451,6 +471,7 @@ class Lowering:
                 rs = pl.f32(Mo * cout)
                 sts = pl.stat(2 * cout) if training else None
                 self.conv(tm1, cur, blk["sc"], rs, bias=blk["sc_b"], stats=sts, note=blk["prefix"] + "shortcut (resize)")
+                self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut (resize)")
                 out = pl.f32(Mo * cout)
                 self.bn_apply(Mo, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
                 blk.update(rs=rs)
@@ -488,11 +509,13 @@ class Lowering:
             else:
                 g, dr1, drs = self.bn_bwd(Mo, blk["bn1"], G1, G2, blk["out"], blk["r1"], SLOPE_BACKBONE, blk["scbn"], blk["rs"])
                 self.wgrad(blk["tm1"], dr1, blk["a2"], blk["conv1"], note=blk["prefix"] + "conv1 (resize) wgrad")
+                self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut (resize) wgrad")
                 da2 = pl.f32(Mi * cin)
                 self.conv(self.map_dgrad_up(Li, cin, cout), dr1, blk["conv1"], da2, w_kn=True, note=blk["prefix"] + "conv1 (resize) dgrad")
-                self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut (resize) wgrad")
                 side = pl.f32(Mi * cin)
                 self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, note=blk["prefix"] + "shortcut (resize) dgrad")
+                if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
+                    self.pair_last_two("pair " + blk["prefix"] + "resize dgrads")
             _, dr2, _ = self.bn_bwd(Mi, blk["bn2"], da2, None, blk["a2"], blk["r2"], SLOPE_BACKBONE)
             self.wgrad(blk["tm2"], dr2, blk["x"], blk["conv2"], note=blk["prefix"] + "conv2 wgrad")
             dxa = pl.f32(Mi * cin)
