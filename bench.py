@@ -39,19 +39,19 @@ BATCH = 512
 Z_DIM = 10
 
 
-def synth_dataset(n, device, seed=42):
+def synth_dataset(n, device, seed=42, lw=50, lt=100):
     """Synthetic waveform [n,50] / ISI [n,100] / source labels, SURVEY.md section 8(d)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
-    t = torch.linspace(0, 1, 50)[None, :]
+    t = torch.linspace(0, 1, lw)[None, :]
     ratio = 0.2 + 0.4 * torch.rand(n, 1, generator=g)
     wave = -torch.exp(-0.5 * ((t - 0.3) / 0.04) ** 2) + ratio * torch.exp(-0.5 * ((t - 0.5) / 0.1) ** 2)
-    wave = wave + 0.02 * torch.randn(n, 50, generator=g)
+    wave = wave + 0.02 * torch.randn(n, lw, generator=g)
     lo, hi = wave.min(1, keepdim=True).values, wave.max(1, keepdim=True).values
     wave = (wave - lo) / (hi - lo) * 2 - 1
-    bins = torch.arange(1, 101, dtype=torch.float32)[None, :]
+    bins = torch.arange(1, lt + 1, dtype=torch.float32)[None, :]
     theta = 3 + 12 * torch.rand(n, 1, generator=g)
     pdf = bins * torch.exp(-bins / theta)
-    isi = pdf / pdf.sum(1, keepdim=True) + (1e-3 * torch.randn(n, 100, generator=g)).abs()
+    isi = pdf / pdf.sum(1, keepdim=True) + (1e-3 * torch.randn(n, lt, generator=g)).abs()
     isi = torch.log1p(isi)
     labels = torch.randint(1, 5, (n,), generator=g)
     return wave.float().to(device), isi.float().to(device), labels.to(device)
@@ -62,9 +62,9 @@ class Pair:
     (the GPU overlaps the two models' kernels).  --pair: ONE zipped program (hippie_amd.pair.PairEngine:
     every heavy op of the two models in one launch) on one stream."""
 
-    def __init__(self, device, world, lr=1e-3, paired=False):
+    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100)):
         self.device, self.world, self.paired = device, world, paired
-        cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=50), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=100)]
+        cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
         tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0), planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0)]
         if paired:
             from hippie_amd.pair import PairEngine
@@ -250,8 +250,17 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pair", action="store_true", help="one zipped wave+time program (paired launches) instead of two engines on two streams")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
+    # non-default shapes (BASELINE configs[2]: --batch 4096 --z-dim 32 --wave-len 256 --time-len 32); the headline
+    # metric is always quoted on the defaults
+    ap.add_argument("--batch", type=int, default=512)
+    ap.add_argument("--z-dim", type=int, default=10)
+    ap.add_argument("--wave-len", type=int, default=50)
+    ap.add_argument("--time-len", type=int, default=100)
+    ap.add_argument("--units", type=int, default=N_UNITS)
     args = ap.parse_args()
 
+    global BATCH, Z_DIM, N_UNITS
+    BATCH, Z_DIM, N_UNITS = args.batch, args.z_dim, max(args.units, args.batch * 2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("HIPPIE_SINGLE_DEVICE"):                       # rehearsal: every rank on GPU 0
@@ -270,8 +279,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    data = synth_dataset(N_UNITS, device)
-    pair = Pair(device, world, paired=args.pair)
+    data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
+    pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len))
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -320,9 +329,11 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
-                                   "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "
-                                   "fp32 arithmetic on f32 MFMA (parity path; bf16 not used)",
+            "config": {"workload": ("BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
+                                    "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "
+                                    "fp32 arithmetic on f32 MFMA (parity path; bf16 not used)")
+                       if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
+                       f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
