@@ -242,6 +242,7 @@ def cpu_baseline(steps=3):
 
 
 def main():
+    global BATCH, Z_DIM, N_UNITS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -256,10 +257,9 @@ def main():
     ap.add_argument("--z-dim", type=int, default=10)
     ap.add_argument("--wave-len", type=int, default=50)
     ap.add_argument("--time-len", type=int, default=100)
-    ap.add_argument("--units", type=int, default=N_UNITS)
+    ap.add_argument("--units", type=int, default=15631)
     args = ap.parse_args()
 
-    global BATCH, Z_DIM, N_UNITS
     BATCH, Z_DIM, N_UNITS = args.batch, args.z_dim, max(args.units, args.batch * 2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
