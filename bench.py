@@ -187,23 +187,30 @@ def conv_roofline(pair, data, idx, reps=3, detail=None):
             acc /= reps
             for j in range(count):
                 r = e.ops[first + j]
-                name = P.OP_NAMES[int(r["op"])]
+                opc = int(r["op"])
+                if int(r["flags"]) & P.FLAG_MEMBER:
+                    continue                                  # executed (and timed) by its PAIR / WGRAD_GROUP launch
+                members = [r]
+                name = P.OP_NAMES[opc]
+                if opc == P.PAIR:
+                    members = [e.ops[int(r["i"][0])], e.ops[int(r["i"][1])]]
+                    name = "PAIR:" + P.OP_NAMES[int(members[0]["op"])]
+                elif opc == P.WGRAD_GROUP:
+                    members = list(e.ops[int(r["i"][0]): int(r["i"][0]) + int(r["i"][1])])
                 d = per_kernel.setdefault(name, [0.0, 0])
                 d[0] += acc[j]
                 d[1] += 1
-                if int(r["op"]) == P.CONV_TAPS:
-                    M, N, K, nt = int(r["i"][0]), int(r["i"][1]), int(r["i"][2]), int(r["i"][9])
-                    tot_flop += 2.0 * M * N * K * nt
-                    tot_ms += acc[j]
-                    launches += 1
-                if detail is not None and int(r["op"]) in (P.CONV_TAPS, P.WGRAD_TAPS) and not (int(r["flags"]) & P.FLAG_MEMBER):
-                    M, N, K, nt = int(r["i"][0]), int(r["i"][1]), int(r["i"][2]), int(r["i"][9])
-                    fl = 2.0 * M * N * K * nt
-                    detail.append((name, e.plan.ops.notes[first + j], M, N, K, nt, int(r["flags"]), acc[j] * 1e3, fl / (acc[j] * 1e-3) / 1e12))
-                if detail is not None and int(r["op"]) == P.WGRAD_GROUP:
-                    mem = e.ops[int(r["i"][0]): int(r["i"][0]) + int(r["i"][1])]
-                    fl = sum(2.0 * int(m["i"][0]) * int(m["i"][1]) * int(m["i"][2]) * int(m["i"][9]) for m in mem)
-                    detail.append((name, e.plan.ops.notes[first + j], len(mem), 0, 0, int(r["i"][2]), 0, acc[j] * 1e3, fl / (acc[j] * 1e-3) / 1e12))
+                mop = int(members[0]["op"])
+                if mop in (P.CONV_TAPS, P.WGRAD_TAPS):
+                    flop = sum(2.0 * int(m["i"][0]) * int(m["i"][1]) * int(m["i"][2]) * int(m["i"][9]) for m in members)
+                    if mop == P.CONV_TAPS:
+                        tot_flop += flop
+                        tot_ms += acc[j]
+                        launches += 1
+                    if detail is not None:
+                        m0 = members[0]
+                        detail.append((name, e.plan.ops.notes[first + j], int(m0["i"][0]), int(m0["i"][1]), int(m0["i"][2]), int(m0["i"][9]),
+                                       len(members), acc[j] * 1e3, flop / (acc[j] * 1e-3) / 1e12))
     return tot_ms, tot_flop, launches, per_kernel
 
 
@@ -338,7 +345,7 @@ def main():
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_from_pmc(),
-                         "kernel": ("conv_taps_pair_kernel" if pair.paired else "conv_taps_kernel") + " (fwd conv + dgrad, f32 MFMA 32x32x2)",
+                         "kernel": "conv_taps_kernel + conv_taps_pair_kernel (same body: fwd conv + dgrad, f32 MFMA 32x32x2)",
                          "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
                          "algorithmic_gflop_per_step": conv_flop / 1e9},
         }
