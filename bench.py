@@ -329,7 +329,7 @@ def main():
             for d in detail:
                 print("%-16s %-50s M=%6d N=%4d K=%4d taps=%d n=%d %8.1f us %6.1f TF" % d, file=sys.stderr)
         out = {
-            "metric": "pretrain samples/sec (waveform+time cVAE, batch 512)",
+            "metric": "pretrain samples/sec (waveform+time cVAE, batch 512) at 1/2/4/8 MI355X",
             "value": BATCH * world * args.steps / dt,
             "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -59,3 +59,36 @@ def test_pipeline_end_to_end(tmp_path):
     n = sum(v[0] for k, v in spec.items() if k in pp.pretrain_pool("cellexplorer-celltype"))
     tr, te = random_split(list(range(n)), [int(0.8 * n), n - int(0.8 * n)])
     assert len(tr) == int(0.8 * n) and len(set(tr.indices) & set(te.indices)) == 0
+
+
+def test_inference_script_roundtrip(tmp_path):
+    """checkpoints written by the Trainer -> scripts/inference.py -> embedding CSVs in the reference's layout"""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import inference
+    from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
+    from hippie_amd.trainer import Trainer
+    rng = np.random.default_rng(1)
+    data = tmp_path / "datasets"
+    data.mkdir()
+    make_root(data, rng)
+    z = 8
+    ck = {}
+    for kind, L in (("wave", 50), ("time", 100)):
+        net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+        mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-4)
+        tr = Trainer(max_epochs=1, default_root_dir=str(tmp_path / kind))
+        tr.current_epoch = 0
+        net.engine(4, False)                       # materialise parameters
+        path = str(tmp_path / f"{kind}.ckpt")
+        tr.save_checkpoint(mod, path)
+        ck[kind] = path
+    out = inference.main(["--z_dim", str(z), "--dataset", "cellexplorer-area", "--wave-checkpoint", ck["wave"],
+                          "--time-checkpoint", ck["time"], "--output-dir", str(tmp_path / "emb"), "--data-root", str(data)])
+    for name, width in (("waveform", z), ("isi", z), ("joint", 2 * z)):
+        df = pd.read_csv(out[name])
+        assert list(df.columns) == [str(i) for i in range(width)] + ["label", "label_name"]
+        assert len(df) == 40 and (df["label_name"] == "unknown").all()
+        v = df[[str(i) for i in range(width)]].to_numpy()
+        assert np.isfinite(v).all()
+    w = pd.read_csv(out["waveform"])[[str(i) for i in range(z)]].to_numpy()
+    np.testing.assert_allclose(w.mean(1), 0, atol=1e-5)
