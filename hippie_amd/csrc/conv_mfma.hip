@@ -55,7 +55,13 @@ struct ConvArgs {
 };
 
 constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
+constexpr int kConvThreads = 512;
 
+// One 64x64 output tile per 512-thread workgroup: 8 waves = 4 tile quadrants (32x32 MFMA tiles) x 2 K-halves.
+// The two waves that share a quadrant each take half of every 32-wide K slice (two 8-wide groups) and
+// sit on the same SIMD pair-wise, so one wave's global loads / LDS traffic / address arithmetic overlap
+// the other's MFMAs — at batch 512 a layer has only ~256 tiles for 1024 SIMDs, so this is the only way to
+// get two waves per SIMD.  Their partial accumulators are summed once, through LDS, in the epilogue.
 template <bool W_KN>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
@@ -64,70 +70,54 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
 
   const TapMap& t = p.t;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int quad = wave & 3, kh = wave >> 2;
+  const int wm = quad >> 1, wn = quad & 1, li = lane & 31, lh = lane >> 5;
   const int nt = (t.N + 63) >> 6, mt = (t.M + 63) >> 6;
   const int tile = xcd_remap(bid, mt * nt);
   const int m0 = (tile / nt) << 6, n0 = (tile % nt) << 6;
 
-  // fixed per-thread load slots: rows ar, ar+32 of the A tile; 16-byte column aq
+  // fixed per-thread load slot: row ar of the A tile (and of the [n][k] weight image), 16-byte column aq
   const int ar = tid >> 3, aq = (tid & 7) << 2;
-  int rbase[2], rl[2];
-  bool rvalid[2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int m = m0 + ar + 32 * j;
-    rvalid[j] = m < t.M;
-    const int b = m / t.Lout;
-    rbase[j] = b * t.Lin;
-    rl[j] = t.a * (m - b * t.Lout);
-  }
-  const int kr = tid >> 4, nq = (tid & 15) << 2;   // [k][n] weight image slots
+  const int kr = tid >> 4, nq = (tid & 15) << 2;   // [k][n] weight image slot
+  const int m_row = m0 + ar;
+  const bool rvalid = m_row < t.M;
+  const int b_row = m_row / t.Lout;
+  const int rbase = b_row * t.Lin;
+  const int rl = t.a * (m_row - b_row * t.Lout);
 
-  const int kper = (t.K + 31) >> 5;
+  const int kper = t.K >> 5;
   const int nsteps = t.ntaps * kper;
   const size_t wslab = (size_t)t.N * t.K;
 
-  // Two register sets (plain structs of scalars so they stay in VGPRs): slice s+1 waits in one while
-  // slice s+2 is being fetched into the other, so a global load has ~1.75 K-steps (~1800 MFMA cycles)
-  // to land — with one workgroup per CU (batch 512) nothing else hides the L2 / Infinity-Cache round trip.
-  // Loads are UNCONDITIONAL (a padded / out-of-range row reads a harmless valid address and is zeroed
-  // when written to LDS): branch-free loads let the compiler wait with counted vmcnt(N), so the older
-  // set can be consumed while the younger one is still in flight.
-  struct Pref { float4 a0, a1, b0, b1; };
-  // Per-tap load state: four pointers advanced by a constant per K-slice (K is a multiple of 32 here),
-  // recomputed only at tap boundaries — a slice costs four loads and four pointer adds, no index
-  // arithmetic, no division, no scalar kernarg load (those share lgkmcnt with the LDS traffic).
-  const float* pa0; const float* pa1; const float* pb0; const float* pb1;
-  int ia0, ia1, ib0, ib1;
+  // Two register sets (plain structs so they stay in VGPRs): slice s+1 waits in one while slice s+2 is being
+  // fetched into the other.  Loads are UNCONDITIONAL (a padded / out-of-range row reads 16 bytes of zeros):
+  // branch-free loads let the compiler wait with counted vmcnt(N).
+  struct Pref { float4 a, b; };
+  // Per-tap load state: pointers advanced by a constant per K-slice, recomputed only at tap boundaries.
+  const float* pa; const float* pb;
+  int ia, ib;
   int n_tap = 0, kc = 0;
   auto set_tap = [&](int tap) {
     const int to = t.tap_o[tap];
     const float* wp = p.W + (size_t)t.tap_w[tap] * wslab;
-    const int pos0 = rl[0] + to, pos1 = rl[1] + to;
-    const bool o0 = rvalid[0] && pos0 >= 0 && pos0 < t.P && (!t.even || !(pos0 & 1));
-    const bool o1 = rvalid[1] && pos1 >= 0 && pos1 < t.P && (!t.even || !(pos1 & 1));
-    pa0 = o0 ? p.A + (size_t)(rbase[0] + (pos0 >> t.sh)) * t.K + aq : hp_zero16;
-    pa1 = o1 ? p.A + (size_t)(rbase[1] + (pos1 >> t.sh)) * t.K + aq : hp_zero16;
-    ia0 = o0 ? 32 : 0;
-    ia1 = o1 ? 32 : 0;
-    bool o2, o3;
+    const int pos = rl + to;
+    const bool oa = rvalid && pos >= 0 && pos < t.P && (!t.even || !(pos & 1));
+    pa = oa ? p.A + (size_t)(rbase + (pos >> t.sh)) * t.K + aq : hp_zero16;
+    ia = oa ? 32 : 0;
+    bool ob;
     if (!W_KN) {
-      o2 = n0 + ar < t.N;
-      o3 = n0 + ar + 32 < t.N;
-      pb0 = o2 ? wp + (size_t)(n0 + ar) * t.K + aq : hp_zero16;
-      pb1 = o3 ? wp + (size_t)(n0 + ar + 32) * t.K + aq : hp_zero16;
-      ib0 = o2 ? 32 : 0;
-      ib1 = o3 ? 32 : 0;
+      ob = n0 + ar < t.N;
+      pb = ob ? wp + (size_t)(n0 + ar) * t.K + aq : hp_zero16;
+      ib = ob ? 32 : 0;
     } else {
-      o2 = o3 = n0 + nq < t.N;
-      pb0 = o2 ? wp + (size_t)kr * t.N + n0 + nq : hp_zero16;
-      pb1 = o3 ? wp + (size_t)(kr + 16) * t.N + n0 + nq : hp_zero16;
-      ib0 = ib1 = o2 ? 32 * t.N : 0;
+      ob = n0 + nq < t.N;
+      pb = ob ? wp + (size_t)kr * t.N + n0 + nq : hp_zero16;
+      ib = ob ? 32 * t.N : 0;
     }
   };
   set_tap(0);
   auto advance = [&]() {
-    pa0 += ia0; pa1 += ia1; pb0 += ib0; pb1 += ib1;
+    pa += ia; pb += ib;
     if (++kc == kper) {
       kc = 0;
       if (++n_tap < t.ntaps) set_tap(n_tap);
@@ -135,73 +125,59 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   };
   auto fetch = [&]() -> Pref {
     Pref r;
-    r.a0 = *reinterpret_cast<const float4*>(pa0);
-    r.a1 = *reinterpret_cast<const float4*>(pa1);
-    r.b0 = *reinterpret_cast<const float4*>(pb0);
-    r.b1 = *reinterpret_cast<const float4*>(pb1);
+    r.a = *reinterpret_cast<const float4*>(pa);
+    r.b = *reinterpret_cast<const float4*>(pb);
     advance();
     return r;
   };
   auto stash = [&](int buf, const Pref r) {
     float* As = smem + buf * TILE;
     float* Bs = smem + 2 * TILE + buf * TILE;
-    *reinterpret_cast<float4*>(As + ar * LDA + aq) = r.a0;
-    *reinterpret_cast<float4*>(As + (ar + 32) * LDA + aq) = r.a1;
-    const float4 v0 = r.b0, v1 = r.b1;
-    if (!W_KN) {
-      *reinterpret_cast<float4*>(Bs + ar * LDA + aq) = v0;
-      *reinterpret_cast<float4*>(Bs + (ar + 32) * LDA + aq) = v1;
-    } else {
-      *reinterpret_cast<float4*>(Bs + kr * LDBK + nq) = v0;
-      *reinterpret_cast<float4*>(Bs + (kr + 16) * LDBK + nq) = v1;
-    }
+    *reinterpret_cast<float4*>(As + ar * LDA + aq) = r.a;
+    if (!W_KN) *reinterpret_cast<float4*>(Bs + ar * LDA + aq) = r.b;
+    else       *reinterpret_cast<float4*>(Bs + kr * LDBK + nq) = r.b;
   };
 
-  // four independent accumulators (one per 8-wide k group of a slice): blocked summation keeps the
-  // fp32 rounding error of a K=1536 contraction at the level of a vectorised CPU kernel.
-  f32x16 acc4[4];
+  // two independent accumulators per wave (one per 8-wide k group it owns): with the other K-half that is
+  // four partial sums per output — blocked summation keeps the fp32 rounding of a K=1536 contraction at the
+  // level of a vectorised CPU kernel.
+  f32x16 acc2[2];
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
+  for (int q = 0; q < 2; ++q)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc4[q][r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
 
-  // One K-step.  LDS[BUF] holds the current slice; ST holds the next one (stored to the other buffer
-  // before the last MFMA group); LD receives the slice after that.  (1) all LDS fragment reads first, into
-  // distinct registers: lane (i,h) takes k = 8kk+4h..+3 of its row and MFMA jj pairs element jj of both
-  // operands — a K permutation applied identically to A and B; (2) the global loads; (3) MFMAs with the
-  // LDS stores slotted in.  FETCH / STASH are compile-time: the steady-state loop has no conditions, so
-  // the compiler's vmcnt bookkeeping stays exact (a merged "maybe pending" path costs a full drain).
+  // One K-step.  LDS[BUF] holds the current slice; ST holds the next one (stored to the other buffer before
+  // the second MFMA group); LD receives the slice after that.  Lane (i,h) takes k = 8kk+4h..+3 of its row and
+  // MFMA jj pairs element jj of both operands — a K permutation applied identically to A and B.
+  // FETCH / STASH are compile-time: the steady-state loop has no conditions, so the compiler's vmcnt
+  // bookkeeping stays exact (a merged "maybe pending" path costs a full drain).
 #define HP_KSTEP(BUF, ST, LD, FETCH, STASH)                                                             \
   {                                                                                                     \
-    const float* As = smem + (BUF) * TILE + (wm * 32 + li) * LDA + lh * 4;                              \
+    const float* As = smem + (BUF) * TILE + (wm * 32 + li) * LDA + lh * 4 + kh * 16;                    \
     const float* Bs = smem + 2 * TILE + (BUF) * TILE;                                                   \
-    float4 a4[4], b4[4];                                                                                \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
-      a4[kk] = *reinterpret_cast<const float4*>(As + kk * 8);                                           \
+    float4 a4[2], b4[2];                                                                                \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                     \
+      a4[g] = *reinterpret_cast<const float4*>(As + g * 8);                                             \
       if (!W_KN) {                                                                                      \
-        b4[kk] = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDA + kk * 8 + lh * 4);        \
+        b4[g] = *reinterpret_cast<const float4*>(Bs + (wn * 32 + li) * LDA + kh * 16 + g * 8 + lh * 4); \
       } else {                                                                                          \
-        const float* bk = Bs + (kk * 8 + lh * 4) * LDBK + wn * 32 + li;                                 \
-        b4[kk] = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);                              \
+        const float* bk = Bs + (kh * 16 + g * 8 + lh * 4) * LDBK + wn * 32 + li;                        \
+        b4[g] = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);                               \
       }                                                                                                 \
     }                                                                                                   \
-    /* the non-MFMA work is spread over the MFMA groups (each v_mfma_f32_32x32x2 occupies the matrix pipe   \
-       for 64 cycles, during which the wave can issue other instructions): loads after group 0, pointer   \
-       bookkeeping after group 1, LDS stores of the next slice after group 2 */                            \
-    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
-      if (kk == 1 && (FETCH)) {                                                                         \
-        LD.a0 = *reinterpret_cast<const float4*>(pa0);                                                  \
-        LD.a1 = *reinterpret_cast<const float4*>(pa1);                                                  \
-        LD.b0 = *reinterpret_cast<const float4*>(pb0);                                                  \
-        LD.b1 = *reinterpret_cast<const float4*>(pb1);                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                              \
-      }                                                                                                 \
-      if (kk == 2 && (FETCH)) { advance(); __builtin_amdgcn_sched_barrier(0); }                         \
-      if (kk == 3 && (STASH)) { stash((BUF) ^ 1, ST); __builtin_amdgcn_sched_barrier(0); }              \
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].x, b4[kk].x, acc4[kk], 0, 0, 0);           \
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].y, b4[kk].y, acc4[kk], 0, 0, 0);           \
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].z, b4[kk].z, acc4[kk], 0, 0, 0);           \
-      acc4[kk] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[kk].w, b4[kk].w, acc4[kk], 0, 0, 0);           \
+    if (FETCH) {                                                                                        \
+      LD.a = *reinterpret_cast<const float4*>(pa);                                                      \
+      LD.b = *reinterpret_cast<const float4*>(pb);                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+    }                                                                                                   \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                     \
+      if (g == 1 && (FETCH)) { advance(); __builtin_amdgcn_sched_barrier(0); }                          \
+      if (g == 1 && (STASH)) { stash((BUF) ^ 1, ST); __builtin_amdgcn_sched_barrier(0); }               \
+      acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].x, b4[g].x, acc2[g], 0, 0, 0);               \
+      acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].y, b4[g].y, acc2[g], 0, 0, 0);               \
+      acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].z, b4[g].z, acc2[g], 0, 0, 0);               \
+      acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].w, b4[g].w, acc2[g], 0, 0, 0);               \
     }                                                                                                   \
     __syncthreads();                                                                                    \
   }
@@ -229,9 +205,19 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   }
 #undef HP_KSTEP
 
+  // sum the two K-halves through LDS (the staging buffers are free after the last barrier)
   f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = (acc4[0][r] + acc4[1][r]) + (acc4[2][r] + acc4[3][r]);
+  for (int r = 0; r < 16; ++r) acc[r] = acc2[0][r] + acc2[1][r];
+  float* red = smem + quad * (16 * 64);
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
 
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int n = n0 + wn * 32 + li;
@@ -260,7 +246,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
 }
 
 template <bool W_KN>
-__global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
+__global__ __launch_bounds__(kConvThreads) void conv_taps_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[kConvLds];
   conv_body<W_KN>(p, blockIdx.x, smem);
 }
@@ -269,7 +255,7 @@ __global__ __launch_bounds__(256) void conv_taps_kernel(ConvArgs p) {
 // block's conv1 and its shortcut) in ONE launch: twice the workgroups per launch at batch 512, where a
 // single layer only fills each CU with one workgroup.
 template <bool W_KN>
-__global__ __launch_bounds__(256) void conv_taps_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
+__global__ __launch_bounds__(kConvThreads) void conv_taps_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
   __shared__ __attribute__((aligned(16))) float smem[kConvLds];
   if ((int)blockIdx.x < nblk_a) conv_body<W_KN>(a, blockIdx.x, smem);
   else conv_body<W_KN>(b, blockIdx.x - nblk_a, smem);
@@ -290,16 +276,16 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
   if ((opa.flags & 1) != (opb.flags & 1)) return hipErrorInvalidValue;
   const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
   const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
-  if (opa.flags & 1) hipLaunchKernelGGL(conv_taps_pair_kernel<true>, dim3(na + nb), dim3(256), 0, s, a, b, na);
-  else               hipLaunchKernelGGL(conv_taps_pair_kernel<false>, dim3(na + nb), dim3(256), 0, s, a, b, na);
+  if (opa.flags & 1) hipLaunchKernelGGL(conv_taps_pair_kernel<true>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
+  else               hipLaunchKernelGGL(conv_taps_pair_kernel<false>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
   return hipGetLastError();
 }
 
 hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
   const ConvArgs a = conv_args_from(op, bases);
   const int nblk = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64);
-  if (op.flags & 1) hipLaunchKernelGGL(conv_taps_kernel<true>, dim3(nblk), dim3(256), 0, s, a);
-  else              hipLaunchKernelGGL(conv_taps_kernel<false>, dim3(nblk), dim3(256), 0, s, a);
+  if (op.flags & 1) hipLaunchKernelGGL(conv_taps_kernel<true>, dim3(nblk), dim3(kConvThreads), 0, s, a);
+  else              hipLaunchKernelGGL(conv_taps_kernel<false>, dim3(nblk), dim3(kConvThreads), 0, s, a);
   return hipGetLastError();
 }
 
