@@ -70,3 +70,25 @@ def test_planner_programs_validate_without_gpu(kind):
     segs = plan.ops.segments
     assert set(segs) == {"fwd_train", "bwd", "opt", "fwd_eval"}
     assert sum(c for _, c in segs.values()) == len(ops)
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: on a machine without an MI355X the engine refuses to construct."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from hippie_amd.engine import Engine
+    from hippie_amd.program import HipEngineError
+    with pytest.raises(HipEngineError):
+        Engine(planner.ModelCfg("unimodal", 10, 50), 8)
+    from hippie_amd.dataloading import resample_on_device
+    with pytest.raises(HipEngineError):
+        resample_on_device(torch.zeros(4, 40), 50)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under hippie_amd/ or scripts/ may import it."""
+    import glob
+    for path in glob.glob(os.path.join(ROOT, "hippie_amd", "*.py")) + glob.glob(os.path.join(ROOT, "scripts", "*.py")):
+        src = open(path).read()
+        assert "import oracle" not in src and "from oracle" not in src, path

@@ -312,3 +312,20 @@ def test_pair_engine_equals_two_engines():
             if not re.search(H.ZERO_GRAD_RE, kk):
                 # two runs with different atomic summation orders may differ in a few leaky-ReLU masks
                 H.grad_parity(n(ga[kk]), n(gb[kk]), n(gb[kk]), flips=1, msg="pair grad " + kk)
+
+
+@pytest.mark.parametrize("B,L", [(2, 50), (3, 100), (65, 33), (513, 50)])
+def test_ragged_batches_and_lengths(B, L):
+    """Tiny, odd and tile-straddling batches / lengths: forward, loss and one full step against the oracle."""
+    c = dict(kind="unimodal", z=10, L=L, B=B, with_class=False, beta=1.0, clip=1.0, lr=1e-4, salt=40 + B)
+    eng, oms, batch, batch64, eps = build(**c)
+    check_forward(eng, oms, batch, batch64, eps, training=False)
+    outs64 = oms[1].forward(batch64, eps.double(), True)
+    ls64 = oms[1].losses(batch64, outs64, 1.0)
+    sc = eng.train_step()
+    torch.cuda.synchronize()
+    got = eng.scalars()
+    np.testing.assert_allclose([got[0], got[1], got[3]], [float(v) for v in ls64], rtol=2e-4)
+    sd = eng.state_dict()
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
+    assert eng.adam_step == 1
