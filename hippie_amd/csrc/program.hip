@@ -13,8 +13,6 @@ struct HpProgram {
   std::vector<hipGraphExec_t> segs;
   std::vector<hipGraph_t> graphs;
   hipStream_t capture_stream = nullptr;
-  hipStream_t side_streams[2] = {nullptr, nullptr};
-  std::vector<hipEvent_t> events;
   struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; };
   std::vector<Group> groups;          // indexed by op index (empty entries for non-group ops)
   bool groups_ready = false;
@@ -156,9 +154,7 @@ int hp_program_destroy(HpProgram* p) {
   if (!p) return 0;
   for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
   for (auto g : p->graphs) if (g) hipGraphDestroy(g);
-  for (auto e : p->events) if (e) hipEventDestroy(e);
   for (auto& g : p->groups) { if (g.probs) hipFree(g.probs); if (g.blocks) hipFree(g.blocks); }
-  for (auto s : p->side_streams) if (s) hipStreamDestroy(s);
   if (p->capture_stream) hipStreamDestroy(p->capture_stream);
   delete p;
   return 0;
@@ -217,45 +213,15 @@ int hp_program_capture(HpProgram* p, int first, int count, int* seg) {
     e = hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking);
     if (e != hipSuccess) return fail_hip("hipStreamCreate", e);
   }
-  for (auto& ss : p->side_streams)
-    if (!ss) {
-      e = hipStreamCreateWithFlags(&ss, hipStreamNonBlocking);
-      if (e != hipSuccess) return fail_hip("hipStreamCreate", e);
-    }
-  auto new_event = [&]() -> hipEvent_t {
-    hipEvent_t ev = nullptr;
-    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return nullptr;
-    p->events.push_back(ev);
-    return ev;
-  };
   if (ensure_groups(p)) return 1;
   e = hipStreamBeginCapture(p->capture_stream, hipStreamCaptureModeThreadLocal);
   if (e != hipSuccess) return fail_hip("hipStreamBeginCapture", e);
-  // fork/join: ops flagged HP_FLAG_SIDE go to side branches that depend on everything captured so far
-  int rc = 0, nside = 0;
-  bool used[2] = {false, false};
+  // a linear graph: multi-branch (fork/join) graphs were measured slower on this runtime
+  int rc = 0;
   for (int k = first; k < first + count && rc == 0; ++k) {
-    const HpOp& op = p->ops[k];
-    hipStream_t s = p->capture_stream;
-    if (op.flags & HP_FLAG_SIDE) {
-      const int w = nside++ & 1;
-      hipEvent_t ev = new_event();
-      if (!ev || hipEventRecord(ev, p->capture_stream) != hipSuccess || hipStreamWaitEvent(p->side_streams[w], ev, 0) != hipSuccess) {
-        rc = fail("hp_program_capture: fork failed");
-        break;
-      }
-      used[w] = true;
-      s = p->side_streams[w];
-    }
-    hipError_t le = run_one(p, k, s);
+    hipError_t le = run_one(p, k, p->capture_stream);
     if (le != hipSuccess) rc = fail_hip("capture launch", le);
   }
-  for (int w = 0; w < 2; ++w)
-    if (used[w]) {
-      hipEvent_t ev = new_event();
-      if (!ev || hipEventRecord(ev, p->side_streams[w]) != hipSuccess || hipStreamWaitEvent(p->capture_stream, ev, 0) != hipSuccess)
-        rc = fail("hp_program_capture: join failed");
-    }
   hipGraph_t graph = nullptr;
   e = hipStreamEndCapture(p->capture_stream, &graph);
   if (rc != 0) { if (graph) hipGraphDestroy(graph); return 1; }

@@ -30,7 +30,6 @@ OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
 CONV_W_KN, CONV_BIAS, CONV_STATS = 1, 2, 4
-FLAG_SIDE = 0x100        # HP_FLAG_SIDE: leaf op, may run on a side branch of the captured graph
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP launch
 
 

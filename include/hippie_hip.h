@@ -53,12 +53,6 @@ enum {
 #define HP_OP_NF 8
 #define HP_OP_NB 16
 
-/* Op flag (any opcode): the op is a LEAF of its segment — it depends on everything before it in program
- * order and nothing later in the segment reads what it writes (weight-gradient kernels).  When a
- * segment is captured into a hipGraph such ops are placed on side branches (fork after the preceding
- * op, join at the end of the segment) so they overlap the main dependency chain; hp_program_run
- * executes them in order. */
-#define HP_FLAG_SIDE 0x100
 /* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op: the program executor skips it
  * (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
 #define HP_FLAG_MEMBER 0x200
