@@ -35,3 +35,16 @@ for name in sorted(os.listdir(ROOT)):
     print(name, w.shape, t.shape, out[name + ".wave_out"].shape, out[name + ".isi_out"].shape)
 out["names"] = np.array(names)
 np.savez_compressed(os.path.join(HERE, "datasets_first8.npz"), **out)
+
+# (9) the reference's train/val split: torch.manual_seed(42) then random_split of the index list
+# (scripts/train_model_with_multimodal.py:78,136-147) for the pool sizes the shipped datasets give
+from torch.utils.data import random_split   # noqa: E402
+splits = {}
+for n, prop in ((2975, 0.8), (3797, 0.8), (392, 0.1)):
+    torch.manual_seed(42)
+    idx = list(range(n))
+    tr, te = random_split(idx, [int(prop * n), n - int(prop * n)])
+    splits[f"n{n}_train"] = np.array(tr.indices)
+    splits[f"n{n}_test"] = np.array(te.indices)
+np.savez_compressed(os.path.join(HERE, "random_split_seed42.npz"), **splits)
+print("splits", {k: v.shape for k, v in splits.items()})

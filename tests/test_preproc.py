@@ -80,3 +80,16 @@ def test_get_embeddings_contract():
             e = oms[0].forward((xs[0][i: i + 8], src[i: i + 8], None), torch.zeros(len(xs[0][i: i + 8]), z), training=False)[0]
         want.append(((e - e.mean(1, keepdim=True)) / e.std(1, keepdim=True)).numpy())
     np.testing.assert_allclose(ew, np.concatenate(want), rtol=2e-3, atol=2e-4)
+
+
+def test_train_val_split_matches_reference_seed42():
+    """The pipeline's split is the reference's: same torch function, same seed, same call order."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts"))
+    from torch.utils.data import random_split
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "random_split_seed42.npz"))
+    for n, prop in ((2975, 0.8), (3797, 0.8), (392, 0.1)):
+        torch.manual_seed(42)
+        tr, te = random_split(list(range(n)), [int(prop * n), n - int(prop * n)])
+        np.testing.assert_array_equal(np.array(tr.indices), g[f"n{n}_train"])
+        np.testing.assert_array_equal(np.array(te.indices), g[f"n{n}_test"])
