@@ -224,7 +224,7 @@ def traffic_from_pmc():
         return None
 
 
-def cpu_baseline(steps=3):
+def cpu_baseline(steps=16):
     """The torch-CPU oracle (kind 'port': a restatement of the reference's PyTorch path, pinned to it
     by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512."""
     from oracle import cvae_oracle as O
