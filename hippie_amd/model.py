@@ -95,6 +95,9 @@ class _Net:
         return sum(i.numel for i in self._any_engine().plan.params.values())
 
     def _run_forward(self, eng: Engine, x, src, cls, eps, x2=None):
+        if self.training and eng.B < 2:
+            # torch's BatchNorm1d in training mode: "Expected more than 1 value per channel when training"
+            raise ValueError("Expected more than 1 value per channel when training (batch of 1 in train mode)")
         eng.set_inputs(x, src, cls, eps, x2=x2)
         return eng.forward(training=self.training)
 

@@ -168,6 +168,7 @@ class Lowering:
         self.pl = Plan(cfg, batch, self.train, with_class)
         self.o = self.pl.ops
         self.pending_wgrads = []
+        self.count_flops = False          # forward FLOPs (2*MAC, conv + linear) are counted for the training forward only
 
     # ---- parameter declaration (own order; class_embedding last so that AdamW can skip it) ----
     def declare_encoder(self, pre):
@@ -245,7 +246,8 @@ class Lowering:
     def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note=""):
         flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias is not None else 0) | (P.CONV_STATS if stats is not None else 0)
         self.o.add(P.CONV_TAPS, flags, i=tm.ints(), buf=[a, w.ref, out, bias.ref if bias is not None else None, stats], note=note)
-        self.pl.flops_fwd += 2 * tm.M * tm.N * tm.K * len(tm.taps) if not w_kn else 0
+        if self.count_flops and not w_kn:
+            self.pl.flops_fwd += 2 * tm.M * tm.N * tm.K * len(tm.taps)
 
     def pair_last_two(self, note="pair"):
         """Launch the two most recently emitted ops (independent, same opcode) as one HP_OP_PAIR."""
@@ -321,7 +323,8 @@ class Lowering:
     def linear_fwd(self, M, lin, x, ldx, y, ldy, act=False, stats=None, note=""):
         self.o.add(P.LINEAR_FWD, 0, i=[M, lin["N"], lin["K"], ldx, ldy, 1 if act else 0, 1 if stats is not None else 0],
                    f=[SLOPE_HEADS], buf=[x, lin["w"].ref, lin["b"].ref, y, stats], note=note)
-        self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
+        if self.count_flops:
+            self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
 
     def linear_bwd(self, M, lin, dy, ldy, x, ldx, dx=None, lddx=None, mask=None, ldmask=0, accumulate=False, note=""):
         self.o.add(P.LINEAR_BWD_W, 0, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
@@ -361,7 +364,8 @@ class Lowering:
         raw0 = pl.f32(M * 64)
         st = pl.stat(128) if training else None
         self.o.add(P.STEM_FWD, 0, i=[B, L, L1, 64], buf=[x, e["conv1"].ref, raw0, st], note=e["prefix"] + "conv1")
-        pl.flops_fwd += 2 * M * 64 * 3
+        if self.count_flops:
+            pl.flops_fwd += 2 * M * 64 * 3
         a0 = pl.f32(M * 64)
         self.bn_apply(M, e["bn1"], raw0, a0, st, training, True, SLOPE_BACKBONE)
         e.update(x=x, L=L, L1=L1, raw0=raw0, a0=a0)
@@ -480,7 +484,8 @@ class Lowering:
         assert Lc == 32
         t = pl.f32(B * 64)
         self.o.add(P.TAIL_FWD, 0, i=[B, 32, 64], buf=[cur, d["tail_w"].ref, d["tail_b"].ref, t], note=d["prefix"] + "conv1 (resize 64->1)")
-        pl.flops_fwd += 2 * B * 64 * 64 * 3
+        if self.count_flops:
+            pl.flops_fwd += 2 * B * 64 * 64 * 3
         lo = dict(w=d["out_w"], b=d["out_b"], N=d["output_size"], K=64)
         rec = pl.f32(B * d["output_size"])
         self.linear_fwd(B, lo, t, 64, rec, d["output_size"], note=d["prefix"] + "linear_out")
@@ -601,6 +606,7 @@ class Lowering:
         segs = {}
         for mode in ("train", "eval"):
             training = mode == "train"
+            self.count_flops = training
             self.o.begin("fwd_" + mode)
             zero_idx = self.o.add(P.ZERO, 0, i=[0, 0], buf=[Ref(P.WS, pl.stats_base)], note="zero statistics")
             pooled = [self.encoder_fwd(e, x, L, training) for e, x, L in zip(enc, xs, lens)]
@@ -660,13 +666,11 @@ class Lowering:
             self.o.add(P.LOSS_FINALIZE, 0, i=[B, n1, n2], f=[self.train.beta, self.train.w1 if multi else 1.0,
                                                              self.train.w2 if multi else 0.0], buf=[loss, scal], note="loss scalars")
             self.o.end()
+            self.count_flops = False
             if not training:
-                self.o.recs[zero_idx]["i"][0] = pl.stats_cap   # patched below
                 segs["eval_zero"] = zero_idx
                 continue
             segs["train_zero"] = zero_idx
-            if mode == "train":
-                fwd_flops = pl.flops_fwd
 
             # ---------------- backward ----------------
             self.o.begin("bwd")
@@ -722,8 +726,6 @@ class Lowering:
             self.o.add(P.ADAMW, 0, i=[n], f=[t.lr, t.beta1, t.beta2, t.adam_eps, t.weight_decay, t.clip],
                        buf=[Ref(P.PARAM, 0), Ref(P.GRAD, 0), Ref(P.ADAM_M, 0), Ref(P.ADAM_V, 0), self.step_ref, norm2], note="AdamW")
             self.o.end()
-            pl.flops_fwd = 0
-        pl.flops_fwd = fwd_flops
         # finalize: statistics region size into both ZERO ops; slab at the end of the workspace
         used = _round_up(pl.stats_bytes, 256)
         for key in ("train_zero", "eval_zero"):

@@ -95,6 +95,12 @@ def test_two_column_labels_and_lr_rewrap():
     assert enc.shape == (16, z) and dec.shape == (16, 1, L)
     with pytest.raises(ValueError):
         net(torch.zeros(4, 1, 60).cuda(), source_labels=torch.ones(4, dtype=torch.int64).cuda())
+    net.train()
+    with pytest.raises(ValueError):          # BatchNorm cannot train on a single row (torch raises too)
+        net(torch.zeros(1, 1, L).cuda(), source_labels=torch.ones(1, dtype=torch.int64).cuda())
+    net.eval()
+    one = net(torch.zeros(1, 1, L).cuda(), source_labels=torch.ones(1, dtype=torch.int64).cuda())
+    assert one[0].shape == (1, z) and torch.isfinite(one[3]).all()
 
 
 def test_multimodal_module_step_and_metrics():

@@ -132,3 +132,10 @@ def test_unimodal_deterministic_wgrad_slabs():
 
 def test_multimodal_step():
     run_case("multimodal", 10, 50, 6, False, 1.0, 1.0, 1e-3, 7, L2=100, w1=1.0, w2=0.5)
+
+
+def test_forward_flop_count_matches_survey_probe():
+    """SURVEY.md section 2.1 [probe]: conv+linear forward FLOPs per sample (2*MAC)."""
+    for L, z, want in ((50, 10, 98585744), (100, 10, 131336976), (256, 32, 232528384), (32, 32, 80151040)):
+        pl = planner.lower(planner.ModelCfg("unimodal", z, L), 4, planner.TrainCfg())
+        assert pl.flops_fwd // 4 == want, (L, z, pl.flops_fwd // 4)
