@@ -671,18 +671,19 @@ __global__ __launch_bounds__(256) void gradnorm_kernel(const float* g, double* n
   block_atomic_f64(s, norm2);
 }
 
-struct AdamArgs { float* p; const float* g; float* m; float* v; const int64_t* step; const double* norm2; int n; float lr, b1, b2, eps, wd, clip; };
+struct AdamArgs { float* p; const float* g; float* m; float* v; const int64_t* step; const double* norm2; int n; float lr, b1, b2, eps, wd, clip, omb1, omb2; };
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& a, float coef, float step_size, float bc2s) {
   g *= coef;
   p *= (1.f - a.lr * a.wd);
-  m = m + (1.f - a.b1) * (g - m);          // exp_avg.lerp_(grad, 1 - beta1)
-  v = v * a.b2 + (1.f - a.b2) * g * g;
+  m = m + a.omb1 * (g - m);          // exp_avg.lerp_(grad, 1 - beta1)
+  v = v * a.b2 + a.omb2 * g * g;
   const float denom = sqrtf(v) / bc2s + a.eps;
   p = p - step_size * (m / denom);
 }
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
   const double t = (double)a.step[0];
-  const double bc1 = 1.0 - pow((double)a.b1, t), bc2 = 1.0 - pow((double)a.b2, t);
+  // beta reconstructed from the fp32 complements: 1 - beta^t keeps ~1e-7 relative accuracy at small t
+  const double bc1 = 1.0 - pow(1.0 - (double)a.omb1, t), bc2 = 1.0 - pow(1.0 - (double)a.omb2, t);
   const float step_size = (float)((double)a.lr / bc1), bc2s = (float)sqrt(bc2);
   float coef = 1.f;
   if (a.clip > 0.f) {
@@ -707,6 +708,78 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
     const int i = (nv << 2) + threadIdx.x;
     adam1(a.p[i], a.g[i], a.m[i], a.v[i], a, coef, step_size, bc2s);
   }
+}
+// ---- Schedule-Free AdamW (hippie/optimizers.py:105-209) -------------------------------------------
+// per-step scalars, fp64 like the reference's Python floats (:118-138)
+__global__ void sf_schedule_kernel(const int64_t* step, double* st, int warmup, float lr, float omb2, float r, float power) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double k = (double)step[0];
+  const double sched = k < (double)warmup ? (k + 1.0) / (double)warmup : 1.0;
+  const double bc2 = 1.0 - pow(1.0 - (double)omb2, k + 1.0);
+  const double lr_t = (double)lr * sched * sqrt(bc2);
+  const double lr_max = lr_t > st[0] ? lr_t : st[0];
+  const double weight = pow(k + 1.0, (double)r) * pow(lr_max, (double)power);
+  const double wsum = st[1] + weight;
+  st[0] = lr_max;
+  st[1] = wsum;
+  st[2] = lr_t;
+  st[3] = wsum != 0.0 ? weight / wsum : 0.0;
+}
+// torch.lerp: start + w*(end-start) for |w| < 0.5, else end - (end-start)*(1-w)
+__device__ __forceinline__ float torch_lerp(float a, float b, float w) {
+  const float d = b - a;
+  return fabsf(w) < 0.5f ? a + w * d : b - d * (1.f - w);
+}
+struct SfArgs {
+  float *y, *z, *v;
+  const float* g;
+  const int64_t* step;
+  const double *st, *norm2;
+  int n;
+  float b1, b2, eps, wd, clip, omb2;
+};
+__device__ __forceinline__ void sf1(float& y, float g, float& z, float& v, const SfArgs& a, float coef, float ckp1,
+                                    float ay, float lr_t, bool first) {
+  g *= coef;
+  if (first) z = y;
+  v = v * a.b2 + a.omb2 * g * g;
+  float gn = g / (sqrtf(v) + a.eps);
+  if (a.wd != 0.f) gn += a.wd * y;
+  y = torch_lerp(y, z, ckp1);
+  y += ay * gn;
+  z -= lr_t * gn;
+}
+__global__ __launch_bounds__(256) void adamw_sf_kernel(SfArgs a) {
+  const bool first = a.step[0] == 0;
+  const double lr_d = a.st[2], ck_d = a.st[3];
+  const float lr_t = (float)lr_d, ckp1 = (float)ck_d;
+  const float ay = (float)(lr_d * ((double)a.b1 * (1.0 - ck_d) - 1.0));
+  float coef = 1.f;
+  if (a.clip > 0.f) {
+    const float c = a.clip / ((float)sqrt(a.norm2[0]) + 1e-6f);
+    coef = c < 1.f ? c : 1.f;
+  }
+  const int nv = a.n >> 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += gridDim.x * blockDim.x) {
+    float4 y = reinterpret_cast<float4*>(a.y)[i];
+    const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+    float4 z = reinterpret_cast<float4*>(a.z)[i];
+    float4 v = reinterpret_cast<float4*>(a.v)[i];
+    sf1(y.x, g.x, z.x, v.x, a, coef, ckp1, ay, lr_t, first);
+    sf1(y.y, g.y, z.y, v.y, a, coef, ckp1, ay, lr_t, first);
+    sf1(y.z, g.z, z.z, v.z, a, coef, ckp1, ay, lr_t, first);
+    sf1(y.w, g.w, z.w, v.w, a, coef, ckp1, ay, lr_t, first);
+    reinterpret_cast<float4*>(a.y)[i] = y;
+    reinterpret_cast<float4*>(a.z)[i] = z;
+    reinterpret_cast<float4*>(a.v)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
+    const int i = (nv << 2) + threadIdx.x;
+    sf1(a.y[i], a.g[i], a.z[i], a.v[i], a, coef, ckp1, ay, lr_t, first);
+  }
+}
+__global__ __launch_bounds__(256) void lerp_kernel(float* y, const float* z, int n, float w) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[i] = torch_lerp(y[i], z[i], w);
 }
 // F.interpolate(mode="linear", align_corners=False) per row (+ optional log(x+1)): dataloading.py:78,93,96
 __global__ void resample_linear_kernel(const float* in, float* out, int N, int W, int L, int log1) {
@@ -944,10 +1017,27 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       AdamArgs a;
       a.p = ptr<float>(op, 0, bases); a.g = ptr<const float>(op, 1, bases); a.m = ptr<float>(op, 2, bases);
       a.v = ptr<float>(op, 3, bases); a.step = ptr<const int64_t>(op, 4, bases); a.norm2 = ptr<const double>(op, 5, bases);
-      a.n = I[0]; a.lr = op.f[0]; a.b1 = op.f[1]; a.b2 = op.f[2]; a.eps = op.f[3]; a.wd = op.f[4]; a.clip = op.f[5];
+      a.n = I[0]; a.lr = op.f[0]; a.b1 = op.f[1]; a.b2 = op.f[2]; a.eps = op.f[3]; a.wd = op.f[4]; a.clip = op.f[5]; a.omb1 = op.f[6]; a.omb2 = op.f[7];
       hipLaunchKernelGGL(adamw_kernel, dim3(min(2048, max(1, blocks_for(a.n >> 2)))), dim3(256), 0, s, a);
       break;
     }
+    case HP_OP_SF_SCHEDULE:
+      hipLaunchKernelGGL(sf_schedule_kernel, dim3(1), dim3(64), 0, s, ptr<const int64_t>(op, 0, bases), ptr<double>(op, 1, bases),
+                         I[0], op.f[0], op.f[1], op.f[2], op.f[3]);
+      break;
+    case HP_OP_ADAMW_SF: {
+      SfArgs a;
+      a.y = ptr<float>(op, 0, bases); a.g = ptr<const float>(op, 1, bases); a.z = ptr<float>(op, 2, bases);
+      a.v = ptr<float>(op, 3, bases); a.step = ptr<const int64_t>(op, 4, bases); a.st = ptr<const double>(op, 5, bases);
+      a.norm2 = ptr<const double>(op, 6, bases);
+      a.n = I[0]; a.b1 = op.f[0]; a.b2 = op.f[1]; a.eps = op.f[2]; a.wd = op.f[3]; a.clip = op.f[4]; a.omb2 = op.f[5];
+      hipLaunchKernelGGL(adamw_sf_kernel, dim3(min(2048, max(1, blocks_for(a.n >> 2)))), dim3(256), 0, s, a);
+      break;
+    }
+    case HP_OP_LERP:
+      hipLaunchKernelGGL(lerp_kernel, dim3(min(2048, max(1, blocks_for(I[0])))), dim3(256), 0, s, ptr<float>(op, 0, bases),
+                         ptr<const float>(op, 1, bases), I[0], op.f[0]);
+      break;
     case HP_OP_RESAMPLE_LINEAR:
       hipLaunchKernelGGL(resample_linear_kernel, dim3(blocks_for((int64_t)I[0] * I[2])), dim3(256), 0, s,
                          ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2], op.flags & 1);

@@ -62,3 +62,45 @@ class EphysDatasetLabeled:
         for i in range(0, len(idx), batch_size):
             j = idx[i: i + batch_size]
             yield self.data.index_select(0, j).unsqueeze(1), self.labels.index_select(0, j)
+
+
+class BalancedBatchSampler:
+    """Class-balanced oversampling index stream — counterpart of hippie/dataloading.py:107-151, used by the
+    supervised stage (scripts/train_model_with_multimodal.py:398, :865).
+
+    Host-side index logic (no device work): classes are keyed in order of first appearance, every class is
+    topped up to the size of the largest one with `random.choice` draws from its own (growing) list — the
+    same calls on Python's global `random` in the same order as the reference, so a seeded run yields the
+    same permutation — and iteration interleaves the classes round-robin.  `len()` = max class size x classes.
+    Pass the result to `EphysDatasetLabeled.batches(batch_size, indices=list(sampler))`."""
+
+    def __init__(self, dataset, labels=None):
+        import random
+        if labels is None:
+            raise Exception("You should pass the tensor of labels to the constructor as second argument")
+        self.labels = labels
+        self.dataset = {}
+        for idx in range(len(dataset)):
+            lab = self._get_label(dataset, idx)
+            self.dataset.setdefault(lab, []).append(idx)
+        self.balanced_max = max((len(v) for v in self.dataset.values()), default=0)
+        for pool in self.dataset.values():
+            while len(pool) < self.balanced_max:
+                pool.append(random.choice(pool))
+        self.keys = list(self.dataset)
+        self.currentkey = 0
+        self.indices = [-1] * len(self.keys)
+
+    def _get_label(self, dataset, idx, labels=None):
+        return self.labels[idx].item()
+
+    def __iter__(self):
+        # the cursor state is kept on the object, as in the reference (:130-135)
+        while self.keys and self.indices[self.currentkey] < self.balanced_max - 1:
+            self.indices[self.currentkey] += 1
+            yield self.dataset[self.keys[self.currentkey]][self.indices[self.currentkey]]
+            self.currentkey = (self.currentkey + 1) % len(self.keys)
+        self.indices = [-1] * len(self.keys)
+
+    def __len__(self):
+        return self.balanced_max * len(self.keys)

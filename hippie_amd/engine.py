@@ -66,7 +66,7 @@ class Engine:
 
     def io(self, name):
         ref, shape, dt = self.plan.io[name]
-        tdt = torch.float32 if dt == "f4" else torch.int64
+        tdt = {"f4": torch.float32, "i8": torch.int64, "f8": torch.float64}[dt]
         nb = int(np.prod(shape)) * (4 if dt == "f4" else 8)
         arena = self.ws if ref.space == P.WS else self.bufs.view(torch.uint8)
         return arena[ref.offset: ref.offset + nb].view(tdt).view(*shape)
@@ -182,6 +182,13 @@ class Engine:
 
     def optimizer_step(self, use_graph=False):
         self.run("opt", use_graph)
+
+    def optimizer_swap(self, to_eval: bool, use_graph=False):
+        """AdamWScheduleFree.eval() / .train() (hippie/optimizers.py:82-103): move the parameter arena between
+        the training point y and the averaged point x.  The caller tracks which mode it is in."""
+        if self.train_cfg.optimizer != "schedulefree":
+            raise HipEngineError("optimizer_swap needs TrainCfg(optimizer='schedulefree')")
+        self.run("sf_eval" if to_eval else "sf_train", use_graph)
 
     def train_step(self, use_graph=False):
         """forward(train) + backward + AdamW on the staged inputs; returns the scalars tensor (device)."""

@@ -15,6 +15,7 @@ optimiser arenas.  All arithmetic runs in libhippie_hip.so; there is no CPU fall
 from __future__ import annotations
 
 from collections import OrderedDict
+from dataclasses import replace
 
 import torch
 
@@ -90,6 +91,11 @@ class _Net:
 
     def load_state_dict(self, sd, strict=True, prefix=""):
         return self._any_engine().load_state_dict(sd, strict=strict, prefix=prefix)
+
+    def parameters(self):
+        """Handle for optimisers (hippie_amd.optimizers.AdamWScheduleFree(model.parameters(), ...))."""
+        from .optimizers import ParamHandle
+        return ParamHandle(self)
 
     def parameters_numel(self):
         return sum(i.numel for i in self._any_engine().plan.params.values())
@@ -246,6 +252,12 @@ class _TrainModule:
         self.optimizer = _Optimizer(self)
 
     def _apply_cfg(self):
+        opt = getattr(self, "optimizer", None)
+        if opt is not None and not isinstance(opt, _Optimizer):
+            # a user-installed optimiser (AdamWScheduleFree) owns lr / weight decay; keep its settings
+            self.model.configure_training(replace(self.model._train_cfg, beta=self.beta, clip=self.gradient_clip_val or 0.0,
+                                                  w1=self.mod1_weight, w2=self.mod2_weight))
+            return
         self.model.configure_training(planner.TrainCfg(lr=self.lr, weight_decay=self.weight_decay, beta=self.beta,
                                                        clip=self.gradient_clip_val or 0.0, w1=self.mod1_weight, w2=self.mod2_weight))
 
@@ -262,6 +274,10 @@ class _TrainModule:
     def train(self, mode=True):
         self.training = mode
         self.model.train(mode)
+        # a schedule-free optimiser evaluates at the averaged point x and trains at y (hippie/optimizers.py:82-103)
+        swap = getattr(getattr(self, "optimizer", None), "train" if mode else "eval", None)
+        if swap is not None:
+            swap()
         return self
 
     def eval(self):

@@ -54,6 +54,10 @@ class TrainCfg:
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
+    optimizer: str = "adamw"            # "adamw" (model.py:93) | "schedulefree" (hippie/optimizers.py:18-209)
+    warmup_steps: int = 0               # schedule-free only
+    sf_r: float = 0.0
+    sf_weight_lr_power: float = 2.0
 
 
 @dataclass
@@ -593,6 +597,12 @@ class Lowering:
         pl._boff = step_off + 4
         self.step_ref = Ref(P.BUF, step_off * 4)
         pl.io["adam_step"] = (self.step_ref, (1,), "i8")
+        # schedule-free AdamW scalars {lr_max, weight_sum, lr_t, ckp1} (double[4]); always present so that
+        # the BUF layout does not depend on the optimiser choice
+        sf_off = _round_up(pl._boff, 4)
+        pl._boff = sf_off + 8
+        self.sf_ref = Ref(P.BUF, sf_off * 4)
+        pl.io["sf_state"] = (self.sf_ref, (4,), "f8")
         lens = [cfg.output_size] if not multi else [cfg.output_size, cfg.output_size2]
         xs = [pl.f32(B * L, "x" if i == 0 else "x2", (B, 1, L)) for i, L in enumerate(lens)]
         self.src = pl.ws(8 * B, "src", (B,), "i8")
@@ -721,11 +731,28 @@ class Lowering:
             n = pl.n_active
             if self.train.clip > 0:
                 self.o.add(P.GRADNORM, 0, i=[n], buf=[Ref(P.GRAD, 0), norm2], note="clip_grad_norm: total norm")
-            self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="adam step += 1")
             t = self.train
-            self.o.add(P.ADAMW, 0, i=[n], f=[t.lr, t.beta1, t.beta2, t.adam_eps, t.weight_decay, t.clip],
-                       buf=[Ref(P.PARAM, 0), Ref(P.GRAD, 0), Ref(P.ADAM_M, 0), Ref(P.ADAM_V, 0), self.step_ref, norm2], note="AdamW")
+            arenas = [Ref(P.PARAM, 0), Ref(P.GRAD, 0), Ref(P.ADAM_M, 0), Ref(P.ADAM_V, 0)]
+            if t.optimizer == "adamw":
+                self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="adam step += 1")
+                self.o.add(P.ADAMW, 0, i=[n], f=[t.lr, t.beta1, t.beta2, t.adam_eps, t.weight_decay, t.clip, 1.0 - t.beta1, 1.0 - t.beta2],
+                           buf=arenas + [self.step_ref, norm2], note="AdamW")
+            elif t.optimizer == "schedulefree":
+                # z lives in the ADAM_M arena, exp_avg_sq in ADAM_V; k (= STEP) is incremented after the update
+                self.o.add(P.SF_SCHEDULE, 0, i=[t.warmup_steps], f=[t.lr, 1.0 - t.beta2, t.sf_r, t.sf_weight_lr_power],
+                           buf=[self.step_ref, self.sf_ref], note="schedule-free: lr_t, ckp1")
+                self.o.add(P.ADAMW_SF, 0, i=[n], f=[t.beta1, t.beta2, t.adam_eps, t.weight_decay, t.clip, 1.0 - t.beta2],
+                           buf=arenas + [self.step_ref, self.sf_ref, norm2], note="AdamWScheduleFree")
+                self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="k += 1")
+            else:
+                raise ValueError(f"unknown optimizer {t.optimizer!r}")
             self.o.end()
+            if t.optimizer == "schedulefree":
+                # AdamWScheduleFree.eval() / .train(): y <-> x swaps (hippie/optimizers.py:82-103)
+                for seg, w in (("sf_eval", 1.0 - 1.0 / t.beta1), ("sf_train", 1.0 - t.beta1)):
+                    self.o.begin(seg)
+                    self.o.add(P.LERP, 0, i=[n], f=[w], buf=[Ref(P.PARAM, 0), Ref(P.ADAM_M, 0)], note=seg)
+                    self.o.end()
         # finalize: statistics region size into both ZERO ops; slab at the end of the workspace
         used = _round_up(pl.stats_bytes, 256)
         for key in ("train_zero", "eval_zero"):

@@ -25,7 +25,7 @@ assert OP_DTYPE.itemsize == 280
 (CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
  POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
  REPARAM_KL_BWD, MSE_FWD_BWD, TAIL_FWD, TAIL_BWD_X, TAIL_BWD_W, LOSS_FINALIZE, GRADNORM, ADAMW, STEP_INC,
- ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR) = range(1, 32)
+ ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR, SF_SCHEDULE, ADAMW_SF, LERP) = range(1, 35)
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
@@ -108,6 +108,7 @@ class OpList:
 
 # ---- shared library ---------------------------------------------------------------
 _LIB = None
+ABI_VERSION = 2          # include/hippie_hip.h: HP_ABI_VERSION
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")
 
 EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",
@@ -146,7 +147,7 @@ def load_library():
     lib.hp_program_replay.argtypes = [vp, ctypes.c_int, vp]
     lib.hp_program_profile.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.hp_run_op.argtypes = [vp, ctypes.POINTER(vp), vp]
-    if lib.hp_abi_version() != 1:
+    if lib.hp_abi_version() != ABI_VERSION:
         raise HipEngineError("libhippie_hip.so ABI version mismatch")
     _LIB = lib
     return lib

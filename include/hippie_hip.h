@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 1
+#define HP_ABI_VERSION 2
 
 enum {
   HP_SPACE_WS = 0, HP_SPACE_PARAM = 1, HP_SPACE_GRAD = 2, HP_SPACE_BUF = 3,
@@ -174,7 +174,8 @@ enum {
   HP_OP_GRADNORM = 25,
   /* torch.optim.AdamW step (model.py:93) with optional clip_grad_norm_ scale folded in.
    * step count t is read from STEP (int64, incremented by HP_OP_STEP_INC).
-   * i[0]=n  f: 0 lr 1 beta1 2 beta2 3 eps 4 weight_decay 5 clip(0 = off)
+   * i[0]=n  f: 0 lr 1 beta1 2 beta2 3 eps 4 weight_decay 5 clip(0 = off) 6 (1-beta1) 7 (1-beta2)
+   * (the complements are formed in fp64 on the host, as torch does, so 1-beta^t stays accurate in fp32 transport)
    * buf: 0 P 1 G 2 M 3 V 4 STEP(int64[1]) 5 NORM2(double[1]) */
   HP_OP_ADAMW = 26,
   /* STEP[0] += 1.  buf: 0 STEP */
@@ -196,6 +197,24 @@ enum {
    * x1 = min(x0 + 1, W - 1), w = src - x0.  i[0]=N i[1]=W i[2]=L  flags: 1 = log(x+1) first
    * buf: 0 IN[N][W] 1 OUT[N][L] */
   HP_OP_RESAMPLE_LINEAR = 31,
+  /* Schedule-Free AdamW, per-step scalars (hippie/optimizers.py:118-138), one thread, all in fp64 as the
+   * reference's Python floats:  k = STEP[0];  sched = k < warmup ? (k+1)/warmup : 1;
+   * lr_t = lr * sched * sqrt(1 - beta2^(k+1));  lr_max = max(lr_t, lr_max);
+   * weight = (k+1)^r * lr_max^power;  weight_sum += weight;  ckp1 = weight_sum != 0 ? weight/weight_sum : 0.
+   * STATE = {lr_max, weight_sum, lr_t, ckp1} (lr_max, weight_sum persist; a zero-initialised lr_max is
+   * equivalent to the reference's -1 because lr_t >= 0).
+   * i[0]=warmup_steps  f: 0 lr 1 (1-beta2) 2 r 3 weight_lr_power.  buf: 0 STEP(int64[1]) 1 STATE(double[4]) */
+  HP_OP_SF_SCHEDULE = 32,
+  /* Schedule-Free AdamW, element update (hippie/optimizers.py:145-207), with the clip_grad_norm_ scale folded
+   * in as for HP_OP_ADAMW.  On the first step (STEP[0] == 0) z := y first (:147).
+   *   v = beta2*v + (1-beta2)*g^2;  gn = g / (sqrt(v) + eps);  if wd: gn += wd*y;
+   *   y = lerp(y, z, ckp1);  y += gn * lr_t*(beta1*(1-ckp1) - 1);  z -= lr_t*gn.
+   * i[0]=n  f: 0 beta1 1 beta2 2 eps 3 weight_decay 4 clip(0 = off) 5 (1-beta2)
+   * buf: 0 Y(=P) 1 G 2 Z 3 V 4 STEP(int64[1]) 5 STATE(double[4]) 6 NORM2(double[1]) */
+  HP_OP_ADAMW_SF = 33,
+  /* y = torch.lerp(y, z, w): AdamWScheduleFree.eval() (w = 1 - 1/beta1) and .train() (w = 1 - beta1)
+   * (hippie/optimizers.py:82-103).  i[0]=n f[0]=w.  buf: 0 Y 1 Z */
+  HP_OP_LERP = 34,
   HP_OP__COUNT
 };
 

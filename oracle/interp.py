@@ -56,6 +56,12 @@ def _src_rows(M, Lout, Lin, Pb, a, sh, even, off):
     return src, ok
 
 
+def _torch_lerp(a, b, w):
+    """torch.lerp: a + w*(b-a) for |w| < 0.5, else b - (b-a)*(1-w)."""
+    d = b - a
+    return (a + w * d if abs(float(w)) < 0.5 else b - d * (np.float32(1) - w)).astype(np.float32)
+
+
 def _lrelu(x, s):
     return np.where(x > 0, x, x * np.float32(s)).astype(np.float32)
 
@@ -336,19 +342,19 @@ def run(ops, A: Arenas, first=0, count=None):
             A.f64(b[1], 1)[0] += float((A.f32(b[0], n).astype(np.float64) ** 2).sum())
         elif op == 26:   # ADAMW
             n = int(i[0])
-            lr, b1, b2, eps, wd, clip = [np.float32(v) for v in f[:6]]
+            lr, b1, b2, eps, wd, clip, omb1, omb2 = [np.float32(v) for v in f[:8]]
             p, g, m, v = A.f32(b[0], n), A.f32(b[1], n), A.f32(b[2], n), A.f32(b[3], n)
             t = float(A.i64(b[4], 1)[0])
-            bc1 = 1.0 - float(b1) ** t
-            bc2 = 1.0 - float(b2) ** t
+            bc1 = 1.0 - (1.0 - float(omb1)) ** t
+            bc2 = 1.0 - (1.0 - float(omb2)) ** t
             coef = np.float32(1)
             if clip > 0:
                 c = clip / (np.float32(np.sqrt(A.f64(b[5], 1)[0])) + np.float32(1e-6))
                 coef = min(c, np.float32(1))
             gg = (g * coef).astype(np.float32)
             p[:] = p * (np.float32(1) - lr * wd)
-            m[:] = m + (np.float32(1) - b1) * (gg - m)
-            v[:] = v * b2 + (np.float32(1) - b2) * gg * gg
+            m[:] = m + omb1 * (gg - m)
+            v[:] = v * b2 + omb2 * gg * gg
             denom = np.sqrt(v) / np.float32(np.sqrt(bc2)) + eps
             p[:] = p - np.float32(float(lr) / bc1) * (m / denom)
         elif op == 27:   # STEP_INC
@@ -356,6 +362,41 @@ def run(ops, A: Arenas, first=0, count=None):
         elif op == 28:   # ZERO
             nb = int(np.uint32(i[0])) + (int(np.uint32(i[1])) << 32)
             A.view(b[0], np.uint8, nb)[:] = 0
+        elif op == 32:   # SF_SCHEDULE (hippie/optimizers.py:118-138)
+            k = float(A.i64(b[0], 1)[0])
+            st = A.f64(b[1], 4)
+            warm = int(i[0])
+            lr, omb2, r, power = [float(np.float32(v)) for v in f[:4]]
+            sched = (k + 1) / warm if k < warm else 1.0
+            lr_t = lr * sched * np.sqrt(1.0 - (1.0 - omb2) ** (k + 1))
+            st[0] = max(lr_t, st[0])
+            weight = (k + 1) ** r * st[0] ** power
+            st[1] += weight
+            st[2] = lr_t
+            st[3] = weight / st[1] if st[1] != 0 else 0.0
+        elif op == 33:   # ADAMW_SF (hippie/optimizers.py:145-207)
+            n = int(i[0])
+            b1, b2, eps, wd, clip, omb2 = [np.float32(v) for v in f[:6]]
+            y, g, z, v = A.f32(b[0], n), A.f32(b[1], n), A.f32(b[2], n), A.f32(b[3], n)
+            st = A.f64(b[5], 4)
+            if int(A.i64(b[4], 1)[0]) == 0:
+                z[:] = y
+            coef = np.float32(1)
+            if clip > 0:
+                c = clip / (np.float32(np.sqrt(A.f64(b[6], 1)[0])) + np.float32(1e-6))
+                coef = min(c, np.float32(1))
+            gg = (g * coef).astype(np.float32)
+            v[:] = v * b2 + omb2 * gg * gg
+            gn = gg / (np.sqrt(v) + eps)
+            if wd != 0:
+                gn = gn + wd * y
+            y[:] = _torch_lerp(y, z, np.float32(st[3]))
+            y[:] = y + np.float32(st[2] * (float(b1) * (1.0 - st[3]) - 1.0)) * gn
+            z[:] = z - np.float32(st[2]) * gn
+        elif op == 34:   # LERP
+            n = int(i[0])
+            y = A.f32(b[0], n)
+            y[:] = _torch_lerp(y, A.f32(b[1], n), np.float32(f[0]))
         elif op == 31:   # RESAMPLE_LINEAR
             from oracle.preproc import resample_linear
             N, W, L = int(i[0]), int(i[1]), int(i[2])

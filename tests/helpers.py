@@ -7,6 +7,9 @@ from oracle import cvae_oracle as O
 from oracle import interp
 
 
+_NP_DT = {"f4": np.float32, "i8": np.int64, "f8": np.float64}
+
+
 def to_arena_layout(info, value):
     v = np.asarray(value, dtype=np.float32)
     if info.layout == "tnc":
@@ -47,14 +50,14 @@ def read_bufs(plan, A):
 
 def set_io(plan, A, name, value):
     ref, shape, dt = plan.io[name]
-    arr = np.ascontiguousarray(np.asarray(value)).astype(np.float32 if dt == "f4" else np.int64).reshape(-1)
+    arr = np.ascontiguousarray(np.asarray(value)).astype(_NP_DT[dt]).reshape(-1)
     A.view(ref.encode(), arr.dtype, arr.size)[:] = arr
 
 
 def get_io(plan, A, name):
     ref, shape, dt = plan.io[name]
     n = int(np.prod(shape))
-    return A.view(ref.encode(), np.float32 if dt == "f4" else np.int64, n).reshape(shape).copy()
+    return A.view(ref.encode(), _NP_DT[dt], n).reshape(shape).copy()
 
 
 ZERO_GRAD_RE = (r"(encoder(_mod\d)?\.linear\.bias|encoder_fc\.[03]\.bias|fusion_encoder\.0\.bias|"

@@ -374,7 +374,7 @@ def test_adamw_gradnorm_steps(n, clip):
         ol.add(P.ZERO, 0, [8, 0], (), [norm2])
         ol.add(P.GRADNORM, 0, [n], (), [g, norm2])
         ol.add(P.STEP_INC, 0, (), (), [step])
-        ol.add(P.ADAMW, 0, [n], [1e-3, 0.9, 0.999, 1e-8, 0.01, clip], [p, g, m, v, step, norm2])
+        ol.add(P.ADAMW, 0, [n], [1e-3, 0.9, 0.999, 1e-8, 0.01, clip, 1 - 0.9, 1 - 0.999], [p, g, m, v, step, norm2])
     gpu, cpu = run_both(img, ol.array())
     check(gpu, cpu, norm2, 1, np.float64, rel=1e-9, what="norm2")
     for ref, nm in ((p, "p"), (m, "m"), (v, "v")):
