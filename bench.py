@@ -23,6 +23,11 @@ import os
 import sys
 import time
 
+# The step keeps three HIP streams busy (wave model, time model, RCCL).  ROCm multiplexes streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4, shared with the null and copy streams); two streams on one queue
+# serialise.  Measured with a 1-rank RCCL all-reduce in the step: 61.0k samples/s at 4 queues, 84.0k at 8.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -62,8 +67,8 @@ class Pair:
     (the GPU overlaps the two models' kernels).  --pair: ONE zipped program (hippie_amd.pair.PairEngine:
     every heavy op of the two models in one launch) on one stream."""
 
-    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100)):
-        self.device, self.world, self.paired = device, world, paired
+    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False):
+        self.device, self.world, self.paired, self.overlap = device, world, paired, overlap
         cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
         tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0), planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0)]
         if paired:
@@ -75,9 +80,11 @@ class Pair:
             self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
         self.groups = None
-        if world > 1:
+        if world > 1 or os.environ.get("HIPPIE_FORCE_DIST"):
             import torch.distributed as dist
-            self.groups = [dist.new_group(list(range(world))) for _ in self.eng]
+            # one communicator: the two models' all-reduces are issued in the same order on every rank and
+            # serialise on its stream (the wave model's backward finishes first anyway)
+            self.groups = [dist.group.WORLD for _ in self.eng]
         self.init_params()
 
     def init_params(self):
@@ -123,9 +130,10 @@ class Pair:
                 e.io("src").copy_(data[2].index_select(0, idx), non_blocking=True)
                 e.io("eps").normal_()
                 e.forward(True, use_graph)
-                e.backward(use_graph)
                 if self.groups is not None:
-                    parallel.allreduce_mean_(e.grads, self.groups[k])
+                    parallel.backward_allreduce(e, self.groups[k], use_graph, self.overlap)
+                else:
+                    e.backward(use_graph, overlap=self.overlap)
                 e.optimizer_step(use_graph)
         for s in self.streams:
             cur.wait_stream(s)
@@ -257,6 +265,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pair", action="store_true", help="one zipped wave+time program (paired launches) instead of two engines on two streams")
+    ap.add_argument("--overlap", action="store_true", help="decoder-side wgrad + first gradient bucket on a side stream (measured slower on ROCm 7: DESIGN.md 5.3)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     # non-default shapes (BASELINE configs[2]: --batch 4096 --z-dim 32 --wave-len 256 --time-len 32); the headline
     # metric is always quoted on the defaults
@@ -277,7 +286,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = bool(os.environ.get("HIPPIE_FORCE_DIST"))          # experiment: 1-rank RCCL, all-reduce still issued
+    if force_dist:
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("HIPPIE_DIST_BACKEND", "nccl")      # nccl = RCCL on ROCm; gloo only for single-GPU rehearsals
@@ -287,7 +301,7 @@ def main():
             dist.init_process_group(backend)
 
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
-    pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len))
+    pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len), overlap=args.overlap)
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -341,7 +355,7 @@ def main():
                                     "fp32 arithmetic on f32 MFMA (parity path; bf16 not used)")
                        if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
                        f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_from_pmc(),
@@ -349,7 +363,7 @@ def main():
                          "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
                          "algorithmic_gflop_per_step": conv_flop / 1e9},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

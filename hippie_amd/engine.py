@@ -27,6 +27,7 @@ class Engine:
         self.cfg, self.B, self.with_class = cfg, batch, with_class
         self.train_cfg = train or planner.TrainCfg()
         self._graphs = {}
+        self._side = None
         if _view is not None:
             # a view over one model's slice of joint arenas owned by a PairEngine (which runs the program)
             self.plan, (self.ws, self.params, self.grads, self.bufs, self.m, self.v) = _view
@@ -177,8 +178,34 @@ class Engine:
             outs.append(self.io("rec2_" + mode))
         return tuple(outs)
 
-    def backward(self, use_graph=False):
-        self.run("bwd", use_graph)
+    def backward(self, use_graph=False, overlap=False, after_first_half=None):
+        """Backward pass (consumes the forward's gradient seeds in place: one backward per forward).
+        overlap=True runs the decoder-side weight-gradient GEMMs ("wg_a") on a second HIP
+        stream underneath the encoder-side chain ("bwd_b"): the chain is latency-bound (one small launch after
+        another), the grouped GEMM fills the CUs it leaves idle.  `after_first_half(side_stream)` is called
+        with the side stream current once "wg_a" is enqueued (data parallel: all-reduce that gradient bucket
+        there, see Plan.grad_bucket_a); the main stream joins the side stream before this returns."""
+        if not overlap:
+            self.run("bwd", use_graph)
+            if after_first_half is not None:
+                after_first_half(torch.cuda.current_stream(self.device))
+            return
+        if self._side is None:
+            # lowest priority: the grouped GEMM must only fill CUs the latency-bound chain leaves idle
+            self._side = torch.cuda.Stream(device=self.device)
+            self._ev = (torch.cuda.Event(), torch.cuda.Event())
+        cur = torch.cuda.current_stream(self.device)
+        self.run("bwd_a", use_graph)
+        self._ev[0].record(cur)
+        self._side.wait_event(self._ev[0])
+        with torch.cuda.stream(self._side):
+            self.run("wg_a", use_graph)
+            if after_first_half is not None:
+                after_first_half(self._side)
+            self._ev[1].record(self._side)
+        self.run("bwd_b", use_graph)
+        self.run("wg_b", use_graph)
+        cur.wait_event(self._ev[1])
 
     def optimizer_step(self, use_graph=False):
         self.run("opt", use_graph)

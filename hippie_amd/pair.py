@@ -57,6 +57,8 @@ def zip_programs(plan_a, plan_b):
     out, notes, segments = [], [], {}
     new_a, new_b = {}, {}
     for seg, (fa, ca) in plan_a.ops.segments.items():
+        if seg == "bwd":
+            continue                      # alias of bwd_a + wg_a + bwd_b + wg_b, rebuilt below
         fb, cb = plan_b.ops.segments[seg]
         start = len(out)
         same = ca == cb and all(int(ops_a[fa + k]["op"]) == int(ops_b[fb + k]["op"]) for k in range(ca))
@@ -104,6 +106,8 @@ def zip_programs(plan_a, plan_b):
                 out += [ra, rb]
                 notes += ["A:" + na, "B:" + nb]
         segments[seg] = (start, len(out) - start)
+    first = segments["bwd_a"][0]
+    segments["bwd"] = (first, segments["wg_b"][0] + segments["wg_b"][1] - first)
     return np.array(out, dtype=P.OP_DTYPE), segments, notes, bases_b
 
 

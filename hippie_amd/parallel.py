@@ -5,6 +5,8 @@ The reference has no distributed code of its own; these are the semantics Lightn
 would give its scripts (scripts/train_model_with_multimodal.py:200-207)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -32,7 +34,7 @@ def allreduce_mean_(flat_grads, group=None, buckets=1):
     gloo on CPU).  `buckets` > 1 splits the arena so that the collective of one bucket can overlap
     whatever is enqueued next on other streams."""
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not os.environ.get("HIPPIE_FORCE_DIST"):     # (the env knob keeps the 1-rank collective for measurements)
         return flat_grads
     n = flat_grads.numel()
     step = -(-n // buckets)
@@ -53,17 +55,34 @@ def broadcast_(tensors, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
-class DataParallelEngine:
-    """Wraps an Engine: train_step = forward + backward + all-reduce(mean) + AdamW."""
+def backward_allreduce(engine, group=None, use_graph=True, overlap=False):
+    """Backward + gradient mean over ranks.  Default: the whole active arena in one collective after the
+    backward pass.  overlap=True uses two buckets: the decoder-side one (Plan.grad_bucket_a, about half of the
+    32 MB arena) is final after the first half of the backward pass and is all-reduced on the engine's side
+    stream while the encoder-side chain still runs; the rest follows on the main stream (same order on every
+    rank).  On ROCm 7 the extra stream costs more than the overlap gains at N=1, hence opt-in."""
+    e = engine
+    if not overlap:
+        e.backward(use_graph)
+        allreduce_mean_(e.grads[: e.plan.n_active], group)
+        return
+    lo, hi = e.plan.grad_bucket_a
+    e.backward(use_graph, overlap=overlap, after_first_half=lambda _s: allreduce_mean_(e.grads[lo:hi], group))
+    allreduce_mean_(e.grads[:lo], group)
+    if e.plan.n_active > hi:
+        allreduce_mean_(e.grads[hi: e.plan.n_active], group)       # class_embedding rows
 
-    def __init__(self, engine, group=None, buckets=1):
-        self.engine, self.group, self.buckets = engine, group, buckets
+
+class DataParallelEngine:
+    """Wraps an Engine: train_step = forward + backward (+ overlapped all-reduce(mean)) + AdamW."""
+
+    def __init__(self, engine, group=None, overlap=False):
+        self.engine, self.group, self.overlap = engine, group, overlap
         broadcast_([engine.params, engine.bufs, engine.m, engine.v], 0, group)
 
     def train_step(self, use_graph=True):
         e = self.engine
         e.forward(True, use_graph)
-        e.backward(use_graph)
-        allreduce_mean_(e.grads[: e.plan.n_active], self.group, self.buckets)
+        backward_allreduce(e, self.group, use_graph, self.overlap)
         e.optimizer_step(use_graph)
         return e.io("scalars")

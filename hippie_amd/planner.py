@@ -557,6 +557,20 @@ class Lowering:
         if self.with_class:
             self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0 + H], buf=[dcat, self.cls, self.cemb.gref], note="class_embedding grad")
 
+    def flush_wgrads(self, seg):
+        """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, in their own segment."""
+        self.o.begin(seg)
+        for ntaps in (3, 1):
+            mem = [w_ for w_ in self.pending_wgrads if len(w_[0].taps) == ntaps]
+            if not mem:
+                continue
+            first = len(self.o.recs)
+            for (tm, nsplit, rps, dy, x, w, note) in mem:
+                self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
+            self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
+        self.pending_wgrads = []
+        self.o.end()
+
     # ---- whole model ---------------------------------------------------------------
     def build(self):
         cfg, pl, B, z, H = self.cfg, self.pl, self.B, self.cfg.z_dim, self.cfg.class_hidden_dim
@@ -587,6 +601,10 @@ class Lowering:
             decs.append(self.declare_decoder(dpre, osz))
         self.cemb = pl.param("class_embedding.weight", (cfg.num_classes, H))    # LAST: skipped by AdamW without class labels
         pl.n_active = pl.n_param_floats if self.with_class else _round_up(self.cemb.offset, 4)
+        # gradient range that is final once "bwd_a" + "wg_a" have run (decoder heads + decoder); the embeddings
+        # and everything in front of it are finished by "bwd_b" + "wg_b"
+        first_dec = names[0][0] + ".0.weight"
+        pl.grad_bucket_a = (pl.params[first_dec].offset, self.cemb.offset)
         # the floats between n_active and cemb.offset (alignment gap) are zero padding
 
         # ---------------- workspace: persistent + I/O ----------------
@@ -683,7 +701,10 @@ class Lowering:
             segs["train_zero"] = zero_idx
 
             # ---------------- backward ----------------
-            self.o.begin("bwd")
+            # Two halves, each followed by its deferred weight-gradient GEMMs, so that a caller may run "wg_a"
+            # (decoder side) on a second stream underneath "bwd_b" (encoder side): bwd_a, wg_a, bwd_b, wg_b.
+            # "bwd" names the whole range; running it serially is equivalent.
+            self.o.begin("bwd_a")
             nb = pl.n_param_floats * 4
             self.o.add(P.ZERO, 0, i=[nb & 0xFFFFFFFF, nb >> 32], buf=[Ref(P.GRAD, 0)], note="zero gradients")
             dc1 = pl.f32(B * ncat1)
@@ -694,6 +715,9 @@ class Lowering:
                 du3 = pl.f32(B * 2 * z)
                 self.linear_bwd(B, fc["f2"], du4, 2 * z, hd["u3"], 2 * z, du3, 2 * z, mask=hd["u3"], ldmask=2 * z, note="decoder_fc.2")
                 self.linear_bwd(B, fc["f0"], du3, 2 * z, c1, ncat1, dc1, ncat1, accumulate=(k > 0), note="decoder_fc.0")
+            self.o.end()
+            self.flush_wgrads("wg_a")
+            self.o.begin("bwd_b")
             self.emb_bwd(dc1, ncat1, z)
             dmulv = pl.f32(B * 2 * z)
             self.o.add(P.REPARAM_KL_BWD, 0, i=[B, z, ncat1], f=[self.train.beta], buf=[mulv, eps, dc1, dmulv], note="reparameterize + KL bwd")
@@ -715,16 +739,10 @@ class Lowering:
                 dh = dc0 + 4 * (2 * z * k)      # column window of dc0, leading dimension ncat
                 self.linear_bwd(B, lin, dh, ncat, e["pooled"], 512, dpooled, 512, note=e["prefix"] + "linear")
                 self.encoder_bwd(e, dpooled)
-            for ntaps in (3, 1):
-                mem = [w_ for w_ in self.pending_wgrads if len(w_[0].taps) == ntaps]
-                if not mem:
-                    continue
-                first = len(self.o.recs)
-                for (tm, nsplit, rps, dy, x, w, note) in mem:
-                    self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
-                self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
-            self.pending_wgrads = []
             self.o.end()
+            self.flush_wgrads("wg_b")
+            first_bwd = self.o.segments["bwd_a"][0]
+            self.o.segments["bwd"] = (first_bwd, len(self.o.recs) - first_bwd)      # the four sub-segments in program order
 
             # ---------------- optimiser ----------------
             self.o.begin("opt")

@@ -33,7 +33,7 @@ def _worker(rank, world, port, q):
     eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=1.0))
     om = O.OracleModel("unimodal", z, L, salt=rank)          # different init per rank: broadcast must fix it
     eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
-    dp = parallel.DataParallelEngine(eng, buckets=2)
+    dp = parallel.DataParallelEngine(eng, overlap=True)
     n = 64
     x, src, cls, eps = O.synth_inputs(n, L, z, salt=5)
     ok_grad = True
@@ -48,6 +48,13 @@ def _worker(rank, world, port, q):
         parallel.allreduce_mean_(eng.grads[: eng.plan.n_active], None, 2)
         want = (gathered[0] + gathered[1]) / 2
         ok_grad &= bool(torch.allclose(eng.grads[: eng.plan.n_active], want[: eng.plan.n_active], rtol=1e-6, atol=1e-8))
+        # the overlapped, two-bucket path (side stream + all-reduce under the encoder-side chain) gives the same
+        # mean up to the summation order of the fp32 atomics in the weight-gradient GEMMs
+        eng.forward(True, True)              # the backward pass consumes its inputs in place: stage them again
+        parallel.backward_allreduce(eng, None, True, overlap=True)
+        torch.cuda.synchronize()
+        got, ref = eng.grads[: eng.plan.n_active], want[: eng.plan.n_active]
+        ok_grad &= bool((got - ref).abs().max() <= 2e-5 * ref.abs().max())
         eng.optimizer_step(True)
     loss = dp.train_step(use_graph=True).clone()
     torch.cuda.synchronize()

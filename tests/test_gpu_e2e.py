@@ -305,7 +305,9 @@ def test_pair_engine_equals_two_engines():
         assert pe.models[k].adam_step == 3
         a, b = pe.models[k].state_dict(), singles[k].state_dict()
         for kk in a:
-            if a[kk].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, kk):
+            if "running_" in kk:
+                np.testing.assert_allclose(n(a[kk]), n(b[kk]), rtol=1e-4, atol=1e-4 * float(b[kk].abs().max()), err_msg=kk)   # follow the +-lr parameter noise
+            elif a[kk].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, kk):
                 H.assert_adam_close(n(a[kk]), n(b[kk]), 1e-6, kk, steps=3, frac=5e-2)
         ga, gb = pe.models[k].grad_dict(), singles[k].grad_dict()
         for kk in ga:
@@ -329,3 +331,24 @@ def test_ragged_batches_and_lengths(B, L):
     sd = eng.state_dict()
     assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
     assert eng.adam_step == 1
+
+
+def test_overlapped_backward_equals_serial():
+    """Engine.backward(overlap=True): decoder-side wgrad on a side stream under the encoder-side chain."""
+    eng, oms, batch, batch64, eps = build("unimodal", 10, 100, 64, True, 1.0, 1.0, 1e-3, 3)
+    for use_graph in (False, True):
+        eng.forward(True, use_graph)
+        eng.backward(use_graph)
+        torch.cuda.synchronize()
+        want = eng.grads.clone()
+        eng.forward(True, use_graph)          # backward consumes gradient buffers in place: stage a fresh forward
+        eng.backward(use_graph, overlap=True)
+        torch.cuda.synchronize()
+        scale = want.abs().max()
+        assert (eng.grads - want).abs().max() <= 2e-5 * scale      # fp32 atomics order only
+        lo, hi = eng.plan.grad_bucket_a
+        seen = []
+        eng.forward(True, use_graph)
+        eng.backward(use_graph, overlap=True, after_first_half=lambda s: seen.append(eng.grads[lo:hi].clone()))
+        torch.cuda.synchronize()
+        assert (seen[0] - want[lo:hi]).abs().max() <= 2e-5 * scale, "bucket A not final after the first half"
