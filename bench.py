@@ -70,7 +70,8 @@ class Pair:
     def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False):
         self.device, self.world, self.paired, self.overlap = device, world, paired, overlap
         cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
-        tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0), planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0)]
+        tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, split_backward=overlap),
+               planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, split_backward=overlap)]
         if paired:
             from hippie_amd.pair import PairEngine
             self.pe = PairEngine(cfgs[0], cfgs[1], BATCH, tcs[0], tcs[1], device=device)

@@ -37,11 +37,31 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
 // sum of one entry of a replicated statistics slot double[HP_STAT_REPL][2][C]
-__device__ __forceinline__ double stat_sum(const double* st, int C, int which, int c) {
-  double s = 0.0;
+// Both entries (which = 0, 1) of channel c summed over the replicas.  All 2*HP_STAT_REPL loads are issued
+// before anything consumes them (sched_barrier: otherwise the scheduler interleaves the adds and the prologue
+// of every BatchNorm kernel becomes a chain of dependent L2 round trips, ~5 us), then two pairwise trees.
+__device__ __forceinline__ void stat_sum2(const double* st, int C, int c, double& s0, double& s1) {
+  const double* p = st + c;
+  const size_t stride = (size_t)2 * C;
+  double a[HP_STAT_REPL], b[HP_STAT_REPL];
 #pragma unroll
-  for (int r = 0; r < HP_STAT_REPL; ++r) s += st[(size_t)r * 2 * C + which * C + c];
-  return s;
+  for (int r = 0; r < HP_STAT_REPL; ++r) {
+    a[r] = p[r * stride];
+    b[r] = p[r * stride + C];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int w = HP_STAT_REPL / 2; w > 0; w >>= 1) {
+#pragma unroll
+    for (int r = 0; r < w; ++r) { a[r] += a[r + w]; b[r] += b[r + w]; }
+  }
+  s0 = a[0];
+  s1 = b[0];
+}
+__device__ __forceinline__ double stat_sum(const double* st, int C, int which, int c) {
+  double s0, s1;
+  stat_sum2(st, C, c, s0, s1);
+  return which ? s1 : s0;
 }
 __device__ __forceinline__ double* stat_replica(double* st, int C, int key) {
   return st + (size_t)(key % HP_STAT_REPL) * 2 * C;

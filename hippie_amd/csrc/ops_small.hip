@@ -56,24 +56,30 @@ __device__ __forceinline__ void fold_rowlanes(const ColMap& m, double (&v)[NV], 
   }
 }
 
-struct BnCoef { float mean, invstd, scale, shift; double var; };
+struct BnCoef { float mean, invstd, scale, shift, rm, rv; double var; };
 
+// every global load of the prologue (gamma, beta, running stats, all statistic replicas) is issued before the
+// first use: one memory round trip instead of one per operand
 __device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* stats, int C, int c, const float* gamma,
                                           const float* beta, const float* rmean, const float* rvar, float eps) {
   BnCoef k;
+  const float g = gamma[c], b = beta[c];
+  k.rm = rmean[c]; k.rv = rvar[c];
   double mean, var;
   if (training) {
-    mean = stat_sum(stats, C, 0, c) / (double)M;
-    var = stat_sum(stats, C, 1, c) / (double)M - mean * mean;
+    double s0, s1;
+    stat_sum2(stats, C, c, s0, s1);
+    mean = s0 / (double)M;
+    var = s1 / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
   } else {
-    mean = (double)rmean[c];
-    var = (double)rvar[c];
+    mean = (double)k.rm;
+    var = (double)k.rv;
   }
   const double invstd = 1.0 / sqrt(var + (double)eps);
-  const double sc = (double)gamma[c] * invstd;
+  const double sc = (double)g * invstd;
   k.mean = (float)mean; k.invstd = (float)invstd; k.var = var;
-  k.scale = (float)sc; k.shift = (float)((double)beta[c] - mean * sc);
+  k.scale = (float)sc; k.shift = (float)((double)b - mean * sc);
   return k;
 }
 
@@ -142,14 +148,35 @@ __device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, i
   save[c] = k.mean;
   save[C + c] = k.invstd;
   const double unb = M > 1 ? k.var * (double)M / (double)(M - 1) : k.var;
-  rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * (double)k.mean);
-  rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unb);
+  rmean[c] = (float)((1.0 - (double)momentum) * (double)k.rm + (double)momentum * (double)k.mean);
+  rvar[c] = (float)((1.0 - (double)momentum) * (double)k.rv + (double)momentum * unb);
 }
 
 template <int V>
 __device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
   const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
+  // The kernel is latency-bound (one round trip for the statistics, one for the rows): issue the row loads
+  // first so both round trips overlap.  (V = 4: exactly rpl_of(4) = 4 rows per thread.)
+  constexpr int NR = V == 4 ? 4 : 1;
+  T xs[NR], rs[NR];
+  if (V == 4) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = m.row + k * m.rstep;
+      if (m.active && r < m.rend) {
+        const size_t idx = (size_t)r * p.C + m.c;
+        xs[k] = *reinterpret_cast<const T*>(p.raw + idx);
+      }
+    }
+    if (p.res_mode != 0) {
+#pragma unroll
+      for (int k = 0; k < NR; ++k) {
+        const int r = m.row + k * m.rstep;
+        if (m.active && r < m.rend) rs[k] = *reinterpret_cast<const T*>(p.res + (size_t)r * p.C + m.c);
+      }
+    }
+  }
   // each channel's (replicated) statistics are summed ONCE per block, not once per thread
   for (int ci = threadIdx.x; ci < m.cw * V; ci += 256) {
     const int c = by * m.cw * V + ci;
@@ -175,21 +202,32 @@ __device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx
     sc[j] = s_coef[0][ci0 + j]; sh[j] = s_coef[1][ci0 + j];
     sc2[j] = p.res_mode == 2 ? s_coef[2][ci0 + j] : 0.f; sh2[j] = p.res_mode == 2 ? s_coef[3][ci0 + j] : 0.f;
   }
-  for (int r = m.row; r < m.rend; r += m.rstep) {
-    const size_t idx = (size_t)r * p.C + m.c;
-    T x = *reinterpret_cast<const T*>(p.raw + idx);
-    T rs = x;
-    if (p.res_mode != 0) rs = *reinterpret_cast<const T*>(p.res + idx);
+  auto apply = [&](T x, T rsd, size_t idx) {
     T o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float v = fmaf(at<V>(x, j), sc[j], sh[j]);
-      if (p.res_mode == 1) v += at<V>(rs, j);
-      else if (p.res_mode == 2) v += fmaf(at<V>(rs, j), sc2[j], sh2[j]);
+      if (p.res_mode == 1) v += at<V>(rsd, j);
+      else if (p.res_mode == 2) v += fmaf(at<V>(rsd, j), sc2[j], sh2[j]);
       if (p.act) v = lrelu(v, p.slope);
       at<V>(o, j) = v;
     }
     *reinterpret_cast<T*>(p.out + idx) = o;
+  };
+  if (V == 4) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = m.row + k * m.rstep;
+      if (r < m.rend) apply(xs[k], rs[k], (size_t)r * p.C + m.c);
+    }
+    return;
+  }
+  for (int r = m.row; r < m.rend; r += m.rstep) {
+    const size_t idx = (size_t)r * p.C + m.c;
+    T x = *reinterpret_cast<const T*>(p.raw + idx);
+    T rsd = x;
+    if (p.res_mode != 0) rsd = *reinterpret_cast<const T*>(p.res + idx);
+    apply(x, rsd, idx);
   }
 }
 // single and paired launch forms (HP_OP_PAIR: two independent ops, one launch, flattened 2-D grids)
@@ -230,14 +268,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
       mean2[j] = 0.f; invstd2[j] = 0.f;
       if (p.has_second) { mean2[j] = p.save2[m.c + j]; invstd2[j] = p.save2[p.C + m.c + j]; }
     }
-    for (int r = m.row; r < m.rend; r += m.rstep) {
-      const size_t idx = (size_t)r * p.C + m.c;
-      T g = *reinterpret_cast<const T*>(p.g1 + idx);
-      T a = *reinterpret_cast<const T*>(p.act + idx);
-      T x = *reinterpret_cast<const T*>(p.raw + idx);
-      T gg = g, x2 = x;
-      if (p.g2 != nullptr) gg = *reinterpret_cast<const T*>(p.g2 + idx);
-      if (p.has_second) x2 = *reinterpret_cast<const T*>(p.raw2 + idx);
+    auto accumulate = [&](T g, T a, T x, T gg, T x2, size_t idx) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float gv = at<V>(g, j);
@@ -249,6 +280,50 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
         if (p.has_second) v[3 * j + 2] += (double)gv * (double)((at<V>(x2, j) - mean2[j]) * invstd2[j]);
       }
       *reinterpret_cast<T*>(p.gout + idx) = g;
+    };
+    if (V == 4) {
+      // exactly rpl_of(4) = 4 rows per thread: all loads of all rows in flight before the first use
+      constexpr int NR = 4;
+      T g[NR], a[NR], x[NR], gg[NR], x2[NR];
+      // unconditional loads from a clamped row (so that they form one straight-line batch), then a scheduling
+      // barrier: otherwise the compiler folds each row's mask computation into its load block and the four
+      // rows become four dependent round trips
+      const int rlast = m.rend - 1;
+      if (m.row <= rlast) {
+        size_t idx[NR];
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          idx[k] = (size_t)min(m.row + k * m.rstep, rlast) * p.C + m.c;
+          g[k] = *reinterpret_cast<const T*>(p.g1 + idx[k]);
+          a[k] = *reinterpret_cast<const T*>(p.act + idx[k]);
+          x[k] = *reinterpret_cast<const T*>(p.raw + idx[k]);
+        }
+        if (p.g2 != nullptr) {
+#pragma unroll
+          for (int k = 0; k < NR; ++k) gg[k] = *reinterpret_cast<const T*>(p.g2 + idx[k]);
+        }
+        if (p.has_second) {
+#pragma unroll
+          for (int k = 0; k < NR; ++k) x2[k] = *reinterpret_cast<const T*>(p.raw2 + idx[k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < NR; ++k) {
+          const int r = m.row + k * m.rstep;
+          if (r <= rlast) accumulate(g[k], a[k], x[k], gg[k], x2[k], (size_t)r * p.C + m.c);
+        }
+      }
+    } else {
+      for (int r = m.row; r < m.rend; r += m.rstep) {
+        const size_t idx = (size_t)r * p.C + m.c;
+        T g = *reinterpret_cast<const T*>(p.g1 + idx);
+        T a = *reinterpret_cast<const T*>(p.act + idx);
+        T x = *reinterpret_cast<const T*>(p.raw + idx);
+        T gg = g, x2 = x;
+        if (p.g2 != nullptr) gg = *reinterpret_cast<const T*>(p.g2 + idx);
+        if (p.has_second) x2 = *reinterpret_cast<const T*>(p.raw2 + idx);
+        accumulate(g, a, x, gg, x2, idx);
+      }
     }
   }
   fold_rows<3 * V>(m, v, lds);
@@ -279,14 +354,28 @@ template <int V>
 __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
   const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
+  constexpr int NR = V == 4 ? 4 : 1;          // row loads first: overlaps the statistics round trip (see bn_apply_body)
+  T xs[NR], gs[NR];
+  if (V == 4) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = m.row + k * m.rstep;
+      if (m.active && r < m.rend) {
+        const size_t idx = (size_t)r * p.C + m.c;
+        xs[k] = *reinterpret_cast<const T*>(p.raw + idx);
+        gs[k] = *reinterpret_cast<const T*>(p.g + idx);
+      }
+    }
+  }
   for (int ci = threadIdx.x; ci < m.cw * V; ci += 256) {
     const int c = by * m.cw * V + ci;
     if (c >= p.C) continue;
-    const float mean = p.save[c], invstd = p.save[p.C + c];
-    const double sg = stat_sum(p.bs, p.C, 0, c), sgx = stat_sum(p.bs, p.C, 1, c);
+    const float mean = p.save[c], invstd = p.save[p.C + c], gam = p.gamma[c];
+    double sg, sgx;
+    stat_sum2(p.bs, p.C, c, sg, sgx);
     s_coef[0][ci] = mean; s_coef[1][ci] = invstd;
     s_coef[2][ci] = (float)(sg / (double)p.M); s_coef[3][ci] = (float)(sgx / (double)p.M);
-    s_coef[4][ci] = p.gamma[c] * invstd;
+    s_coef[4][ci] = gam * invstd;
     if (bx == 0) { p.dgamma[c] = (float)sgx; p.dbeta[c] = (float)sg; }
   }
   __syncthreads();
@@ -298,10 +387,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
     mean[j] = s_coef[0][ci0 + j]; invstd[j] = s_coef[1][ci0 + j];
     c1[j] = s_coef[2][ci0 + j]; c2[j] = s_coef[3][ci0 + j]; sc[j] = s_coef[4][ci0 + j];
   }
-  for (int r = m.row; r < m.rend; r += m.rstep) {
-    const size_t idx = (size_t)r * p.C + m.c;
-    T x = *reinterpret_cast<const T*>(p.raw + idx);
-    T g = *reinterpret_cast<const T*>(p.g + idx);
+  auto apply = [&](T x, T g, size_t idx) {
     T o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
@@ -309,6 +395,18 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
       at<V>(o, j) = sc[j] * (at<V>(g, j) - c1[j] - xh * c2[j]);
     }
     *reinterpret_cast<T*>(p.dr + idx) = o;
+  };
+  if (V == 4) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+      const int r = m.row + k * m.rstep;
+      if (r < m.rend) apply(xs[k], gs[k], (size_t)r * p.C + m.c);
+    }
+    return;
+  }
+  for (int r = m.row; r < m.rend; r += m.rstep) {
+    const size_t idx = (size_t)r * p.C + m.c;
+    apply(*reinterpret_cast<const T*>(p.raw + idx), *reinterpret_cast<const T*>(p.g + idx), idx);
   }
 }
 

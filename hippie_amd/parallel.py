@@ -62,7 +62,7 @@ def backward_allreduce(engine, group=None, use_graph=True, overlap=False):
     stream while the encoder-side chain still runs; the rest follows on the main stream (same order on every
     rank).  On ROCm 7 the extra stream costs more than the overlap gains at N=1, hence opt-in."""
     e = engine
-    if not overlap:
+    if not overlap or not e.train_cfg.split_backward:
         e.backward(use_graph)
         allreduce_mean_(e.grads[: e.plan.n_active], group)
         return

@@ -54,6 +54,8 @@ class TrainCfg:
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
+    split_backward: bool = False        # emit the deferred wgrad GEMMs in two groups (decoder | encoder side) so that
+                                        # Engine.backward(overlap=True) can run the first under the encoder-side chain
     optimizer: str = "adamw"            # "adamw" (model.py:93) | "schedulefree" (hippie/optimizers.py:18-209)
     warmup_steps: int = 0               # schedule-free only
     sf_r: float = 0.0
@@ -557,10 +559,11 @@ class Lowering:
         if self.with_class:
             self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0 + H], buf=[dcat, self.cls, self.cemb.gref], note="class_embedding grad")
 
-    def flush_wgrads(self, seg):
-        """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, in their own segment."""
+    def flush_wgrads(self, seg, only_if=True):
+        """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, in their own segment
+        (an empty segment, with the GEMMs left pending, when only_if is False)."""
         self.o.begin(seg)
-        for ntaps in (3, 1):
+        for ntaps in (3, 1) if only_if else ():
             mem = [w_ for w_ in self.pending_wgrads if len(w_[0].taps) == ntaps]
             if not mem:
                 continue
@@ -568,7 +571,8 @@ class Lowering:
             for (tm, nsplit, rps, dy, x, w, note) in mem:
                 self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
             self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
-        self.pending_wgrads = []
+        if only_if:
+            self.pending_wgrads = []
         self.o.end()
 
     # ---- whole model ---------------------------------------------------------------
@@ -604,7 +608,7 @@ class Lowering:
         # gradient range that is final once "bwd_a" + "wg_a" have run (decoder heads + decoder); the embeddings
         # and everything in front of it are finished by "bwd_b" + "wg_b"
         first_dec = names[0][0] + ".0.weight"
-        pl.grad_bucket_a = (pl.params[first_dec].offset, self.cemb.offset)
+        pl.grad_bucket_a = (pl.params[first_dec].offset, self.cemb.offset) if self.train.split_backward else None
         # the floats between n_active and cemb.offset (alignment gap) are zero padding
 
         # ---------------- workspace: persistent + I/O ----------------
@@ -716,7 +720,7 @@ class Lowering:
                 self.linear_bwd(B, fc["f2"], du4, 2 * z, hd["u3"], 2 * z, du3, 2 * z, mask=hd["u3"], ldmask=2 * z, note="decoder_fc.2")
                 self.linear_bwd(B, fc["f0"], du3, 2 * z, c1, ncat1, dc1, ncat1, accumulate=(k > 0), note="decoder_fc.0")
             self.o.end()
-            self.flush_wgrads("wg_a")
+            self.flush_wgrads("wg_a", only_if=self.train.split_backward)
             self.o.begin("bwd_b")
             self.emb_bwd(dc1, ncat1, z)
             dmulv = pl.f32(B * 2 * z)

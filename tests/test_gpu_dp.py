@@ -30,7 +30,7 @@ def _worker(rank, world, port, q):
     from hippie_amd.engine import Engine
     from oracle import cvae_oracle as O
     z, L, B = 10, 50, 16
-    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=1.0))
+    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=1.0, split_backward=True))
     om = O.OracleModel("unimodal", z, L, salt=rank)          # different init per rank: broadcast must fix it
     eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
     dp = parallel.DataParallelEngine(eng, overlap=True)

@@ -21,9 +21,9 @@ def n(t):
     return t.detach().cpu().numpy()
 
 
-def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0):
+def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, split=False):
     cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=L, output_size2=L2 or 100)
-    tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2)
+    tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2, split_backward=split)
     eng = Engine(cfg, B, tc, with_class=with_class)
     oms = []
     for dt in (torch.float32, torch.float64):
@@ -335,7 +335,10 @@ def test_ragged_batches_and_lengths(B, L):
 
 def test_overlapped_backward_equals_serial():
     """Engine.backward(overlap=True): decoder-side wgrad on a side stream under the encoder-side chain."""
-    eng, oms, batch, batch64, eps = build("unimodal", 10, 100, 64, True, 1.0, 1.0, 1e-3, 3)
+    eng, oms, batch, batch64, eps = build("unimodal", 10, 100, 64, True, 1.0, 1.0, 1e-3, 3, split=True)
+    plain = build("unimodal", 10, 100, 64, True, 1.0, 1.0, 1e-3, 3)[0]
+    with pytest.raises(Exception, match="split_backward"):
+        plain.backward(overlap=True)
     for use_graph in (False, True):
         eng.forward(True, use_graph)
         eng.backward(use_graph)

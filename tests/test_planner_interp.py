@@ -147,7 +147,7 @@ def test_backward_halves_commute_and_first_bucket_is_final(kind):
     must give the serial result, and the gradient bucket [grad_bucket_a) must be final after bwd_a + wg_a."""
     B, z = 4, 10
     cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=50, output_size2=100)
-    plan = planner.lower(cfg, B, planner.TrainCfg(clip=1.0), with_class=True)
+    plan = planner.lower(cfg, B, planner.TrainCfg(clip=1.0, split_backward=True), with_class=True)
     ops = plan.ops.array()
     om = O.OracleModel(kind, z, 50, output_size2=100 if kind == "multimodal" else None, salt=2)
     x, src, cls, eps = O.synth_inputs(B, 50, z, salt=2, name="x1")
