@@ -190,8 +190,9 @@ class Engine:
             if after_first_half is not None:
                 after_first_half(torch.cuda.current_stream(self.device))
             return
+        if not self.train_cfg.split_backward:
+            raise HipEngineError("backward(overlap=True) needs TrainCfg(split_backward=True)")
         if self._side is None:
-            # lowest priority: the grouped GEMM must only fill CUs the latency-bound chain leaves idle
             self._side = torch.cuda.Stream(device=self.device)
             self._ev = (torch.cuda.Event(), torch.cuda.Event())
         cur = torch.cuda.current_stream(self.device)
