@@ -18,14 +18,14 @@ struct ColMap {
   bool active;
 };
 
-__device__ __forceinline__ ColMap colmap(int M, int C) {
+__device__ __forceinline__ ColMap colmap(int M, int C, int rpl = kRowsPerLane) {
   ColMap m;
   m.cw = C < 256 ? C : 256;
   m.rl = 256 / m.cw;
   const int tid = threadIdx.x;
   m.rlane = tid / m.cw;
   m.c = blockIdx.y * m.cw + (tid - m.rlane * m.cw);
-  const int rpb = m.rl * kRowsPerLane;
+  const int rpb = m.rl * rpl;
   m.row = blockIdx.x * rpb + m.rlane;
   m.rstep = m.rl;
   m.rend = min(M, (int)(blockIdx.x + 1) * rpb);
@@ -33,9 +33,9 @@ __device__ __forceinline__ ColMap colmap(int M, int C) {
   return m;
 }
 
-inline dim3 colgrid(int M, int C) {
+inline dim3 colgrid(int M, int C, int rpl = kRowsPerLane) {
   const int cw = C < 256 ? C : 256;
-  const int rpb = (256 / cw) * kRowsPerLane;
+  const int rpb = (256 / cw) * rpl;
   return dim3(hp::cdiv(M, rpb), hp::cdiv(C, cw));
 }
 
@@ -443,20 +443,36 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs p) {
   }
 }
 
+constexpr int kStemRows = 64;
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs p) {
   __shared__ double lds[3 * 256];
   const int M = p.B * p.Lout;
-  const ColMap m = colmap(M, p.C);
+  const ColMap m = colmap(M, p.C, kStemRows);      // many rows per block: the 3*C outputs are one atomic target per block
   double v[3] = {0.0, 0.0, 0.0};
   if (m.active) {
-    for (int r = m.row; r < m.rend; r += m.rstep) {
-      const int b = r / p.Lout, l = r - b * p.Lout;
-      const float* xb = p.x + (size_t)b * p.Lin;
-      const int j = 2 * l - 1;
-      const float d = p.dr[(size_t)r * p.C + m.c];
-      if (j >= 0) v[0] += (double)(d * xb[j]);
-      v[1] += (double)(d * xb[j + 1]);
-      if (j + 2 < p.Lin) v[2] += (double)(d * xb[j + 2]);
+    // kRowsPerLane rows per thread in batches of 8: every load of a batch is issued before the first use
+    for (int k0 = 0; k0 < kStemRows; k0 += 8) {
+      float d[8], x0[8], x1[8], x2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = m.row + (k0 + k) * m.rstep;
+        const bool ok = r < m.rend;
+        const int rr = ok ? r : m.rend - 1;
+        const int b = rr / p.Lout, l = rr - b * p.Lout;
+        const float* xb = p.x + (size_t)b * p.Lin;
+        const int j = 2 * l - 1;
+        d[k] = ok ? p.dr[(size_t)rr * p.C + m.c] : 0.f;
+        x0[k] = j >= 0 ? xb[j] : 0.f;
+        x1[k] = xb[j + 1];
+        x2[k] = j + 2 < p.Lin ? xb[j + 2] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        v[0] += (double)(d[k] * x0[k]);
+        v[1] += (double)(d[k] * x1[k]);
+        v[2] += (double)(d[k] * x2[k]);
+      }
     }
   }
   fold_rowlanes<3>(m, v, lds);
@@ -611,11 +627,22 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinArgs p, int rows_p
   const bool active = mlane < ml && k < p.K;
   const int mbeg = blockIdx.z * rows_per_z, mend = min(p.M, mbeg + rows_per_z);
   double v[2] = {0.0, 0.0};
-  if (active) {
-    for (int m = mbeg + mlane; m < mend; m += ml) {
-      const float d = p.DY[(size_t)m * p.ldy + n];
-      v[0] += (double)(d * p.X[(size_t)m * p.ldx + k]);
-      v[1] += (double)d;
+  if (active && mbeg < mend) {
+    for (int m0 = mbeg + mlane; m0 < mend; m0 += 8 * ml) {      // batches of 8 rows: loads first, then use
+      float d[8], x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int m = m0 + j * ml;
+        const int mm = m < mend ? m : mend - 1;
+        d[j] = m < mend ? p.DY[(size_t)mm * p.ldy + n] : 0.f;
+        x[j] = p.X[(size_t)mm * p.ldx + k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[0] += (double)(d[j] * x[j]);
+        v[1] += (double)d[j];
+      }
     }
   }
   lds[tid] = active ? v[0] : 0.0;
@@ -716,27 +743,61 @@ __global__ void tail_bwd_x_kernel(const float* dt, const float* w, float* dact, 
     }
   dact[id] = s;
 }
-// grid.x over batch slices; thread = (channel c, tap t); fp32 atomics into zeroed DW/DB
+// dw[c][t] = sum_{b,h} act[b,h,c] * D_t[b,h] with D_t[b,h] = dt[b][2h+1-t] + dt[b][2h+2-t] (in range), db = sum dt.
+// thread = (channel, row lane); kTailRows rows (b,h) per thread, loaded in batches of 8 before use (a per-row
+// load -> use loop is one dependent memory round trip per row); fp32 atomics into zeroed DW/DB.
+constexpr int kTailRows = 32;
 __global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int bper) {
-  const int tid = threadIdx.x;
-  const int Lo = 2 * Lh;
-  const int b0 = blockIdx.x * bper, b1 = min(B, b0 + bper);
-  for (int ct = tid; ct < C * 3; ct += 256) {
-    const int c = ct / 3, t = ct - c * 3;
-    double s = 0.0;
-    for (int b = b0; b < b1; ++b)
-      for (int pz = 0; pz < Lo; ++pz) {
-        const int u = pz + t - 1;
-        if (u < 0 || u >= Lo) continue;
-        s += (double)(dt[(size_t)b * Lo + pz] * act[((size_t)b * Lh + (u >> 1)) * C + c]);
+  __shared__ double lds[4 * 256];
+  const int cw = C < 256 ? C : 256, rl = 256 / cw;
+  const int tid = threadIdx.x, rlane = tid / cw;
+  const int c = blockIdx.y * cw + (tid - rlane * cw);
+  const bool active = rlane < rl && c < C;
+  const int M = B * Lh, Lo = 2 * Lh;
+  const int row0 = blockIdx.x * rl * kTailRows + rlane;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (active) {
+    for (int k0 = 0; k0 < kTailRows; k0 += 8) {
+      float a[8], d0[8], d1[8], d2[8], d3[8];
+      bool ok[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = row0 + (k0 + k) * rl;
+        ok[k] = r < M;
+        const int rr = ok[k] ? r : M - 1;
+        const int b = rr / Lh, h = rr - b * Lh;
+        const float* dtb = dt + (size_t)b * Lo + 2 * h;
+        a[k] = act[(size_t)rr * C + c];
+        d0[k] = h > 0 ? dtb[-1] : 0.f;
+        d1[k] = dtb[0];
+        d2[k] = dtb[1];
+        d3[k] = h + 1 < Lh ? dtb[2] : 0.f;
       }
-    atomic_add_f32(dw + ct, (float)s);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (!ok[k]) continue;
+        v[0] += (double)(a[k] * (d2[k] + d3[k]));      // tap 0: pz = 2h+1, 2h+2
+        v[1] += (double)(a[k] * (d1[k] + d2[k]));      // tap 1: pz = 2h,   2h+1
+        v[2] += (double)(a[k] * (d0[k] + d1[k]));      // tap 2: pz = 2h-1, 2h
+        v[3] += (double)(d1[k] + d2[k]);
+      }
+    }
   }
-  if (tid == 0) {
-    double s = 0.0;
-    for (int b = b0; b < b1; ++b)
-      for (int pz = 0; pz < Lo; ++pz) s += (double)dt[(size_t)b * Lo + pz];
-    atomic_add_f32(db, (float)s);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) lds[j * 256 + tid] = active ? v[j] : 0.0;
+  __syncthreads();
+  if (active && rlane == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double sum = 0.0;
+      for (int r = 0; r < rl; ++r) sum += lds[j * 256 + r * cw + tid];
+      v[j] = sum;
+    }
+    atomic_add_f32(dw + c * 3 + 0, (float)v[0]);
+    atomic_add_f32(dw + c * 3 + 1, (float)v[1]);
+    atomic_add_f32(dw + c * 3 + 2, (float)v[2]);
+    if (c == 0) atomic_add_f32(db, (float)v[3]);
   }
 }
 
@@ -1004,7 +1065,7 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       StemArgs a{};
       a.dr = ptr<const float>(op, 0, bases); a.x = ptr<const float>(op, 1, bases); a.dw = ptr<float>(op, 2, bases);
       a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3];
-      hipLaunchKernelGGL(stem_wgrad_kernel, colgrid(a.B * a.Lout, a.C), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(stem_wgrad_kernel, colgrid(a.B * a.Lout, a.C, kStemRows), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_POOL_FWD:
@@ -1067,8 +1128,8 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
       const int kw = a.K < 256 ? a.K : 256;
       const int ky = hp::cdiv(a.K, kw);
-      int nz = hp::cdiv(256, a.N * ky);                       // aim at >= 256 workgroups
-      nz = max(1, min(nz, hp::cdiv(a.M, 32)));
+      int nz = hp::cdiv(1024, a.N * ky);                      // aim at >= 1024 workgroups, >= 16 rows each
+      nz = max(1, min(nz, hp::cdiv(a.M, 16)));
       const int rows_per_z = hp::cdiv(a.M, nz);
       dim3 grid(a.N, ky, hp::cdiv(a.M, rows_per_z));
       hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(256), 0, s, a, rows_per_z);
@@ -1098,9 +1159,10 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
                          ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2]);
       break;
     case HP_OP_TAIL_BWD_W: {
-      const int bper = 2;
-      hipLaunchKernelGGL(tail_bwd_w_kernel, dim3(hp::cdiv(I[0], bper)), dim3(256), 0, s, ptr<const float>(op, 0, bases),
-                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], bper);
+      const int cw = I[2] < 256 ? I[2] : 256;
+      const dim3 grid(hp::cdiv(I[0] * I[1], (256 / cw) * kTailRows), hp::cdiv(I[2], cw));
+      hipLaunchKernelGGL(tail_bwd_w_kernel, grid, dim3(256), 0, s, ptr<const float>(op, 0, bases),
+                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], 0);
       break;
     }
     case HP_OP_LOSS_FINALIZE:
