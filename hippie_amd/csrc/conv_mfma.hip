@@ -10,6 +10,8 @@
 #include "hp_common.h"
 
 #include <vector>
+#include <algorithm>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -451,6 +453,11 @@ hipError_t hp::build_wgrad_group(const HpOp* members, int count, void* const* ba
     for (int sp = 0; sp < probs[j].nsplit; ++sp)
       for (int tl = 0; tl < tiles; ++tl) blocks.push_back(make_int4(j, tl, sp, 0));
   }
+  // longest blocks first (LPT): the group mixes 12-slice and 100-slice blocks, and a long block that starts
+  // last is the tail of the whole launch (measured on the time model's 35-problem group: 757 us -> 675 us)
+  std::stable_sort(blocks.begin(), blocks.end(), [&](const int4& a, const int4& b) {
+    return probs[a.x].rows_per_split > probs[b.x].rows_per_split;
+  });
   hipError_t e = hipMalloc(d_probs, probs.size() * sizeof(WgradArgs));
   if (e != hipSuccess) return e;
   e = hipMalloc(d_blocks, blocks.size() * sizeof(int4));

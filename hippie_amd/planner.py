@@ -274,6 +274,10 @@ class Lowering:
             # deferred: all wgrads of the backward pass run in one grouped launch at its end.  With the
             # whole chip shared, ~64 workgroups per problem suffice: big-weight layers are not split at all.
             nsplit = max(1, min(64 // tiles, -(-tm.M // 256)))
+            if len(tm.taps) == 1:
+                # the 1-tap group (three shortcut convs) is too small to fill the chip at 64 blocks per problem
+                # (measured: 75 us -> 35 us with <= 512 rows per split)
+                nsplit = max(nsplit, -(-tm.M // 512))
             rps = _round_up(-(-tm.M // nsplit), 32)
             nsplit = -(-tm.M // rps)
             self.pending_wgrads.append((tm, nsplit, rps, dy, x, w, note))
