@@ -303,10 +303,20 @@ struct WgradArgs {
   int atomic;   // 1: accumulate into `slab` (= the zeroed gradient tensor) with fp32 atomics, no slabs
 };
 
+// 16-byte load through the global address space: pointers read from a record in memory are generic to the
+// compiler, and a flat_load also counts against the LDS counter
+typedef float hp_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float* p) {
+  const hp_v4f v = *(const hp_v4f __attribute__((address_space(1)))*)(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+
 template <int NT>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, const int split, float* smem) {
   constexpr int T = 32 * 64;   // one [32 rows][64 cols] image
   const TapMap& t = p.t;
+  const float* gDY = p.DY;
+  const float* gX = p.X;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
   const int ntc = (t.K + 63) >> 6;
@@ -331,7 +341,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
       const int m = mb + lr + 16 * j;
       const bool mv = m < mend;
       rdy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mv && n0 + cq < t.N) rdy[j] = *reinterpret_cast<const float4*>(p.DY + (size_t)m * t.N + n0 + cq);
+      if (mv && n0 + cq < t.N) rdy[j] = gload4(gDY + (size_t)m * t.N + n0 + cq);
       const int b = rb_[j];
       const int al = t.a * rl_[j];
       rl_[j] += r32; rb_[j] += q32;
@@ -341,7 +351,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
         const int pos = al + t.tap_o[tau];
         const bool ok = mv && pos >= 0 && pos < t.P && (!t.even || !(pos & 1)) && (c0 + cq < t.K);
         rx[tau][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) rx[tau][j] = *reinterpret_cast<const float4*>(p.X + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
+        if (ok) rx[tau][j] = gload4(gX + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
       }
     }
   };
@@ -403,7 +413,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
         const int n = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (n < t.N) {
           // a half-wave writes/adds one 128-byte row segment: the full-rate shape for float atomics
-          if (p.atomic) atomic_add_f32(dst + (size_t)n * t.K + c, acc[tau][r]);
+          if (p.atomic) atomic_add_f32_global(dst + (size_t)n * t.K + c, acc[tau][r]);
           else dst[(size_t)n * t.K + c] = acc[tau][r];
         }
       }
@@ -427,7 +437,10 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __res
   const int pj = __builtin_amdgcn_readfirstlane(bi.x);
   const int tile = __builtin_amdgcn_readfirstlane(bi.y);
   const int split = __builtin_amdgcn_readfirstlane(bi.z);
-  wgrad_body<NT>(probs[pj], tile, split, smem);
+  // by value: one scalar load of the problem record up front.  Through a reference into global memory the
+  // compiler re-loads the fields (s_load + wait) inside every guarded load of the slice loop.
+  const WgradArgs p = probs[pj];
+  wgrad_body<NT>(p, tile, split, smem);
 }
 
 static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {

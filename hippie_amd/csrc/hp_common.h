@@ -35,6 +35,10 @@ __device__ __forceinline__ void atomic_add_f64(double* p, double v) {
   unsafeAtomicAdd(p, v);
 }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+// same, for a pointer that was read from a record in memory (generic to the compiler: it would emit flat_atomic)
+__device__ __forceinline__ void atomic_add_f32_global(float* p, float v) {
+  __builtin_amdgcn_global_atomic_fadd_f32((float __attribute__((address_space(1)))*)p, v);
+}
 
 // sum of one entry of a replicated statistics slot double[HP_STAT_REPL][2][C]
 // Both entries (which = 0, 1) of channel c summed over the replicas.  All 2*HP_STAT_REPL loads are issued
