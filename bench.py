@@ -67,8 +67,8 @@ class Pair:
     (the GPU overlaps the two models' kernels).  --pair: ONE zipped program (hippie_amd.pair.PairEngine:
     every heavy op of the two models in one launch) on one stream."""
 
-    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False):
-        self.device, self.world, self.paired, self.overlap = device, world, paired, overlap
+    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False, lockstep=False):
+        self.device, self.world, self.paired, self.overlap, self.lockstep = device, world, paired, overlap, lockstep
         cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
         tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, split_backward=overlap),
                planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, split_backward=overlap)]
@@ -109,8 +109,22 @@ class Pair:
                 sd[k] = v
             e.load_state_dict(sd, strict=False)
 
+    def fork(self):
+        """The model streams start after whatever is queued on the current stream."""
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            s.wait_stream(cur)
+
+    def join(self):
+        cur = torch.cuda.current_stream(self.device)
+        for s in self.streams:
+            cur.wait_stream(s)
+
     def step(self, data, idx, use_graph=True):
-        import torch.distributed as dist
+        """One optimisation step of each model.  The two models' step sequences are independent of each other
+        (the reference trains them one after the other), so unless --lockstep is given their streams are joined
+        only at the ends of a run (fork()/join()), not per step: the shorter wave step does not wait for the
+        time step."""
         if self.paired:
             src = data[2].index_select(0, idx)
             for k, e in enumerate(self.eng):
@@ -123,9 +137,9 @@ class Pair:
                 parallel.allreduce_mean_(self.pe.grads, self.groups[0])   # both models: one 64 MB buffer
             self.pe.optimizer_step(use_graph)
             return
-        cur = torch.cuda.current_stream(self.device)
+        if self.lockstep:
+            self.fork()
         for k, (e, s) in enumerate(zip(self.eng, self.streams)):
-            s.wait_stream(cur)
             with torch.cuda.stream(s):
                 e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
                 e.io("src").copy_(data[2].index_select(0, idx), non_blocking=True)
@@ -136,8 +150,8 @@ class Pair:
                 else:
                     e.backward(use_graph, overlap=self.overlap)
                 e.optimizer_step(use_graph)
-        for s in self.streams:
-            cur.wait_stream(s)
+        if self.lockstep:
+            self.join()
 
 
 def conv_roofline(pair, data, idx, reps=3, detail=None):
@@ -267,6 +281,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pair", action="store_true", help="one zipped wave+time program (paired launches) instead of two engines on two streams")
     ap.add_argument("--overlap", action="store_true", help="decoder-side wgrad + first gradient bucket on a side stream (measured slower on ROCm 7: DESIGN.md 5.3)")
+    ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     # non-default shapes (BASELINE configs[2]: --batch 4096 --z-dim 32 --wave-len 256 --time-len 32); the headline
     # metric is always quoted on the defaults
@@ -302,7 +317,7 @@ def main():
             dist.init_process_group(backend)
 
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
-    pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len), overlap=args.overlap)
+    pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len), overlap=args.overlap, lockstep=args.lockstep)
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -312,15 +327,19 @@ def main():
         return perm[j * BATCH:(j + 1) * BATCH]
 
     use_graph = not args.no_graph
+    pair.fork()
     for i in range(args.warmup):
         pair.step(data, batch_idx(i), use_graph)
+    pair.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pair.fork()
     for i in range(args.steps):
         pair.step(data, batch_idx(args.warmup + i), use_graph)
+    pair.join()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -356,7 +375,7 @@ def main():
                                     "fp32 arithmetic on f32 MFMA (parity path; bf16 not used)")
                        if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
                        f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired, "lockstep": pair.lockstep,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_from_pmc(),
