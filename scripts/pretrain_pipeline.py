@@ -10,8 +10,15 @@ tables (:234-236), `torch.manual_seed(42)` then `random_split` of the index list
 shuffle=True for pretrain / False for fine-tune, the wave trainer without and the time trainer with
 gradient clipping (:200-224), `val_loss`-monitored top-1 checkpoints reloaded before fine-tuning
 (:227-230), embeddings = row-standardised `enc` of the *train* fine-tune subset (:313-315), CSV layout
-(:329-343).  wandb is replaced by JSONL logs.  The supervised stage (:349-616) needs a `label` column
-that none of the shipped labels.csv has, and is not reproduced here.
+(:329-343).  wandb is replaced by JSONL logs.
+
+The supervised stage (:349-616) is behind `--supervised` (the reference runs it unconditionally and dies with
+KeyError("label") on every shipped labels.csv, whose only column is "0"; `--label-column 0` selects that one):
+LabelEncoder + `random_split` at --train-val-split, `[class, source]` label pairs, class-balanced oversampling
+(BalancedBatchSampler) at --supervised-batch-size, fresh models with `num_classes = #train classes` loaded from the
+PRETRAIN checkpoints minus `class_embedding` (strict=False), lr/10, gradient clipping on BOTH trainers, best
+checkpoint (+ optimiser state) reloaded, embeddings at batch 128, the 5..19-neighbour kNN sweep (scikit-learn, CPU)
+and the `{dataset}_{waveform,isi,joint}_{knn,embeddings}.csv` files.
 """
 import argparse
 import json
@@ -70,6 +77,8 @@ def build_parser():
     # additions of this build
     p.add_argument("--data-root", type=str, default="datasets")
     p.add_argument("--output-dir", type=str, default=".")
+    p.add_argument("--supervised", action="store_true", help="run the supervised fine-tune + kNN stage (:349-616)")
+    p.add_argument("--label-column", type=str, default="label", help='column of labels.csv (the reference reads "label")')
     return p
 
 
@@ -176,7 +185,91 @@ def main(argv=None):
         paths[name] = path
     with open(os.path.join(args.output_dir, "run_config.json"), "w") as f:
         json.dump(vars(args), f)
+    if args.supervised:
+        paths.update(supervised_stage(args, num_sources, trw.best_model_path, trt.best_model_path, fit))
     return paths
+
+
+def supervised_stage(args, num_sources, wave_path, time_path, fit):
+    """scripts/train_model_with_multimodal.py:349-616 (unimodal branch)."""
+    from sklearn.metrics import balanced_accuracy_score, confusion_matrix
+    from sklearn.neighbors import KNeighborsClassifier
+    from sklearn.preprocessing import LabelEncoder
+    from hippie_amd.dataloading import BalancedBatchSampler
+    dataset = args.dataset
+    root = os.path.join(args.data_root, dataset)
+    sup_wf = pd.read_csv(os.path.join(root, "waveforms.csv")).to_numpy()
+    sup_isi = pd.read_csv(os.path.join(root, "isi_dist.csv")).to_numpy()
+    if os.path.exists(os.path.join(root, "labels.csv")):
+        labels = pd.read_csv(os.path.join(root, "labels.csv"))
+        raw = labels[args.label_column].values            # KeyError on the shipped files unless --label-column 0, as in the reference
+        le = LabelEncoder().fit(raw)
+        sup_labels = le.transform(raw)
+    else:
+        print(f"No labels.csv found for {dataset}")
+        sup_labels = np.zeros(len(sup_wf))
+        le = LabelEncoder().fit(sup_labels)
+    n = len(sup_wf)
+    train_size = int(args.train_val_split * n)
+    tr_i, va_i = random_split(list(range(n)), [train_size, n - train_size])
+    tr_i, va_i = list(tr_i), list(va_i)
+    label_train, label_val = sup_labels[tr_i], sup_labels[va_i]
+    num_class_labels = len(np.unique(label_train))
+    sid = DATASET_FILES[dataset]
+
+    def tables(idx, lab):
+        pair = np.vstack((lab, sid * np.ones_like(lab))).T             # [class, source], model.py:97-99
+        return (_Concat([EphysDatasetLabeled(sup_wf[idx], sup_isi[idx], pair, mode="wave", normalize=False)]),
+                _Concat([EphysDatasetLabeled(sup_wf[idx], sup_isi[idx], pair, mode="time", normalize=False)]))
+    tr_wave, tr_time = tables(tr_i, label_train)
+    va_wave, va_time = tables(va_i, label_val)
+    sampler = BalancedBatchSampler(range(len(tr_i)), torch.as_tensor(label_train))
+    order = list(sampler)                                                # the same stream every epoch, shared by both loaders
+    sb = args.supervised_batch_size
+    mods = {}
+    for kind, L, ckpt, tr_t, va_t in (("wave", 50, wave_path, tr_wave, va_wave), ("time", 100, time_path, tr_time, va_time)):
+        net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=L, class_hidden_dim=5, num_sources=num_sources,
+                                 num_classes=num_class_labels)
+        mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay)
+        if ckpt:
+            sd = torch.load(ckpt, weights_only=False)["state_dict"]
+            sd.pop("model.class_embedding.weight")
+            mod.load_state_dict(sd, strict=False)
+        tr = fit(kind, mod, tr_t.loader(order, sb, False), va_t.loader(range(len(va_i)), sb, False),
+                 args.supervised_max_epochs, args.gradient_clip_val, "supervised")
+        if tr.best_model_path:
+            best = torch.load(tr.best_model_path, weights_only=False)
+            mod.load_state_dict(best["state_dict"])
+            mod.optimizer.load_state_dict(best["optimizer_states"][0])
+        mod.eval()
+        mods[kind] = mod
+    emb_tr = get_embeddings(tr_wave.loader(range(len(tr_i)), 128, False), tr_time.loader(range(len(tr_i)), 128, False),
+                            mods["wave"], mods["time"])
+    emb_va = get_embeddings(va_wave.loader(range(len(va_i)), sb, False), va_time.loader(range(len(va_i)), sb, False),
+                            mods["wave"], mods["time"])
+    out = {}
+    neighbor_options = list(range(5, 20))
+    for name, e_tr, e_va in zip(("waveform", "isi", "joint"), emb_tr, emb_va):
+        acc = []
+        for k in neighbor_options:
+            knn = KNeighborsClassifier(n_neighbors=min(k, len(e_tr))).fit(e_tr, label_train)
+            acc.append(balanced_accuracy_score(label_val, knn.predict(e_va)))
+        best_k = neighbor_options[int(np.argmax(acc))]
+        pred = KNeighborsClassifier(n_neighbors=min(best_k, len(e_tr))).fit(e_tr, label_train).predict(e_va)
+        confusion_matrix(label_val, pred)
+        path = os.path.join(args.output_dir, f"{dataset}_{name}_knn.csv")
+        pd.DataFrame({"pred": le.inverse_transform(pred.astype(int)), "true": le.inverse_transform(label_val.astype(int))}).to_csv(path)
+        out[name + "_knn"] = path
+        out[name + "_balanced_accuracy"] = acc
+    all_wave, all_time = tables(list(range(n)), sup_labels)
+    embs = get_embeddings(all_wave.loader(range(n), 128, False), all_time.loader(range(n), 128, False), mods["wave"], mods["time"])
+    for name, e in zip(("waveform", "isi", "joint"), embs):
+        df = pd.DataFrame(e)
+        df["label"] = le.inverse_transform(sup_labels.astype(int))
+        path = os.path.join(args.output_dir, f"{dataset}_{name}_embeddings.csv")
+        df.to_csv(path)
+        out[name + "_supervised_embeddings"] = path
+    return out
 
 
 if __name__ == "__main__":

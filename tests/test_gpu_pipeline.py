@@ -61,6 +61,34 @@ def test_pipeline_end_to_end(tmp_path):
     assert len(tr) == int(0.8 * n) and len(set(tr.indices) & set(te.indices)) == 0
 
 
+def test_supervised_stage(tmp_path):
+    """--supervised: class labels, balanced sampler, class_embedding re-created, kNN + embedding CSVs."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pretrain_pipeline as pp
+    rng = np.random.default_rng(3)
+    data = tmp_path / "datasets"
+    data.mkdir()
+    spec = make_root(data, rng)
+    n = spec["extracellular-mouse-a1"][0]
+    names = np.array(["PV", "SST", "PYR"])[rng.choice(3, size=n, p=[0.6, 0.3, 0.1])]
+    pd.DataFrame({"0": names}).to_csv(data / "extracellular-mouse-a1" / "labels.csv")
+    out = tmp_path / "out"
+    common = ["--dataset", "extracellular-mouse-a1", "--data-root", str(data), "--output-dir", str(out), "--batch-size", "64",
+              "--supervised-batch-size", "16", "--z_dim", "5", "--supervised"]
+    with pytest.raises(KeyError):                       # the reference's behaviour on the shipped column name
+        pp.main(common)
+    paths = pp.main(common + ["--label-column", "0"])
+    for name, width in (("waveform", 5), ("isi", 5), ("joint", 10)):
+        knn = pd.read_csv(paths[name + "_knn"])
+        assert list(knn.columns) == ["Unnamed: 0", "pred", "true"] and len(knn) == n - int(0.8 * n)
+        assert set(knn["pred"]) <= {"PV", "SST", "PYR"}
+        emb = pd.read_csv(paths[name + "_supervised_embeddings"])
+        assert len(emb) == n and list(emb.columns)[-1] == "label" and emb.shape[1] == width + 2
+        assert np.isfinite(emb[[str(i) for i in range(width)]].to_numpy()).all()
+        assert len(paths[name + "_balanced_accuracy"]) == 15
+    assert any(f.endswith(".ckpt") for f in os.listdir(out / "checkpoints" / "wave_supervised"))
+
+
 def test_inference_script_roundtrip(tmp_path):
     """checkpoints written by the Trainer -> scripts/inference.py -> embedding CSVs in the reference's layout"""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
