@@ -247,9 +247,10 @@ def traffic_from_pmc():
         return None
 
 
-def cpu_baseline(steps=16):
+def cpu_baseline(steps=20, warm=3):
     """The torch-CPU oracle (kind 'port': a restatement of the reference's PyTorch path, pinned to it
-    by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512."""
+    by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512; median of `steps` timed
+    steps after `warm` warm-up steps."""
     from oracle import cvae_oracle as O
     try:
         cores = len(os.sched_getaffinity(0))
@@ -261,13 +262,16 @@ def cpu_baseline(steps=16):
     for L, clip in ((50, None), (100, 1.0)):
         m = O.OracleModel("unimodal", Z_DIM, L)
         x, src, cls, eps = O.synth_inputs(BATCH, L, Z_DIM)
-        m.train_step((x, src, None), eps, lr=1e-6, clip=clip)        # warm-up
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(warm):
             m.train_step((x, src, None), eps, lr=1e-6, clip=clip)
-        times.append((time.perf_counter() - t0) / steps)
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            m.train_step((x, src, None), eps, lr=1e-6, clip=clip)
+            ts.append(time.perf_counter() - t0)
+        times.append(float(np.median(ts)))
     return dict(value=BATCH / sum(times), unit="samples/s", cores=cores, kind="port",
-                sample=f"{steps} steps of wave (L=50) + time (L=100, clip 1.0) cVAE at batch 512, torch {torch.__version__} CPU, "
+                sample=f"median of {steps} steps (after {warm} warm-up) of wave (L=50) + time (L=100, clip 1.0) cVAE at batch 512, torch {torch.__version__} CPU, "
                        f"wave {times[0]*1e3:.0f} ms + time {times[1]*1e3:.0f} ms per step")
 
 
@@ -381,7 +385,9 @@ def main():
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_from_pmc(),
                          "kernel": "conv_taps_kernel + conv_taps_pair_kernel (same body: fwd conv + dgrad, f32 MFMA 32x32x2)",
                          "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
-                         "algorithmic_gflop_per_step": conv_flop / 1e9},
+                         "algorithmic_gflop_per_step": conv_flop / 1e9,
+                         # whole-step view: samples/s x 3 x forward FLOPs per unit, all kernels and gaps included
+                         "whole_step_tflops_per_gpu": BATCH * args.steps / dt * 3.0 * sum(e.plan.flops_fwd for e in pair.eng) / BATCH / 1e12},
         }
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline()
