@@ -123,3 +123,26 @@ def test_multimodal_module_step_and_metrics():
     enc, mu, lv, d1, d2 = mod(batch)
     assert d1.shape == (20, 1, 50) and d2.shape == (20, 1, 100) and enc.shape == (20, z)
     assert len(mod.state_dict()) == 529
+
+
+def test_get_embeddings_matches_reference_fixture():
+    """hippie_amd.utils.get_embeddings on the GPU modules against the reference's own function output
+    (tests/golden/get_embeddings_z10_B6x2.npz); 1e-4 relative to the row-standardised scale (~1)."""
+    from hippie_amd.utils import get_embeddings
+    g = np.load(os.path.join(G, "get_embeddings_z10_B6x2.npz"))
+    z, B, nb, sw, st = (int(v) for v in g["meta"])
+    xw, src, _, _ = O.synth_inputs(B * nb, 50, z, salt=sw)
+    xt = O.synth_inputs(B * nb, 100, z, salt=st)[0]
+    mods = []
+    for L, salt in ((50, 0), (100, 1)):
+        net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+        net.load_state_dict({k: v.detach() for k, v in O.OracleModel("unimodal", z, L, salt=salt).state.items()})
+        mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3)
+        mod.eval()
+        mods.append(mod)
+    lw = [(xw[i * B:(i + 1) * B].cuda(), src[i * B:(i + 1) * B].cuda()) for i in range(nb)]
+    lt = [(xt[i * B:(i + 1) * B].cuda(), src[i * B:(i + 1) * B].cuda()) for i in range(nb)]
+    ew, et, joint = get_embeddings(lw, lt, mods[0], mods[1])
+    np.testing.assert_allclose(ew, g["waveform"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(et, g["isi"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(joint, g["joint"], rtol=1e-4, atol=1e-4)

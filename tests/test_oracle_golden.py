@@ -147,3 +147,24 @@ def test_multimodal_oracle_equals_reference():
         enc, mu, lv, d1, d2 = m.forward(batch, eps, training=False)
     for k, v in (("eval_enc", enc), ("eval_mu", mu), ("eval_logvar", lv), ("eval_dec1", d1), ("eval_dec2", d2)):
         np.testing.assert_allclose(v.numpy(), g[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_get_embeddings_oracle_equals_reference():
+    """Fixture (11): scripts/utils.py:get_embeddings run on the reference's modules (make_golden_embeddings.py)."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "get_embeddings_z10_B6x2.npz"))
+    z, B, nb, sw, st = (int(v) for v in g["meta"])
+    xw, src, _, eps = O.synth_inputs(B * nb, 50, z, salt=sw)
+    xt = O.synth_inputs(B * nb, 100, z, salt=st)[0]
+    out = []
+    for L, salt, x in ((50, 0, xw), (100, 1, xt)):
+        om = O.OracleModel("unimodal", z, L, salt=salt)
+        rows = []
+        with torch.no_grad():
+            for i in range(nb):
+                sl = slice(i * B, (i + 1) * B)
+                enc = om.forward((x[sl], src[sl], None), eps[sl], training=False)[0]
+                rows.append((enc - enc.mean(dim=1)[:, None]) / enc.std(dim=1)[:, None])
+        out.append(torch.cat(rows).numpy())
+    np.testing.assert_allclose(out[0], g["waveform"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out[1], g["isi"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(np.concatenate(out, axis=1), g["joint"], rtol=1e-5, atol=1e-6)
