@@ -140,6 +140,7 @@ struct BnApplyArgs {
   const float* res; const double* stats2; const float* gamma2; const float* beta2;
   float* rmean2; float* rvar2; float* save2;
   int M, C, res_mode, training, act;
+  int Mstat;          // rows behind the statistics: M, or M * world under sync-BatchNorm (HP_OP_STATS_SYNC)
   float slope, eps, momentum;
 };
 
@@ -181,16 +182,16 @@ __device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx
   for (int ci = threadIdx.x; ci < m.cw * V; ci += 256) {
     const int c = by * m.cw * V + ci;
     if (c >= p.C) continue;
-    const BnCoef k = bn_coef(p.training, p.M, p.stats, p.C, c, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
+    const BnCoef k = bn_coef(p.training, p.Mstat, p.stats, p.C, c, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
     s_coef[0][ci] = k.scale; s_coef[1][ci] = k.shift;
     BnCoef k2 = k;
     if (p.res_mode == 2) {
-      k2 = bn_coef(p.training, p.M, p.stats2, p.C, c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
+      k2 = bn_coef(p.training, p.Mstat, p.stats2, p.C, c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
       s_coef[2][ci] = k2.scale; s_coef[3][ci] = k2.shift;
     }
     if (p.training && bx == 0) {
-      bn_side_effects(k, p.M, p.C, c, p.save, p.rmean, p.rvar, p.momentum);
-      if (p.res_mode == 2) bn_side_effects(k2, p.M, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
+      bn_side_effects(k, p.Mstat, p.C, c, p.save, p.rmean, p.rvar, p.momentum);
+      if (p.res_mode == 2) bn_side_effects(k2, p.Mstat, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
     }
   }
   __syncthreads();
@@ -348,6 +349,8 @@ struct BnBwdApplyArgs {
   const float* g; const float* raw; const float* save; const double* bs; const float* gamma;
   float* dr; float* dgamma; float* dbeta;
   int M, C;
+  int Mstat;          // M * world under sync-BatchNorm: BS then holds the sums over all ranks
+  float gscale;       // 1 / world: dgamma / dbeta are written so that the data-parallel MEAN of the ranks gives the sum
 };
 
 template <int V>
@@ -374,9 +377,9 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
     double sg, sgx;
     stat_sum2(p.bs, p.C, c, sg, sgx);
     s_coef[0][ci] = mean; s_coef[1][ci] = invstd;
-    s_coef[2][ci] = (float)(sg / (double)p.M); s_coef[3][ci] = (float)(sgx / (double)p.M);
+    s_coef[2][ci] = (float)(sg / (double)p.Mstat); s_coef[3][ci] = (float)(sgx / (double)p.Mstat);
     s_coef[4][ci] = gam * invstd;
-    if (bx == 0) { p.dgamma[c] = (float)sgx; p.dbeta[c] = (float)sg; }
+    if (bx == 0) { p.dgamma[c] = (float)(sgx * (double)p.gscale); p.dbeta[c] = (float)(sg * (double)p.gscale); }
   }
   __syncthreads();
   if (!m.active) return;
@@ -971,6 +974,7 @@ BnApplyArgs bn_apply_args(const HpOp& op, void* const* bases) {
   a.gamma2 = ptr<const float>(op, 10, bases); a.beta2 = ptr<const float>(op, 11, bases);
   a.rmean2 = ptr<float>(op, 12, bases); a.rvar2 = ptr<float>(op, 13, bases); a.save2 = ptr<float>(op, 14, bases);
   a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
+  a.Mstat = I[0] * (I[5] > 1 ? I[5] : 1);
   a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
   return a;
 }
@@ -992,6 +996,8 @@ BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
   a.bs = ptr<const double>(op, 3, bases); a.gamma = ptr<const float>(op, 4, bases); a.dr = ptr<float>(op, 5, bases);
   a.dgamma = ptr<float>(op, 6, bases); a.dbeta = ptr<float>(op, 7, bases);
   a.M = op.i[0]; a.C = op.i[1];
+  const int w = op.i[2] > 1 ? op.i[2] : 1;
+  a.Mstat = a.M * w; a.gscale = 1.f / (float)w;
   return a;
 }
 
@@ -1181,6 +1187,8 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       hipLaunchKernelGGL(adamw_kernel, dim3(min(2048, max(1, blocks_for(a.n >> 2)))), dim3(256), 0, s, a);
       break;
     }
+    case HP_OP_STATS_SYNC:
+      return hipSuccess;          // marker: the host sums buf[0] over the data-parallel ranks at this point
     case HP_OP_SF_SCHEDULE:
       hipLaunchKernelGGL(sf_schedule_kernel, dim3(1), dim3(64), 0, s, ptr<const int64_t>(op, 0, bases), ptr<double>(op, 1, bases),
                          I[0], op.f[0], op.f[1], op.f[2], op.f[3]);

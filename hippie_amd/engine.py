@@ -28,6 +28,8 @@ class Engine:
         self.train_cfg = train or planner.TrainCfg()
         self._graphs = {}
         self._side = None
+        self._sync_cache = {}
+        self.sync_group = None          # process group of the sync-BatchNorm collectives (None = WORLD)
         if _view is not None:
             # a view over one model's slice of joint arenas owned by a PairEngine (which runs the program)
             self.plan, (self.ws, self.params, self.grads, self.bufs, self.m, self.v) = _view
@@ -153,10 +155,44 @@ class Engine:
     def _stream(self):
         return torch.cuda.current_stream(self.device).cuda_stream
 
+    # ---- sync-BatchNorm (TrainCfg.sync_bn_world > 1) ---------------------------------------
+    def _sync_points(self, first, count):
+        key = (first, count)
+        pts = self._sync_cache.get(key)
+        if pts is None:
+            pts = []
+            for k in range(first, first + count):
+                if int(self.ops[k]["op"]) == P.STATS_SYNC:
+                    ref = int(self.ops[k]["buf"][0])
+                    assert (ref >> 56) == P.WS
+                    off, n = ref & ((1 << 56) - 1), int(self.ops[k]["i"][0])
+                    pts.append((k, self.ws[off: off + 8 * n].view(torch.float64)))
+            self._sync_cache[key] = pts
+        return pts
+
+    def _run_synced(self, first, count):
+        """Run an op range, summing every HP_OP_STATS_SYNC slot over the data-parallel ranks where its marker
+        stands (torch.nn.SyncBatchNorm semantics: all ranks normalise with the statistics of the global batch).
+        Eager and collective-bound (~85 small all-reduces per pass): the parity mode, not the fast one."""
+        import torch.distributed as dist
+        W = self.train_cfg.sync_bn_world
+        if not dist.is_initialized() or dist.get_world_size(self.sync_group) != W:
+            raise HipEngineError(f"sync-BatchNorm was lowered for {W} ranks; initialise torch.distributed with that world size")
+        cur = first
+        for k, slot in self._sync_points(first, count):
+            if k > cur:
+                self.prog.run(cur, k - cur, self._stream())
+            dist.all_reduce(slot, op=dist.ReduceOp.SUM, group=self.sync_group)
+            cur = k + 1
+        if first + count > cur:
+            self.prog.run(cur, first + count - cur, self._stream())
+
     def run(self, seg, use_graph=False):
         first, count = self.plan.ops.segments[seg]
         if count == 0:
             return
+        if self.train_cfg.sync_bn_world > 1 and self._sync_points(first, count):
+            return self._run_synced(first, count)
         if use_graph:
             g = self._graphs.get(seg)
             if g is None:

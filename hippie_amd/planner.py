@@ -54,6 +54,7 @@ class TrainCfg:
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
+    sync_bn_world: int = 0              # > 1: sync-BatchNorm over that many data-parallel ranks (HP_OP_STATS_SYNC markers)
     split_backward: bool = False        # emit the deferred wgrad GEMMs in two groups (decoder | encoder side) so that
                                         # Engine.backward(overlap=True) can run the first under the encoder-side chain
     optimizer: str = "adamw"            # "adamw" (model.py:93) | "schedulefree" (hippie/optimizers.py:18-209)
@@ -304,8 +305,17 @@ class Lowering:
             save2 = self.pl.f32(2 * bn2["C"])
             bn2["save"] = save2
             bufs += [res, stats2 if training else None, bn2["gamma"].ref, bn2["beta"].ref, bn2["rmean"].ref, bn2["rvar"].ref, save2]
-        self.o.add(P.BN_APPLY, 0, i=[M, bn["C"], res_mode, 1 if training else 0, 1 if act else 0],
+        W = self.train.sync_bn_world if training else 0
+        if W > 1:
+            self.stats_sync(stats, bn["C"], bn["prefix"])
+            if res_mode == 2:
+                self.stats_sync(stats2, bn2["C"], bn2["prefix"])
+        self.o.add(P.BN_APPLY, 0, i=[M, bn["C"], res_mode, 1 if training else 0, 1 if act else 0, W],
                    f=[slope, BN_EPS, BN_MOMENTUM], buf=bufs, note=bn["prefix"])
+
+    def stats_sync(self, slot, C, prefix):
+        """sync-BatchNorm: the replicated fp64 slot must be summed over the data-parallel ranks here."""
+        self.o.add(P.STATS_SYNC, 0, i=[STAT_REPL * 2 * C], buf=[slot], note=prefix + " statistics all-reduce")
 
     def bn_bwd(self, M, bn, g1, g2, act, raw, slope, bn_b=None, raw_b=None):
         """returns (g, dr, dr_b): masked upstream gradient and BN input gradients."""
@@ -319,13 +329,18 @@ class Lowering:
             bufs += [raw_b, bn_b["save"], bs_b]
         self.o.add(P.BN_BWD_REDUCE, 0, i=[M, C, 1 if g2 is not None else 0, 1 if bn_b is not None else 0], f=[slope],
                    buf=bufs, note=bn["prefix"] + " bwd-reduce")
+        W = self.train.sync_bn_world
+        if W > 1:
+            self.stats_sync(bs, C, bn["prefix"] + " bwd")
+            if bn_b is not None:
+                self.stats_sync(bs_b, C, bn_b["prefix"] + " bwd")
         dr = self.pl.f32(M * C)
-        self.o.add(P.BN_BWD_APPLY, 0, i=[M, C], buf=[g, raw, bn["save"], bs, bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
+        self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[g, raw, bn["save"], bs, bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
                    note=bn["prefix"] + " bwd-apply")
         dr_b = None
         if bn_b is not None:
             dr_b = self.pl.f32(M * C)
-            self.o.add(P.BN_BWD_APPLY, 0, i=[M, C], buf=[g, raw_b, bn_b["save"], bs_b, bn_b["gamma"].ref, dr_b,
+            self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[g, raw_b, bn_b["save"], bs_b, bn_b["gamma"].ref, dr_b,
                                                          bn_b["gamma"].gref, bn_b["beta"].gref], note=bn_b["prefix"] + " bwd-apply")
             self.pair_last_two("pair " + bn["prefix"] + " + shortcut bwd-apply")
         return g, dr, dr_b

@@ -98,6 +98,7 @@ enum {
    * training: mean/var from STATS (sum, sumsq) over M rows; saves (mean, invstd);
    * updates running stats (momentum, unbiased var).  eval: running stats.
    * i[0]=M i[1]=C i[2]=res_mode(0 none,1 tensor,2 second BN) i[3]=training i[4]=act
+   * i[5]=world (sync-BatchNorm: STATS hold the sums over `world` ranks, i.e. over M*world rows; 0/1 = local)
    * f[0]=slope f[1]=eps f[2]=momentum
    * buf: 0 RAW 1 OUT 2 STATS 3 GAMMA 4 BETA 5 RMEAN 6 RVAR 7 SAVE(float[2][C])
    *      8 RES(tensor or second raw) 9 STATS2 10 GAMMA2 11 BETA2 12 RMEAN2 13 RVAR2 14 SAVE2 */
@@ -109,7 +110,9 @@ enum {
    * buf: 0 G1 1 G2 2 ACT 3 GOUT 4 RAW 5 SAVE 6 BS(double[2][C]) 7 RAW2 8 SAVE2 9 BS2 */
   HP_OP_BN_BWD_REDUCE = 5,
   /* dr = gamma*invstd*(g - BS0/M - xhat*BS1/M);  dgamma = BS1;  dbeta = BS0.
-   * i[0]=M i[1]=C.  buf: 0 G 1 RAW 2 SAVE 3 BS 4 GAMMA 5 DR 6 DGAMMA 7 DBETA */
+   * i[0]=M i[1]=C i[2]=world (sync-BatchNorm: BS summed over ranks, divisor M*world, dgamma/dbeta scaled by
+   * 1/world so that the data-parallel gradient MEAN restores the sum).
+   * buf: 0 G 1 RAW 2 SAVE 3 BS 4 GAMMA 5 DR 6 DGAMMA 7 DBETA */
   HP_OP_BN_BWD_APPLY = 6,
   /* encoder stem Conv1d(1,64,k3,s2,p1) (backbones.py:78,95): raw[b*Lout+l][n] =
    * sum_t x[b][2l+t-1]*W[n][t] (+stats).  i[0]=B i[1]=Lin i[2]=Lout i[3]=C
@@ -215,6 +218,11 @@ enum {
   /* y = torch.lerp(y, z, w): AdamWScheduleFree.eval() (w = 1 - 1/beta1) and .train() (w = 1 - beta1)
    * (hippie/optimizers.py:82-103).  i[0]=n f[0]=w.  buf: 0 Y 1 Z */
   HP_OP_LERP = 34,
+  /* Marker for sync-BatchNorm under data parallelism (torch.nn.SyncBatchNorm semantics; Lightning's
+   * sync_batchnorm=True): the i[0] doubles at buf[0] (a replicated statistics slot) must be summed over all
+   * ranks before the next op runs.  The library executes it as a no-op; the host splits the range here and
+   * issues the collective (hippie_amd/engine.py).  i[0]=count.  buf: 0 SLOT */
+  HP_OP_STATS_SYNC = 35,
   HP_OP__COUNT
 };
 

@@ -153,20 +153,21 @@ def run(ops, A: Arenas, first=0, count=None):
             M, C, res_mode, training, act = [int(v) for v in i[:5]]
             slope, eps, mom = f[0], f[1], f[2]
             raw = A.f32(b[0], M * C).reshape(M, C)
-            mean, var, invstd, sc, sh = _bn_coef(A, training, M, C, b[2], b[3], b[4], b[5], b[6], eps)
+            Ms = M * max(1, int(i[5]))          # sync-BatchNorm: statistics summed over `world` ranks
+            mean, var, invstd, sc, sh = _bn_coef(A, training, Ms, C, b[2], b[3], b[4], b[5], b[6], eps)
             v = raw * sc[None, :] + sh[None, :]
             if res_mode == 1:
                 v = v + A.f32(b[8], M * C).reshape(M, C)
             elif res_mode == 2:
-                mean2, var2, invstd2, sc2, sh2 = _bn_coef(A, training, M, C, b[9], b[10], b[11], b[12], b[13], eps)
+                mean2, var2, invstd2, sc2, sh2 = _bn_coef(A, training, Ms, C, b[9], b[10], b[11], b[12], b[13], eps)
                 v = v + (A.f32(b[8], M * C).reshape(M, C) * sc2[None, :] + sh2[None, :])
             if act:
                 v = _lrelu(v, slope)
             A.f32(b[1], M * C)[:] = v.astype(np.float32).reshape(-1)
             if training:
-                _bn_side(A, M, C, mean, var, invstd, b[7], b[5], b[6], mom)
+                _bn_side(A, Ms, C, mean, var, invstd, b[7], b[5], b[6], mom)
                 if res_mode == 2:
-                    _bn_side(A, M, C, mean2, var2, invstd2, b[14], b[12], b[13], mom)
+                    _bn_side(A, Ms, C, mean2, var2, invstd2, b[14], b[12], b[13], mom)
         elif op == 5:    # BN_BWD_REDUCE
             M, C, has_g2, has_second = [int(v) for v in i[:4]]
             g = A.f32(b[0], M * C).reshape(M, C).copy()
@@ -189,11 +190,12 @@ def run(ops, A: Arenas, first=0, count=None):
             bs = A.f64(b[3], STAT_REPL * 2 * C).reshape(STAT_REPL, 2 * C).sum(0)
             gamma = A.f32(b[4], C)
             xh = (raw - sv[None, :C]) * sv[None, C:]
-            c1 = (bs[:C] / M).astype(np.float32)
-            c2 = (bs[C:] / M).astype(np.float32)
+            W = max(1, int(i[2]))
+            c1 = (bs[:C] / (M * W)).astype(np.float32)
+            c2 = (bs[C:] / (M * W)).astype(np.float32)
             A.f32(b[5], M * C)[:] = ((gamma * sv[C:])[None, :] * (g - c1[None, :] - xh * c2[None, :])).astype(np.float32).reshape(-1)
-            A.f32(b[6], C)[:] = bs[C:].astype(np.float32)
-            A.f32(b[7], C)[:] = bs[:C].astype(np.float32)
+            A.f32(b[6], C)[:] = (bs[C:] / W).astype(np.float32)
+            A.f32(b[7], C)[:] = (bs[:C] / W).astype(np.float32)
         elif op in (7, 8):    # STEM_FWD / STEM_WGRAD
             B, Lin, Lout, C = [int(v) for v in i[:4]]
             xr = b[0] if op == 7 else b[1]
@@ -404,6 +406,8 @@ def run(ops, A: Arenas, first=0, count=None):
             if flags & 1:
                 x = np.log(x + np.float32(1)).astype(np.float32)
             A.f32(b[1], N * L)[:] = resample_linear(x, L).reshape(-1)
+        elif op == 35:         # STATS_SYNC: single-process no-op (the host sums the slot over ranks here)
+            pass
         elif op in (29, 30):   # WGRAD_GROUP / PAIR: its member WGRAD_TAPS records (just before it) were executed in place
             pass
         else:

@@ -77,3 +77,66 @@ def test_two_rank_data_parallel_step_on_one_gpu():
     assert res[0][2] == res[1][2] and res[0][3] == res[1][3], "replicas diverged"
     assert res[0][4] == res[1][4] == 4
     assert np.isfinite(res[0][5]) and np.isfinite(res[1][5])
+
+
+def _sync_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hippie_amd import parallel, planner
+    from hippie_amd.engine import Engine
+    from oracle import cvae_oracle as O
+    z, L, B = 10, 50, 8
+    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, sync_bn_world=world))
+    om = O.OracleModel("unimodal", z, L, salt=3)
+    eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    x, src, cls, eps = O.synth_inputs(world * B, L, z, salt=9)
+    sl = slice(rank * B, (rank + 1) * B)
+    eng.set_inputs(x[sl].cuda(), src[sl].cuda(), None, eps[sl].cuda())
+    enc, mu, lv, rec = eng.forward(True)
+    eng.backward()
+    parallel.allreduce_mean_(eng.grads[: eng.plan.n_active])
+    torch.cuda.synchronize()
+    q.put((rank, enc.cpu().numpy(), rec.cpu().numpy(), {k: v.cpu().numpy() for k, v in eng.grad_dict().items()},
+           {k: v.cpu().numpy() for k, v in eng.state_dict().items() if "running" in k}))
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_two_ranks_equal_global_batch_oracle():
+    """Two ranks x 8 rows with sync-BatchNorm against the float64 oracle at 16 rows: forward rows, running
+    statistics and the all-reduced gradients (the DP path's parity test proper; criterion of tests/helpers.parity)."""
+    import re
+    from oracle import cvae_oracle as O
+    from tests import helpers as H
+    world, z, L, B = 2, 10, 50, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    x, src, cls, eps = O.synth_inputs(world * B, L, z, salt=9)
+    oms = [O.OracleModel("unimodal", z, L, salt=3, dtype=dt) for dt in (torch.float32, torch.float64)]
+    outs = []
+    for om, dt in zip(oms, (torch.float32, torch.float64)):
+        o = om.forward((x.to(dt), src, None), eps.to(dt), True)
+        om.losses((x.to(dt), src, None), o)[0].backward()
+        outs.append(o)
+    n = lambda t: t.detach().numpy()
+    for rank, enc, rec, grads, running in res:
+        sl = slice(rank * B, (rank + 1) * B)
+        H.parity(enc, n(outs[0][0])[sl], n(outs[1][0])[sl], f"rank {rank} enc")
+        H.parity(rec, n(outs[0][3])[sl], n(outs[1][3])[sl], f"rank {rank} rec")
+        for k, v in running.items():
+            np.testing.assert_allclose(v, oms[0].state[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+        g32, g64 = oms[0].grads(), oms[1].grads()
+        for k, g in g32.items():
+            if g is None or re.search(H.ZERO_GRAD_RE, k):
+                continue
+            H.grad_parity(grads[k], g.numpy(), g64[k].numpy(), flips=1, msg=f"rank {rank} grad {k}")
+    for k in res[0][3]:
+        np.testing.assert_array_equal(res[0][3][k], res[1][3][k])        # identical after the all-reduce

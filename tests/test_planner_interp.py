@@ -181,3 +181,74 @@ def test_backward_halves_commute_and_first_bucket_is_final(kind):
     # ... and nothing in front of the bucket has been touched by the first half except embeddings' rows
     first_dec = [k for k in plan.params if k.startswith("decoder_fc")][0]
     assert plan.params[first_dec].offset == lo
+
+
+def run_lockstep(plan, ops, arenas, seg):
+    """Data-parallel ranks in lock step on the interpreter: at every HP_OP_STATS_SYNC marker the slot is summed
+    over the ranks' arenas — what Engine.run does with an all-reduce in sync-BatchNorm mode."""
+    first, count = plan.ops.segments[seg]
+    cur = first
+    for k in range(first, first + count):
+        if int(ops[k]["op"]) == P.STATS_SYNC:
+            for A in arenas:
+                interp.run(ops, A, cur, k - cur)
+            n, ref = int(ops[k]["i"][0]), ops[k]["buf"][0]
+            views = [A.f64(ref, n) for A in arenas]
+            tot = np.sum(views, axis=0)
+            for v in views:
+                v[:] = tot
+            cur = k + 1
+    for A in arenas:
+        interp.run(ops, A, cur, first + count - cur)
+
+
+@pytest.mark.parametrize("kind", ["unimodal", "multimodal"])
+def test_sync_batchnorm_two_ranks_equal_the_global_batch_oracle(kind):
+    """TrainCfg(sync_bn_world=2): two ranks with B rows each must reproduce the single-process oracle at 2B rows
+    (forward rows, running statistics, and mean-over-ranks gradients) — torch.nn.SyncBatchNorm + DDP semantics."""
+    B, z, W = 4, 10, 2
+    L2 = 100 if kind == "multimodal" else None
+    cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=50, output_size2=L2 or 100)
+    plan = planner.lower(cfg, B, planner.TrainCfg(sync_bn_world=W), with_class=True)
+    ops = plan.ops.array()
+    assert sum(int(r["op"]) == P.STATS_SYNC for r in ops) > 80
+    om = O.OracleModel(kind, z, 50, output_size2=L2, salt=6)
+    om64 = O.OracleModel(kind, z, 50, output_size2=L2, salt=6, dtype=torch.float64)
+    x, src, cls, eps = O.synth_inputs(W * B, 50, z, salt=6, name="x1")
+    x2 = O.synth_inputs(W * B, 100, z, salt=6, name="x2")[0]
+    arenas = []
+    for r in range(W):
+        A = H.make_arenas(plan)
+        H.load_state(plan, A, om.state)
+        sl = slice(r * B, (r + 1) * B)
+        H.set_io(plan, A, "x", x[sl].numpy())
+        if kind == "multimodal":
+            H.set_io(plan, A, "x2", x2[sl].numpy())
+        for nm, v in (("src", src), ("cls", cls), ("eps", eps)):
+            H.set_io(plan, A, nm, v[sl].numpy())
+        arenas.append(A)
+    run_lockstep(plan, ops, arenas, "fwd_train")
+    run_lockstep(plan, ops, arenas, "bwd")
+    batch = (x, src, cls) if kind == "unimodal" else (x, x2, src, cls)
+    batch64 = tuple(t.double() if t.is_floating_point() else t for t in batch)
+    outs = om.forward(batch, eps, True)
+    om.losses(batch, outs)[0].backward()
+    outs64 = om64.forward(batch64, eps.double(), True)
+    om64.losses(batch64, outs64)[0].backward()
+    n = lambda t: t.detach().numpy()
+    for r, A in enumerate(arenas):
+        sl = slice(r * B, (r + 1) * B)
+        H.parity(H.get_io(plan, A, "enc_train"), n(outs[0])[sl], n(outs64[0])[sl], f"rank {r} enc")
+        H.parity(H.get_io(plan, A, "rec_train"), n(outs[3])[sl], n(outs64[3])[sl], f"rank {r} rec")
+    # running statistics: every rank holds the GLOBAL batch statistics (unbiased variance over W*M rows)
+    for A in arenas:
+        for k, v in H.read_bufs(plan, A).items():
+            np.testing.assert_allclose(v, om.state[k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+    grads = [H.read_params(plan, A, P.GRAD) for A in arenas]
+    og, og64 = om.grads(), om64.grads()
+    for k, g in og.items():
+        mine = (grads[0][k] + grads[1][k]) / 2          # the data-parallel gradient mean
+        if re.search(H.ZERO_GRAD_RE, k):
+            assert np.abs(mine).max() < 1e-5, k
+            continue
+        H.parity(mine, g.numpy(), og64[k].numpy(), "sync-BN DP grad " + k)
