@@ -295,6 +295,10 @@ def main():
     ap.add_argument("--time-len", type=int, default=100)
     ap.add_argument("--units", type=int, default=15631)
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: native libraries print there too (RCCL's version banner at
+    # communicator creation), so fd 1 is pointed at stderr for the run and the JSON goes to the saved descriptor
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     BATCH, Z_DIM, N_UNITS = args.batch, args.z_dim, max(args.units, args.batch * 2)
     rank = int(os.environ.get("RANK", "0"))
@@ -391,8 +395,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
-    if world > 1:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if world > 1 or force_dist:
         dist.barrier()
         dist.destroy_process_group()
 
