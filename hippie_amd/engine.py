@@ -214,6 +214,14 @@ class Engine:
             outs.append(self.io("rec2_" + mode))
         return tuple(outs)
 
+    def encode(self, use_graph=False):
+        """Eval-mode encoder half only ("enc_eval", a prefix of "fwd_eval"): (enc, mu, logvar) of
+        hippieUnimodalCVAE.encode (hippie/model.py:51-57) without running the decoder."""
+        self.run("enc_eval", use_graph)
+        z = self.cfg.z_dim
+        mulv = self.io("mulv_eval")
+        return self.io("enc_eval"), mulv[:, :z], mulv[:, z:]
+
     def backward(self, use_graph=False, overlap=False, after_first_half=None):
         """Backward pass (consumes the forward's gradient seeds in place: one backward per forward).
         overlap=True runs the decoder-side weight-gradient GEMMs ("wg_a") on a second HIP

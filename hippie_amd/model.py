@@ -152,6 +152,18 @@ class hippieUnimodalCVAE(_Net):
 
     __call__ = forward
 
+    def encode_labels(self, data, source_labels, class_labels=None):
+        """Eval-mode encoder half only -> (encoded, mu, logvar): what `encode` (model.py:51-57) returns, with the
+        embedding look-ups of `forward` (:65-66) included and the decoder skipped.  Same kernels and therefore the
+        same numbers as forward()[:3]; used by the embedding path, which keeps only `encoded`."""
+        if self.training:
+            raise RuntimeError("encode_labels() is the eval-mode fast path; call .eval() first (train mode needs the full forward)")
+        if data.shape[-1] != self.cfg.output_size:
+            raise ValueError(f"expected input length {self.cfg.output_size}, got {tuple(data.shape)}")
+        eng = self.engine(data.shape[0], class_labels is not None)
+        eng.set_inputs(data, source_labels, class_labels, eps=torch.zeros_like(eng.io("eps")))
+        return eng.encode()
+
 
 class MultiModalCVAE(_Net):
     """hippie/model.py:350-432."""
@@ -343,6 +355,14 @@ class hippieUnimodalEmbeddingModelCVAE(_TrainModule):
         return self.model(data, source_labels=src, class_labels=cls)
 
     __call__ = forward
+
+    def embed(self, batch):
+        """`self(batch)[0]` without the decoder when the module is in eval mode (full forward otherwise)."""
+        data, labels = batch
+        src, cls = self._split_labels(labels)
+        if self.model.training:
+            return self.model(data, source_labels=src, class_labels=cls)[0]
+        return self.model.encode_labels(data, src, cls)[0]
 
 
 class MultiModalCVAETrainModule(_TrainModule):

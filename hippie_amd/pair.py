@@ -57,8 +57,8 @@ def zip_programs(plan_a, plan_b):
     out, notes, segments = [], [], {}
     new_a, new_b = {}, {}
     for seg, (fa, ca) in plan_a.ops.segments.items():
-        if seg == "bwd":
-            continue                      # alias of bwd_a + wg_a + bwd_b + wg_b, rebuilt below
+        if seg in ("bwd", "enc_eval"):
+            continue                      # aliases (bwd = bwd_a + wg_a + bwd_b + wg_b; enc_eval = prefix of fwd_eval)
         fb, cb = plan_b.ops.segments[seg]
         start = len(out)
         same = ca == cb and all(int(ops_a[fa + k]["op"]) == int(ops_b[fb + k]["op"]) for k in range(ca))

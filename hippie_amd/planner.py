@@ -688,6 +688,10 @@ class Lowering:
                 self.linear_fwd(B, fc3, a1, 2 * z, encv, z, note="fusion_encoder.3")
             mulv = pl.f32(B * 2 * z, "mulv_" + mode, (B, 2 * z))
             self.linear_fwd(B, zml, encv, z, mulv, 2 * z, note="z_mean | z_log_var")
+            if not training:
+                # encoder-only prefix of the eval forward: (enc, mu, logvar) are complete here.  The embedding path
+                # (scripts/utils.py:75-101) keeps only `enc`, so the decoder (44-59 % of the FLOPs) can be skipped.
+                enc_eval_end = len(self.o.recs)
             zz = pl.f32(B * z)
             self.o.add(P.REPARAM_KL_FWD, 0, i=[B, z], buf=[mulv, eps, zz, loss], note="reparameterize + KL")
             ncat1 = z + 2 * H
@@ -720,6 +724,8 @@ class Lowering:
             self.count_flops = False
             if not training:
                 segs["eval_zero"] = zero_idx
+                f_eval = self.o.segments["fwd_eval"][0]
+                self.o.segments["enc_eval"] = (f_eval, enc_eval_end - f_eval)      # alias: prefix of fwd_eval
                 continue
             segs["train_zero"] = zero_idx
 

@@ -11,8 +11,9 @@ def get_embeddings(dataloader_wave, dataloader_time, wave_model, time_model):
     emb_w, emb_t = [], []
     for (wave, label_wave), (time, label_time) in zip(dataloader_wave, dataloader_time):
         assert (label_wave == label_time).all()
-        e_wave = wave_model((wave, label_wave))[0].clone()
-        e_time = time_model((time, label_time))[0].clone()
+        # only output[0] is used (scripts/utils.py:84-85): modules that offer it run the encoder half alone
+        e_wave = (wave_model.embed((wave, label_wave)) if hasattr(wave_model, "embed") else wave_model((wave, label_wave))[0]).clone()
+        e_time = (time_model.embed((time, label_time)) if hasattr(time_model, "embed") else time_model((time, label_time))[0]).clone()
         e_wave = (e_wave - e_wave.mean(dim=1)[:, None]) / e_wave.std(dim=1)[:, None]
         e_time = (e_time - e_time.mean(dim=1)[:, None]) / e_time.std(dim=1)[:, None]
         emb_w.append(e_wave)

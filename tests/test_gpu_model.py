@@ -146,3 +146,21 @@ def test_get_embeddings_matches_reference_fixture():
     np.testing.assert_allclose(ew, g["waveform"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(et, g["isi"], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(joint, g["joint"], rtol=1e-4, atol=1e-4)
+
+
+def test_encoder_only_path_equals_full_forward():
+    z, L, B = 10, 100, 37
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    net.load_state_dict({k: v.detach() for k, v in O.OracleModel("unimodal", z, L, salt=2).state.items()})
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3)
+    x, src, cls, _ = O.synth_inputs(B, L, z, salt=2)
+    batch = (x.cuda(), torch.stack([cls, src], 1).cuda())
+    with pytest.raises(RuntimeError, match="eval"):
+        net.encode_labels(batch[0], src.cuda())
+    mod.eval()
+    enc, mu, lv, _ = [t.clone() for t in mod(batch)]
+    e2, m2, l2 = [t.clone() for t in net.encode_labels(batch[0], src.cuda(), cls.cuda())]
+    assert torch.equal(enc, e2) and torch.equal(mu, m2) and torch.equal(lv, l2)
+    assert torch.equal(mod.embed(batch), enc)
+    seg = net.engine(B, True).plan.ops.segments
+    assert seg["enc_eval"][1] < 0.6 * seg["fwd_eval"][1]
