@@ -32,11 +32,6 @@ static TapMap tapmap_from(const HpOp& op) {
 // 16 bytes of zeros in device memory: padded / out-of-range rows load from here, so no select is needed
 __device__ __attribute__((aligned(16))) const float hp_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
-// per-component select (v_cndmask): a ternary on a whole float4 is lowered to a stack-array select
-__device__ __forceinline__ float4 mask4(const float4 v, bool ok) {
-  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
-
 // blockIdx -> tile id such that each XCD (blocks are dealt round-robin over the 8 XCDs)
 // owns one contiguous run of tile ids: the N-tiles that share an A row-panel then hit the
 // same L2.  Bijective for any nblk.  Speed only; correctness never depends on it.
@@ -47,12 +42,16 @@ __device__ __forceinline__ int xcd_remap(int id, int nblk) {
 
 // ------------------------------------------------------------------------------------
 // out[M][N] = sum_taps A[src(m,tap)][0:K] . Wslab[tap]   (+bias, +BN statistics)
-// 64x64 output tile per 256-thread workgroup, 2x2 waves of one 32x32 MFMA tile each,
-// K consumed 32 at a time through double-buffered LDS, global->register prefetch of the
-// next K-slice while the MFMAs of the current one run.
+// 64x64 output tile per 512-thread workgroup (8 waves: 4 quadrants of 32x32 x 2 K-halves),
+// K consumed 32 at a time through double-buffered LDS, global->register prefetch two
+// K-slices ahead of the MFMAs.
 // ------------------------------------------------------------------------------------
 struct ConvArgs {
   const float* A; const float* W; float* out; const float* bias; double* stats;
+  // eval-mode BatchNorm epilogue (flag 8): running statistics, optional residual tensor, optional leaky_relu
+  const float* gamma; const float* beta; const float* rmean; const float* rvar; const float* res;
+  float eps, slope;
+  int bn_eval, act;
   TapMap t;
 };
 
@@ -225,6 +224,28 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   const int n = n0 + wn * 32 + li;
   const bool nok = n < t.N;
   const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+  if (p.bn_eval) {
+    // forward-only path: BatchNorm1d in eval mode (+ residual, + leaky_relu) applied to the accumulators; the
+    // coefficients are formed exactly as bn_coef() does for HP_OP_BN_APPLY, so the result is bit-identical
+    float sc = 0.f, sh = 0.f;
+    if (nok) {
+      const double invstd = 1.0 / sqrt((double)p.rvar[n] + (double)p.eps);
+      const double scd = (double)p.gamma[n] * invstd;
+      sc = (float)scd;
+      sh = (float)((double)p.beta[n] - (double)p.rmean[n] * scd);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (nok && m < t.M) {
+        float v = fmaf(acc[r] + bv, sc, sh);
+        if (p.res != nullptr) v += p.res[(size_t)m * t.N + n];
+        if (p.act) v = lrelu(v, p.slope);
+        p.out[(size_t)m * t.N + n] = v;
+      }
+    }
+    return;
+  }
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -271,6 +292,15 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   a.out = hp::ptr<float>(op, 2, bases);
   a.bias = (op.flags & 2) ? hp::ptr<const float>(op, 3, bases) : nullptr;
   a.stats = (op.flags & 4) ? hp::ptr<double>(op, 4, bases) : nullptr;
+  a.bn_eval = (op.flags & 8) ? 1 : 0;
+  a.act = (op.flags & 16) ? 1 : 0;
+  a.gamma = a.beta = a.rmean = a.rvar = a.res = nullptr;
+  a.eps = op.f[0]; a.slope = op.f[1];
+  if (a.bn_eval) {
+    a.gamma = hp::ptr<const float>(op, 5, bases); a.beta = hp::ptr<const float>(op, 6, bases);
+    a.rmean = hp::ptr<const float>(op, 7, bases); a.rvar = hp::ptr<const float>(op, 8, bases);
+    a.res = hp::ptr<const float>(op, 9, bases);
+  }
   return a;
 }
 

@@ -54,6 +54,7 @@ class TrainCfg:
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
+    fold_eval_bn: bool = True           # eval forward: BatchNorm (+residual, +leaky_relu) folded into the producing conv's epilogue
     sync_bn_world: int = 0              # > 1: sync-BatchNorm over that many data-parallel ranks (HP_OP_STATS_SYNC markers)
     split_backward: bool = False        # emit the deferred wgrad GEMMs in two groups (decoder | encoder side) so that
                                         # Engine.backward(overlap=True) can run the first under the encoder-side chain
@@ -175,6 +176,7 @@ class Lowering:
         self.pl = Plan(cfg, batch, self.train, with_class)
         self.o = self.pl.ops
         self.pending_wgrads = []
+        self.conv_rec_of = {}                # encoded OUT ref -> index of the CONV_TAPS record that produced it
         self.count_flops = False          # forward FLOPs (2*MAC, conv + linear) are counted for the training forward only
 
     # ---- parameter declaration (own order; class_embedding last so that AdamW can skip it) ----
@@ -253,6 +255,7 @@ class Lowering:
     def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note=""):
         flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias is not None else 0) | (P.CONV_STATS if stats is not None else 0)
         self.o.add(P.CONV_TAPS, flags, i=tm.ints(), buf=[a, w.ref, out, bias.ref if bias is not None else None, stats], note=note)
+        self.conv_rec_of[out.encode()] = len(self.o.recs) - 1
         if self.count_flops and not w_kn:
             self.pl.flops_fwd += 2 * tm.M * tm.N * tm.K * len(tm.taps)
 
@@ -295,7 +298,61 @@ class Lowering:
         self.o.add(P.WGRAD_TAPS, 0, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, self.slab], note=note)
         self.o.add(P.SLAB_REDUCE, 0, i=[w.numel, nsplit, w.numel], buf=[self.slab, w.gref], note=note + " reduce")
 
+    def foldable(self, raw):
+        k = self.conv_rec_of.get(raw.encode())
+        return k is not None and int(self.o.recs[k]["op"]) == P.CONV_TAPS and not (int(self.o.recs[k]["flags"]) & P.CONV_BN_EVAL)
+
+    def order_shortcut_first(self, raw, res):
+        """The main conv's folded epilogue reads the NORMALISED shortcut, so the shortcut conv must run in an
+        earlier launch.  Encoder blocks already have that order (shortcut paired with conv1, BN2 follows conv2).
+        Decoder blocks emit [conv1, shortcut, PAIR] immediately before their BN: un-pair and swap those two."""
+        k_raw, k_res = self.conv_rec_of[raw.encode()], self.conv_rec_of[res.encode()]
+        if k_res < k_raw:
+            last = self.o.recs[-1]
+            paired_with_raw = int(last["op"]) == P.PAIR and k_raw in (int(last["i"][0]), int(last["i"][1]))
+            return not (paired_with_raw and k_res in (int(last["i"][0]), int(last["i"][1])))
+        n = len(self.o.recs)
+        if k_res != k_raw + 1:
+            return False
+        if k_res == n - 2 and int(self.o.recs[-1]["op"]) == P.PAIR and \
+                sorted((int(self.o.recs[-1]["i"][0]), int(self.o.recs[-1]["i"][1]))) == [k_raw, k_res]:
+            self.o.recs.pop()
+            self.o.notes.pop()
+            for k in (k_raw, k_res):
+                self.o.recs[k]["flags"] = int(self.o.recs[k]["flags"]) & ~P.FLAG_MEMBER
+        elif k_res != n - 1:
+            return False
+        self.o.recs[k_raw], self.o.recs[k_res] = self.o.recs[k_res], self.o.recs[k_raw]
+        self.o.notes[k_raw], self.o.notes[k_res] = self.o.notes[k_res], self.o.notes[k_raw]
+        self.conv_rec_of[raw.encode()], self.conv_rec_of[res.encode()] = k_res, k_raw
+        return True
+
+    def fold_bn_into_conv(self, raw, out, bn, act, slope, res):
+        """Eval mode: turn `conv -> raw; BN_APPLY(raw) -> out` into one conv launch with a BatchNorm epilogue
+        (HP_OP_CONV_TAPS flag 8).  Returns False when `raw` was not produced by a CONV_TAPS record."""
+        if not self.foldable(raw):
+            return False
+        k = self.conv_rec_of[raw.encode()]
+        r = self.o.recs[k]
+        r["flags"] = int(r["flags"]) | P.CONV_BN_EVAL | (P.CONV_ACT if act else 0)
+        r["buf"][2] = out.encode()
+        for j, ref in enumerate((bn["gamma"].ref, bn["beta"].ref, bn["rmean"].ref, bn["rvar"].ref)):
+            r["buf"][5 + j] = ref.encode()
+        r["buf"][9] = res.encode() if res is not None else P.NULL
+        r["f"][0], r["f"][1] = BN_EPS, slope
+        self.o.notes[k] += " + " + bn["prefix"] + " (eval BN folded)"
+        return True
+
     def bn_apply(self, M, bn, raw, out, stats, training, act, slope, res_mode=0, res=None, bn2=None, stats2=None):
+        if not training and self.train.fold_eval_bn:
+            if res_mode == 2:
+                # the shortcut conv normalises its own output in place, then it is a plain residual tensor
+                if self.foldable(res) and self.foldable(raw) and self.order_shortcut_first(raw, res):
+                    self.fold_bn_into_conv(res, res, bn2, False, slope, None)
+                    self.fold_bn_into_conv(raw, out, bn, act, slope, res)
+                    return
+            elif self.fold_bn_into_conv(raw, out, bn, act, slope, res if res_mode == 1 else None):
+                return
         save = self.pl.f32(2 * bn["C"])
         bn["save"] = save
         bufs = [raw, out, stats if training else None, bn["gamma"].ref, bn["beta"].ref, bn["rmean"].ref, bn["rvar"].ref, save]

@@ -81,8 +81,12 @@ enum {
    * the row mapping, and their input-gradients (ATen convolution_backward) with
    * transposed weights.  flags: 1 = weight slab is [K][N] (else [N][K]); 2 = bias;
    * 4 = accumulate per-column sum / sum of squares (fp64 atomics) into buf[4] for the
-   * following BatchNorm.  Requires K % 32 == 0 and N % 4 == 0 (every conv of the backbones: 64..512).
-   * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[HP_STAT_REPL][2][N]) */
+   * following BatchNorm;  8 = eval-mode BatchNorm1d folded into the epilogue (running statistics: the forward-only
+   * path has no batch-wide dependency, so conv + BN (+ residual tensor) (+ leaky_relu with flag 16) is one launch):
+   *   out = act( (acc + bias) * gamma/sqrt(rvar + f[0]) + (beta - rmean * gamma/sqrt(rvar + f[0])) + RES ),
+   * the same arithmetic, in the same order, as HP_OP_BN_APPLY in eval mode on this conv's output.  f[0]=eps f[1]=slope.
+   * Requires K % 32 == 0 and N % 4 == 0 (every conv of the backbones: 64..512).
+   * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[HP_STAT_REPL][2][N]), 5 GAMMA 6 BETA 7 RMEAN 8 RVAR 9 RES(or NULL) */
   HP_OP_CONV_TAPS = 1,
   /* slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]; f32 MFMA.
    * Replaces the weight-gradient half of ATen convolution_backward.

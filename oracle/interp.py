@@ -116,6 +116,14 @@ def run(ops, A: Arenas, first=0, count=None):
             out = acc.astype(np.float32)
             if flags & 2:
                 out = out + A.f32(b[3], N)[None, :]
+            if flags & 8:     # eval-mode BatchNorm (+ residual tensor, + leaky_relu with flag 16) folded into the epilogue
+                _, _, _, sc, sh = _bn_coef(A, False, M, N, NULL, b[5], b[6], b[7], b[8], f[0])
+                out = out * sc[None, :] + sh[None, :]
+                if int(b[9]) != NULL:
+                    out = out + A.f32(b[9], M * N).reshape(M, N)
+                if flags & 16:
+                    out = _lrelu(out, f[1])
+                out = out.astype(np.float32)
             A.f32(b[2], M * N)[:] = out.reshape(-1)
             if flags & 4:
                 st = A.f64(b[4], 2 * N)

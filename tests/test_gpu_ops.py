@@ -461,3 +461,26 @@ def test_wgrad_group_two_problems():
     gpu, cpu = run_program_both(img, ol.array())
     for g, numel in grads:
         check(gpu, cpu, g, numel, rel=3e-5, what="grouped wgrad")
+
+
+@pytest.mark.parametrize("with_res,act", [(False, True), (True, True), (True, False)])
+def test_conv_eval_bn_epilogue_equals_conv_then_bn_apply(with_res, act):
+    """CONV_TAPS flag 8 (eval BatchNorm folded into the epilogue) against the interpreter AND, bit for bit,
+    against the two-launch form conv -> BN_APPLY(eval) on the GPU."""
+    tm = TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(t - 1, t) for t in range(3)])
+    M, N, K = tm.M, tm.N, tm.K
+    img = Img(5)
+    a, w = img.f32(B * 25 * K), img.f32(3 * N * K, 0.05)
+    gamma, beta, rmean = img.f32(N, 0.5), img.f32(N, 0.2), img.f32(N, 0.3)
+    rvar = img._put((np.abs(img.rng.standard_normal(N)) + 0.5).astype(np.float32))
+    res = img.f32(M * N)
+    out_f, raw, out_2, save = img.f32(M * N, zero=True), img.f32(M * N, zero=True), img.f32(M * N, zero=True), img.f32(2 * N, zero=True)
+    ol = P.OpList()
+    ol.add(P.CONV_TAPS, P.CONV_BN_EVAL | (P.CONV_ACT if act else 0), tm.ints(), [1e-5, 0.01],
+           [a, w, out_f, None, None, gamma, beta, rmean, rvar, res if with_res else None])
+    ol.add(P.CONV_TAPS, 0, tm.ints(), (), [a, w, raw, None, None])
+    ol.add(P.BN_APPLY, 0, [M, N, 1 if with_res else 0, 0, 1 if act else 0], [0.01, 1e-5, 0.1],
+           [raw, out_2, None, gamma, beta, rmean, rvar, save] + ([res] if with_res else []))
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, out_f, M * N, rel=3e-5, what="fused conv+BN vs interpreter")
+    assert np.array_equal(view(gpu, out_f, np.float32, M * N), view(gpu, out_2, np.float32, M * N)), "fused != conv -> BN_APPLY"
