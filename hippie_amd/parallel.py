@@ -29,6 +29,9 @@ def shard_indices(n, rank, world, epoch=0, seed=0, shuffle=True, drop_last=False
     return perm[rank:total:world]
 
 
+_NCCL_AVG = [True]
+
+
 def allreduce_mean_(flat_grads, group=None, buckets=1):
     """In-place mean over ranks of a flat gradient arena (works on any backend: nccl = RCCL on ROCm,
     gloo on CPU).  `buckets` > 1 splits the arena so that the collective of one bucket can overlap
@@ -41,11 +44,14 @@ def allreduce_mean_(flat_grads, group=None, buckets=1):
     backend = dist.get_backend(group)
     for lo in range(0, n, step):
         chunk = flat_grads[lo: lo + step]
-        if backend == "nccl":
-            dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=group)
-        else:
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=group)
-            chunk.div_(world)
+        if backend == "nccl" and _NCCL_AVG[0]:
+            try:
+                dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=group)
+                continue
+            except RuntimeError:                      # an RCCL build without ncclAvg: sum and scale instead
+                _NCCL_AVG[0] = False
+        dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=group)
+        chunk.div_(world)
     return flat_grads
 
 
