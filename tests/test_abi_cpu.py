@@ -97,3 +97,12 @@ def test_product_never_imports_oracle():
     for path in glob.glob(os.path.join(ROOT, "hippie_amd", "*.py")) + glob.glob(os.path.join(ROOT, "scripts", "*.py")):
         src = open(path).read()
         assert "import oracle" not in src and "from oracle" not in src, path
+
+
+def test_graft_entry_build_runs():
+    """The driver's build check: __graft_entry__.build() must compile, load the library and accept its ABI."""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = importlib.import_module("__graft_entry__")
+    g.build()
