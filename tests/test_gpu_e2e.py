@@ -355,3 +355,76 @@ def test_overlapped_backward_equals_serial():
         eng.backward(use_graph, overlap=True, after_first_half=lambda s: seen.append(eng.grads[lo:hi].clone()))
         torch.cuda.synchronize()
         assert (seen[0] - want[lo:hi]).abs().max() <= 2e-5 * scale, "bucket A not final after the first half"
+
+
+def test_eval_rows_are_independent_of_batch_composition_at_config3_size():
+    """BASELINE config 3's shape (batch 4096, L=256, z=32) is too large for the CPU oracle in a test, but the
+    eval forward has a size-independent property: a unit's outputs do not depend on which other units share
+    its batch.  The full batch must reproduce four quarter batches bit for bit (same kernels, same K order)."""
+    B, L, z = 4096, 256, 32
+    torch.manual_seed(0)
+    cfg = planner.ModelCfg("unimodal", z, L)
+    big = Engine(cfg, B)
+    om = O.OracleModel("unimodal", z, L, salt=11)
+    big.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    small = Engine(cfg, B // 4, share_params_from=big)
+    x = torch.randn(B, 1, L, device="cuda")
+    src = torch.randint(1, 5, (B,), device="cuda")
+    eps = torch.randn(B, z, device="cuda")
+    big.set_inputs(x, src, None, eps)
+    full = [t.clone() for t in big.forward(False)]
+    for q in range(4):
+        sl = slice(q * B // 4, (q + 1) * B // 4)
+        small.set_inputs(x[sl], src[sl], None, eps[sl])
+        part = small.forward(False)
+        for a, b in zip(full, part):
+            assert torch.equal(a[sl], b), "eval output of a unit depends on its batch"
+    assert all(torch.isfinite(t).all() for t in full)
+
+
+def test_train_forward_is_permutation_equivariant_at_full_batch():
+    """Batch 512 (the headline size), train mode: permuting the units permutes the outputs and leaves the
+    loss scalars and the BatchNorm running statistics unchanged (up to the order of the fp64 statistic sums)."""
+    B, L, z = 512, 100, 10
+    eng = Engine(planner.ModelCfg("unimodal", z, L), B)
+    om = O.OracleModel("unimodal", z, L, salt=12)
+    sd = {k: v.detach() for k, v in om.state.items()}
+    x, src, _, eps = O.synth_inputs(B, L, z, salt=12)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(3))
+    res = []
+    for p in (torch.arange(B), perm):
+        eng.load_state_dict(sd)
+        eng.set_inputs(x[p].cuda(), src[p].cuda(), None, eps[p].cuda())
+        outs = [t.clone().cpu() for t in eng.forward(True)]
+        res.append((outs, eng.scalars(), {k: v.cpu() for k, v in eng.state_dict().items() if "running" in k}))
+    (o0, s0, r0), (o1, s1, r1) = res
+    for a, b in zip(o0, o1):
+        scale = float(a.abs().max())
+        assert float((a[perm] - b).abs().max()) <= 2e-6 * max(scale, 1.0)
+    np.testing.assert_allclose(s0, s1, rtol=1e-6)
+    for k in r0:
+        np.testing.assert_allclose(r0[k].numpy(), r1[k].numpy(), rtol=1e-6, atol=1e-7, err_msg=k)
+
+
+def test_grouped_atomic_wgrad_equals_ordered_slab_reduction_at_full_batch():
+    """Batch 512: the default weight-gradient path (one grouped launch, fp32 atomics, longest blocks first) against
+    the deterministic one (per-conv launches writing slabs, reduced in order): two independent implementations of
+    the same sums at the headline size."""
+    B, L, z = 512, 100, 10
+    om = O.OracleModel("unimodal", z, L, salt=13)
+    sd = {k: v.detach() for k, v in om.state.items()}
+    x, src, _, eps = O.synth_inputs(B, L, z, salt=13)
+    grads = []
+    for det in (False, True):
+        eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(deterministic_wgrad=det))
+        eng.load_state_dict(sd)
+        eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+        eng.forward(True)
+        eng.backward()
+        torch.cuda.synchronize()
+        grads.append({k: v.cpu().double() for k, v in eng.grad_dict().items()})
+    for k, g in grads[1].items():
+        if re.search(H.ZERO_GRAD_RE, k) or float(g.abs().max()) == 0.0:
+            continue
+        err = float((grads[0][k] - g).abs().max()) / float(g.abs().max())
+        assert err <= 5e-5, (k, err)
