@@ -428,3 +428,12 @@ def test_grouped_atomic_wgrad_equals_ordered_slab_reduction_at_full_batch():
             continue
         err = float((grads[0][k] - g).abs().max()) / float(g.abs().max())
         assert err <= 5e-5, (k, err)
+
+
+@pytest.mark.parametrize("B,L", [(1, 50), (1, 5), (7, 2), (3, 1)])
+def test_eval_forward_extreme_shapes(B, L):
+    """Single-unit batches (legal in eval mode; train mode raises like torch's BatchNorm) and inputs so short that
+    the stride-2 stages bottom out at length 1."""
+    z = 10
+    eng, oms, batch, batch64, eps = build("unimodal", z, L, B, False, 1.0, 0.0, 1e-3, 50 + L)
+    check_forward(eng, oms, batch, batch64, eps, training=False)
