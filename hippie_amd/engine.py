@@ -223,7 +223,8 @@ class Engine:
         return self.io("enc_eval"), mulv[:, :z], mulv[:, z:]
 
     def backward(self, use_graph=False, overlap=False, after_first_half=None):
-        """Backward pass (consumes the forward's gradient seeds in place: one backward per forward).
+        """Backward pass.  Exactly one per training forward: its BatchNorm reductions accumulate into the fp64
+        statistic slots that the forward's first op zeroes, so a second backward would double them.
         overlap=True runs the decoder-side weight-gradient GEMMs ("wg_a") on a second HIP
         stream underneath the encoder-side chain ("bwd_b"): the chain is latency-bound (one small launch after
         another), the grouped GEMM fills the CUs it leaves idle.  `after_first_half(side_stream)` is called

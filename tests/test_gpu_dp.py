@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
         ok_grad &= bool(torch.allclose(eng.grads[: eng.plan.n_active], want[: eng.plan.n_active], rtol=1e-6, atol=1e-8))
         # the overlapped, two-bucket path (side stream + all-reduce under the encoder-side chain) gives the same
         # mean up to the summation order of the fp32 atomics in the weight-gradient GEMMs
-        eng.forward(True, True)              # the backward pass consumes its inputs in place: stage them again
+        eng.forward(True, True)              # one backward per forward (the BN-backward statistic slots are zeroed by the forward): run it again
         parallel.backward_allreduce(eng, None, True, overlap=True)
         torch.cuda.synchronize()
         got, ref = eng.grads[: eng.plan.n_active], want[: eng.plan.n_active]

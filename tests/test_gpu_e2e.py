@@ -344,7 +344,7 @@ def test_overlapped_backward_equals_serial():
         eng.backward(use_graph)
         torch.cuda.synchronize()
         want = eng.grads.clone()
-        eng.forward(True, use_graph)          # backward consumes gradient buffers in place: stage a fresh forward
+        eng.forward(True, use_graph)          # one backward per forward (the BN-backward statistic slots are zeroed by the forward)
         eng.backward(use_graph, overlap=True)
         torch.cuda.synchronize()
         scale = want.abs().max()
