@@ -58,42 +58,12 @@ struct ConvArgs {
 constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
 constexpr int kConvThreads = 512;
 
-// ---- split-bf16 variant (HP_OP_CONV_TAPS flag 32) ------------------------------------------------------
-// fp32 operands are split on the way into LDS into three bf16 planes, x = hi + mid + lo (24 mantissa bits in all),
-// and the six cross products of order <= 2 are formed on the bf16 matrix pipe with fp32 accumulation:
-// (mid*mid + hi*lo + lo*hi) into one accumulator, (hi*mid + mid*hi + hi*hi) into the other.  The dropped terms are
-// O(2^-24) relative, i.e. the result is fp32-accurate (tools/micro/bf16x3_gemm.hip: 1.96e-6 vs 1.36e-6 for an fp32
-// fma chain at K = 1536) while a 16-wide K block costs 6 x 8 passes instead of 8 x 16.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef unsigned short u16;
-constexpr int kB3Ld = 40;                  // bf16 per LDS row: 32 + 8 (80-byte rows: 16-byte aligned ds_read_b128)
-constexpr int kB3Plane = 64 * kB3Ld;       // one plane of one operand
-constexpr int kB3Operand = 3 * kB3Plane;   // hi | mid | lo
-constexpr int kB3Stage = 2 * kB3Operand;   // A | B
-constexpr int kConvLdsB3 = 2 * kB3Stage / 2;   // floats (u16 count / 2): two stages = 61 440 bytes
-
-__device__ __forceinline__ void split3(const float x, __bf16& h, __bf16& m, __bf16& l) {
-  h = (__bf16)x;                           // v_cvt_pk_bf16_f32: round to nearest even
-  const float r1 = x - (float)h;           // exact
-  m = (__bf16)r1;
-  const float r2 = r1 - (float)m;          // exact
-  l = (__bf16)r2;
-}
-__device__ __forceinline__ void split3x4(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
-  __bf16 a, b, c;
-  split3(v.x, a, b, c); h[0] = a; m[0] = b; l[0] = c;
-  split3(v.y, a, b, c); h[1] = a; m[1] = b; l[1] = c;
-  split3(v.z, a, b, c); h[2] = a; m[2] = b; l[2] = c;
-  split3(v.w, a, b, c); h[3] = a; m[3] = b; l[3] = c;
-}
-
 // One 64x64 output tile per 512-thread workgroup: 8 waves = 4 tile quadrants (32x32 MFMA tiles) x 2 K-halves.
 // The two waves that share a quadrant each take half of every 32-wide K slice (two 8-wide groups) and
 // sit on the same SIMD pair-wise, so one wave's global loads / LDS traffic / address arithmetic overlap
 // the other's MFMAs — at batch 512 a layer has only ~256 tiles for 1024 SIMDs, so this is the only way to
 // get two waves per SIMD.  Their partial accumulators are summed once, through LDS, in the epilogue.
-template <bool W_KN, bool BF3 = false>
+template <bool W_KN>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
   constexpr int LDBK = 68;   // [k][n] image row stride
@@ -162,31 +132,6 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     return r;
   };
   auto stash = [&](int buf, const Pref r) {
-    if (BF3) {
-      u16* A3 = reinterpret_cast<u16*>(smem) + buf * kB3Stage;
-      u16* B3 = A3 + kB3Operand;
-      bf16x4 h, m, l;
-      split3x4(r.a, h, m, l);
-      *reinterpret_cast<bf16x4*>(A3 + 0 * kB3Plane + ar * kB3Ld + aq) = h;
-      *reinterpret_cast<bf16x4*>(A3 + 1 * kB3Plane + ar * kB3Ld + aq) = m;
-      *reinterpret_cast<bf16x4*>(A3 + 2 * kB3Plane + ar * kB3Ld + aq) = l;
-      split3x4(r.b, h, m, l);
-      if (!W_KN) {
-        *reinterpret_cast<bf16x4*>(B3 + 0 * kB3Plane + ar * kB3Ld + aq) = h;
-        *reinterpret_cast<bf16x4*>(B3 + 1 * kB3Plane + ar * kB3Ld + aq) = m;
-        *reinterpret_cast<bf16x4*>(B3 + 2 * kB3Plane + ar * kB3Ld + aq) = l;
-      } else {
-        // the [k][n] weight row is transposed on the way in: the MFMA wants 8 consecutive k per lane
-        __bf16* Bt = reinterpret_cast<__bf16*>(B3);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          Bt[0 * kB3Plane + (nq + j) * kB3Ld + kr] = h[j];
-          Bt[1 * kB3Plane + (nq + j) * kB3Ld + kr] = m[j];
-          Bt[2 * kB3Plane + (nq + j) * kB3Ld + kr] = l[j];
-        }
-      }
-      return;
-    }
     float* As = smem + buf * TILE;
     float* Bs = smem + 2 * TILE + buf * TILE;
     *reinterpret_cast<float4*>(As + ar * LDA + aq) = r.a;
@@ -209,29 +154,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   // FETCH / STASH are compile-time: the steady-state loop has no conditions, so the compiler's vmcnt
   // bookkeeping stays exact (a merged "maybe pending" path costs a full drain).
 #define HP_KSTEP(BUF, ST, LD, FETCH, STASH)                                                             \
-  if (BF3) {                                                                                            \
-    const u16* A3 = reinterpret_cast<const u16*>(smem) + (BUF) * kB3Stage + (wm * 32 + li) * kB3Ld + kh * 16 + lh * 8;              \
-    const u16* B3 = reinterpret_cast<const u16*>(smem) + (BUF) * kB3Stage + kB3Operand + (wn * 32 + li) * kB3Ld + kh * 16 + lh * 8; \
-    bf16x8 a3[3], b3[3];                                                                                \
-    _Pragma("unroll") for (int pp = 0; pp < 3; ++pp) {                                                  \
-      a3[pp] = *reinterpret_cast<const bf16x8*>(A3 + pp * kB3Plane);                                    \
-      b3[pp] = *reinterpret_cast<const bf16x8*>(B3 + pp * kB3Plane);                                    \
-    }                                                                                                   \
-    if (FETCH) {                                                                                        \
-      LD.a = *reinterpret_cast<const float4*>(pa);                                                      \
-      LD.b = *reinterpret_cast<const float4*>(pb);                                                      \
-      __builtin_amdgcn_sched_barrier(0);                                                                \
-    }                                                                                                   \
-    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[1], acc2[0], 0, 0, 0);                  \
-    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[2], acc2[0], 0, 0, 0);                  \
-    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[2], b3[0], acc2[0], 0, 0, 0);                  \
-    if (FETCH) { advance(); }                                                                           \
-    if (STASH) { stash((BUF) ^ 1, ST); }                                                                \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[1], acc2[1], 0, 0, 0);                  \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[1], b3[0], acc2[1], 0, 0, 0);                  \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[0], b3[0], acc2[1], 0, 0, 0);                  \
-    __syncthreads();                                                                                    \
-  } else {                                                                                              \
+  {                                                                                                     \
     const float* As = smem + (BUF) * TILE + (wm * 32 + li) * LDA + lh * 4 + kh * 16;                    \
     const float* Bs = smem + 2 * TILE + (BUF) * TILE;                                                   \
     float4 a4[2], b4[2];                                                                                \
@@ -361,18 +284,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_taps_pair_kernel(ConvArgs a
   else conv_body<W_KN>(b, blockIdx.x - nblk_a, smem);
 }
 
-template <bool W_KN>
-__global__ __launch_bounds__(kConvThreads) void conv_taps_b3_kernel(ConvArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLdsB3];
-  conv_body<W_KN, true>(p, blockIdx.x, smem);
-}
-template <bool W_KN>
-__global__ __launch_bounds__(kConvThreads) void conv_taps_pair_b3_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLdsB3];
-  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, true>(a, blockIdx.x, smem);
-  else conv_body<W_KN, true>(b, blockIdx.x - nblk_a, smem);
-}
-
 static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   ConvArgs a;
   a.t = tapmap_from(op);
@@ -397,12 +308,6 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
   if ((opa.flags & 1) != (opb.flags & 1)) return hipErrorInvalidValue;
   const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
   const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
-  if ((opa.flags & 32) != (opb.flags & 32)) return hipErrorInvalidValue;
-  if (opa.flags & 32) {
-    if (opa.flags & 1) hipLaunchKernelGGL(conv_taps_pair_b3_kernel<true>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
-    else               hipLaunchKernelGGL(conv_taps_pair_b3_kernel<false>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
-    return hipGetLastError();
-  }
   if (opa.flags & 1) hipLaunchKernelGGL(conv_taps_pair_kernel<true>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
   else               hipLaunchKernelGGL(conv_taps_pair_kernel<false>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
   return hipGetLastError();
@@ -411,11 +316,6 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
 hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
   const ConvArgs a = conv_args_from(op, bases);
   const int nblk = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64);
-  if (op.flags & 32) {
-    if (op.flags & 1) hipLaunchKernelGGL(conv_taps_b3_kernel<true>, dim3(nblk), dim3(kConvThreads), 0, s, a);
-    else              hipLaunchKernelGGL(conv_taps_b3_kernel<false>, dim3(nblk), dim3(kConvThreads), 0, s, a);
-    return hipGetLastError();
-  }
   if (op.flags & 1) hipLaunchKernelGGL(conv_taps_kernel<true>, dim3(nblk), dim3(kConvThreads), 0, s, a);
   else              hipLaunchKernelGGL(conv_taps_kernel<false>, dim3(nblk), dim3(kConvThreads), 0, s, a);
   return hipGetLastError();

@@ -54,7 +54,6 @@ class TrainCfg:
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
-    mfma: str = "f32"                   # "f32": v_mfma_f32_32x32x2_f32 | "bf16x3": fp32 emulated by a 3-way bf16 split (CONV_TAPS flag 32)
     fold_eval_bn: bool = True           # eval forward: BatchNorm (+residual, +leaky_relu) folded into the producing conv's epilogue
     sync_bn_world: int = 0              # > 1: sync-BatchNorm over that many data-parallel ranks (HP_OP_STATS_SYNC markers)
     split_backward: bool = False        # emit the deferred wgrad GEMMs in two groups (decoder | encoder side) so that
@@ -255,10 +254,6 @@ class Lowering:
     # ---- op emitters --------------------------------------------------------------
     def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note=""):
         flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias is not None else 0) | (P.CONV_STATS if stats is not None else 0)
-        if self.train.mfma == "bf16x3":
-            flags |= P.CONV_SPLIT_BF16
-        elif self.train.mfma != "f32":
-            raise ValueError(f"unknown mfma mode {self.train.mfma!r}")
         self.o.add(P.CONV_TAPS, flags, i=tm.ints(), buf=[a, w.ref, out, bias.ref if bias is not None else None, stats], note=note)
         self.conv_rec_of[out.encode()] = len(self.o.recs) - 1
         if self.count_flops and not w_kn:

@@ -29,7 +29,7 @@ assert OP_DTYPE.itemsize == 280
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
-CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_SPLIT_BF16 = 1, 2, 4, 8, 16, 32
+CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT = 1, 2, 4, 8, 16
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP launch
 
 

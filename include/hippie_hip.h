@@ -85,8 +85,6 @@ enum {
    * path has no batch-wide dependency, so conv + BN (+ residual tensor) (+ leaky_relu with flag 16) is one launch):
    *   out = act( (acc + bias) * gamma/sqrt(rvar + f[0]) + (beta - rmean * gamma/sqrt(rvar + f[0])) + RES ),
    * the same arithmetic, in the same order, as HP_OP_BN_APPLY in eval mode on this conv's output.  f[0]=eps f[1]=slope.
-   * 32 = form the products on the bf16 matrix pipe from a 3-way bf16 split of both fp32 operands (hi+mid+lo, the six
-   * cross products of order <= 2, fp32 accumulation): fp32-accurate (dropped terms O(2^-24)), 2.7x less MFMA time.
    * Requires K % 32 == 0 and N % 4 == 0 (every conv of the backbones: 64..512).
    * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[HP_STAT_REPL][2][N]), 5 GAMMA 6 BETA 7 RMEAN 8 RVAR 9 RES(or NULL) */
   HP_OP_CONV_TAPS = 1,

@@ -106,9 +106,8 @@ CONV_CASES = {
 }
 
 
-@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("name", list(CONV_CASES))
-def test_conv_taps(name, split):
+def test_conv_taps(name):
     tm, w_kn, bias = CONV_CASES[name]()
     img = Img(1)
     nb = tm.M // tm.Lout
@@ -118,7 +117,7 @@ def test_conv_taps(name, split):
     out = img.f32(tm.M * tm.N, zero=True)
     bv = img.f32(tm.N) if bias else None
     st = img.f64(R * 2 * tm.N)
-    flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_STATS | (P.CONV_SPLIT_BF16 if split else 0)
+    flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_STATS
     recs = rec_of(P.CONV_TAPS, flags, tm.ints(), (), [a, w, out, bv, st])
     gpu, cpu = run_both(img, recs)
     check(gpu, cpu, out, tm.M * tm.N, what=name + " out")

@@ -10,7 +10,7 @@ from hippie_amd import program as P
 from hippie_amd.program import DeviceProgram, OpList, Ref, TapMap
 
 
-def bench(M, N, K, L, w_kn=False, dbg=0, reps=30, stats=False, split=False):
+def bench(M, N, K, L, w_kn=False, dbg=0, reps=30, stats=False):
     tm = TapMap(M, N, K, L, L, L, 1, 0, 0, [(t - 1, t) for t in range(3)])
     a = torch.randn(M * K, device="cuda")
     w = torch.randn(3 * N * K, device="cuda") * 0.05
@@ -21,7 +21,7 @@ def bench(M, N, K, L, w_kn=False, dbg=0, reps=30, stats=False, split=False):
     rs = Ref(P.WS, 4 * (M * K + 3 * N * K + M * N))
     ol = OpList()
     for _ in range(reps):
-        ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | (P.CONV_STATS if stats else 0) | (P.CONV_SPLIT_BF16 if split else 0), tm.ints(), (),
+        ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | (P.CONV_STATS if stats else 0), tm.ints(), (),
                [ra, rw, ro, None, rs if stats else None])
     dummy = torch.zeros(16, device="cuda")
     prog = DeviceProgram(ol.array(), [ws.data_ptr()] + [dummy.data_ptr()] * 5, [ws.numel() * 4] + [64] * 5)
@@ -32,12 +32,6 @@ def bench(M, N, K, L, w_kn=False, dbg=0, reps=30, stats=False, split=False):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "split":
-        for (M, N, K, L) in ((25600, 64, 64, 50), (12800, 128, 128, 25), (6656, 256, 256, 13), (3584, 512, 512, 7), (2048, 512, 512, 4)):
-            for kn in (False, True):
-                t = [bench(M, N, K, L, kn, split=sp) for sp in (False, True)]
-                print(f"M={M} N={N} K={K} w_kn={int(kn)}: f32 {t[0][0]:6.1f} us {t[0][1]:6.1f} TF | bf16x3 {t[1][0]:6.1f} us {t[1][1]:6.1f} TF (fp32-equivalent)", flush=True)
-        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stats":
         for (M, N, K, L) in ((25600, 64, 64, 50), (12800, 128, 128, 25), (6656, 256, 256, 13), (3584, 512, 512, 7), (2048, 512, 512, 4)):
             for st in (False, True):
