@@ -1,0 +1,27 @@
+"""Soak / convergence check: train both models for many steps on the synthetic pool and print the loss trend."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+dev = torch.device("cuda", 0)
+data = bench.synth_dataset(bench.N_UNITS, dev)
+pair = bench.Pair(dev, 1)
+g = torch.Generator().manual_seed(1)
+hist = []
+pair.fork()
+for i in range(steps):
+    idx = torch.randperm(bench.N_UNITS, generator=g)[: bench.BATCH].to(dev)
+    pair.step(data, idx, True)
+    if i % (steps // 15) == 0 or i == steps - 1:
+        pair.join(); torch.cuda.synchronize()
+        sc = [e.scalars() for e in pair.eng]
+        hist.append((i, sc))
+        print(f"step {i:5d}  wave loss {sc[0][0]:9.5f} (mse {sc[0][1]:.5f} kl {sc[0][3]:.5f})   time loss {sc[1][0]:9.5f} (mse {sc[1][1]:.5f} kl {sc[1][3]:.5f})", flush=True)
+        pair.fork()
+pair.join(); torch.cuda.synchronize()
+ok = all(torch.isfinite(e.params).all().item() for e in pair.eng)
+print("finite parameters:", ok, " adam steps:", [e.adam_step for e in pair.eng])
+assert ok and hist[-1][1][0][0] < 0.5 * hist[0][1][0][0] and hist[-1][1][1][0] < 0.5 * hist[0][1][1][0]
+print("soak ok")
