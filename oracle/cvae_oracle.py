@@ -242,16 +242,53 @@ def synth_inputs(batch, length, z_dim, num_sources=5, num_classes=5, salt=0, dty
 # --------------------------------------------------------------------------
 # functional forward
 # --------------------------------------------------------------------------
-class Ctx:
-    """training flag + optional tap dict collecting named intermediates."""
+class _MaskedLeakyReLU(torch.autograd.Function):
+    """leaky_relu whose branch is chosen by an injected boolean mask instead of sign(x), forward and backward.
 
-    def __init__(self, training=True, taps=None):
+    Why: the loss gradient is discontinuous in the sign of every leaky-ReLU input.  Where an activation is
+    closer to zero than float32 resolves, two correct float32 implementations can land on different sides,
+    and every gradient upstream of that element then differs at the 1e-3..1e-2 level.  Forcing the oracle
+    onto the branch the implementation under test actually took removes that ambiguity: the comparison is
+    then between two evaluations of the SAME piecewise-linear function, and the 1e-4 bar applies to every
+    gradient.  (The forward value changes by |x|*(1-slope) at a flipped element, i.e. by rounding noise.)"""
+
+    @staticmethod
+    def forward(ctx, x, mask, slope):
+        ctx.save_for_backward(mask)
+        ctx.slope = slope
+        return torch.where(mask, x, x * slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return torch.where(mask, g, g * ctx.slope), None, None
+
+
+class Ctx:
+    """training flag + optional tap dict collecting named intermediates + optional injected leaky-ReLU masks
+    ({site name -> bool tensor of the activation's shape}; sites are the tap names of the activations)."""
+
+    def __init__(self, training=True, taps=None, masks=None):
         self.training = training
         self.taps = taps
+        self.masks = masks
+        self.sites = []
 
     def tap(self, name, t):
         if self.taps is not None:
             self.taps[name] = t
+
+    def lrelu(self, name, x, slope):
+        """F.leaky_relu at the named site (backbones.py:37,40,66,69,95; nn.LeakyReLU(0.2) in model.py:24,27,37,40)."""
+        self.sites.append(name)
+        if self.masks is not None:
+            m = self.masks[name]
+            assert m.shape == x.shape and m.dtype == torch.bool, (name, tuple(m.shape), tuple(x.shape))
+            out = _MaskedLeakyReLU.apply(x, m, slope)
+        else:
+            out = F.leaky_relu(x, slope)
+        self.tap(name, out)
+        return out
 
 
 def batch_norm(P, prefix, x, ctx):
@@ -267,23 +304,20 @@ def resize_conv(P, prefix, x, scale):
 
 
 def enc_block(P, p, x, stride, ctx):
-    out = F.leaky_relu(batch_norm(P, p + "bn1", F.conv1d(x, P[p + "conv1.weight"], None, stride, 1), ctx), SLOPE_BACKBONE)
-    ctx.tap(p + "bn1", out)
+    out = ctx.lrelu(p + "bn1", batch_norm(P, p + "bn1", F.conv1d(x, P[p + "conv1.weight"], None, stride, 1), ctx), SLOPE_BACKBONE)
     out = batch_norm(P, p + "bn2", F.conv1d(out, P[p + "conv2.weight"], None, 1, 1), ctx)
     if stride == 1:
         sc = x
     else:
         sc = batch_norm(P, p + "shortcut.1", F.conv1d(x, P[p + "shortcut.0.weight"], None, stride, 0), ctx)
-    out = F.leaky_relu(out + sc, SLOPE_BACKBONE)
+    out = ctx.lrelu(p + "bn2", out + sc, SLOPE_BACKBONE)
     ctx.tap(p + "out", out)
-    ctx.tap(p + "bn2", out)
     return out
 
 
 def enc_forward(P, prefix, x, ctx):
-    x = F.leaky_relu(batch_norm(P, prefix + "bn1", F.conv1d(x, P[prefix + "conv1.weight"], None, 2, 1), ctx), SLOPE_BACKBONE)
+    x = ctx.lrelu(prefix + "bn1", batch_norm(P, prefix + "bn1", F.conv1d(x, P[prefix + "conv1.weight"], None, 2, 1), ctx), SLOPE_BACKBONE)
     ctx.tap(prefix + "stem", x)
-    ctx.tap(prefix + "bn1", x)
     for li in (1, 2, 3, 4):
         for bi in (0, 1):
             stride = 2 if (bi == 0 and li > 1) else 1
@@ -293,17 +327,15 @@ def enc_forward(P, prefix, x, ctx):
 
 
 def dec_block(P, p, x, stride, ctx):
-    out = F.leaky_relu(batch_norm(P, p + "bn2", F.conv1d(x, P[p + "conv2.weight"], None, 1, 1), ctx), SLOPE_BACKBONE)
-    ctx.tap(p + "bn2", out)
+    out = ctx.lrelu(p + "bn2", batch_norm(P, p + "bn2", F.conv1d(x, P[p + "conv2.weight"], None, 1, 1), ctx), SLOPE_BACKBONE)
     if stride == 1:
         out = batch_norm(P, p + "bn1", F.conv1d(out, P[p + "conv1.weight"], None, 1, 1), ctx)
         sc = x
     else:
         out = batch_norm(P, p + "bn1", resize_conv(P, p + "conv1", out, stride), ctx)
         sc = batch_norm(P, p + "shortcut.1", resize_conv(P, p + "shortcut.0", x, stride), ctx)
-    out = F.leaky_relu(out + sc, SLOPE_BACKBONE)
+    out = ctx.lrelu(p + "bn1", out + sc, SLOPE_BACKBONE)
     ctx.tap(p + "out", out)
-    ctx.tap(p + "bn1", out)
     return out
 
 
@@ -336,18 +368,14 @@ def cvae_forward(P, data, source_labels, class_labels, eps, ctx):
     h = enc_forward(P, "encoder.", data, ctx)
     ctx.tap("enc_h", h)
     h = torch.cat([h, semb, cemb], dim=1)
-    h = F.leaky_relu(batch_norm(P, "encoder_fc.1", F.linear(h, P["encoder_fc.0.weight"], P["encoder_fc.0.bias"]), ctx), SLOPE_HEADS)
-    ctx.tap("encoder_fc.1", h)
-    enc = F.leaky_relu(batch_norm(P, "encoder_fc.4", F.linear(h, P["encoder_fc.3.weight"], P["encoder_fc.3.bias"]), ctx), SLOPE_HEADS)
-    ctx.tap("encoder_fc.4", enc)
+    h = ctx.lrelu("encoder_fc.1", batch_norm(P, "encoder_fc.1", F.linear(h, P["encoder_fc.0.weight"], P["encoder_fc.0.bias"]), ctx), SLOPE_HEADS)
+    enc = ctx.lrelu("encoder_fc.4", batch_norm(P, "encoder_fc.4", F.linear(h, P["encoder_fc.3.weight"], P["encoder_fc.3.bias"]), ctx), SLOPE_HEADS)
     mu = F.linear(enc, P["z_mean.weight"], P["z_mean.bias"])
     logvar = F.linear(enc, P["z_log_var.weight"], P["z_log_var.bias"])
     z = _reparam(mu, logvar, eps)
     d = torch.cat([z, semb, cemb], dim=1)
-    d = F.leaky_relu(F.linear(d, P["decoder_fc.0.weight"], P["decoder_fc.0.bias"]), SLOPE_HEADS)
-    ctx.tap("decoder_fc.0", d)
-    d = F.leaky_relu(batch_norm(P, "decoder_fc.3", F.linear(d, P["decoder_fc.2.weight"], P["decoder_fc.2.bias"]), ctx), SLOPE_HEADS)
-    ctx.tap("decoder_fc.3", d)
+    d = ctx.lrelu("decoder_fc.0", F.linear(d, P["decoder_fc.0.weight"], P["decoder_fc.0.bias"]), SLOPE_HEADS)
+    d = ctx.lrelu("decoder_fc.3", batch_norm(P, "decoder_fc.3", F.linear(d, P["decoder_fc.2.weight"], P["decoder_fc.2.bias"]), ctx), SLOPE_HEADS)
     ctx.tap("dec_in", d)
     dec = dec_forward(P, "decoder.", d, ctx)
     return enc, mu, logvar, dec
@@ -359,8 +387,7 @@ def mm_forward(P, data1, data2, source_labels, class_labels, eps, ctx):
     h1 = enc_forward(P, "encoder_mod1.", data1, ctx)
     h2 = enc_forward(P, "encoder_mod2.", data2, ctx)
     h = torch.cat([h1, h2, semb, cemb], dim=1)
-    h = F.leaky_relu(batch_norm(P, "fusion_encoder.1", F.linear(h, P["fusion_encoder.0.weight"], P["fusion_encoder.0.bias"]), ctx), SLOPE_HEADS)
-    ctx.tap("fusion_encoder.1", h)
+    h = ctx.lrelu("fusion_encoder.1", batch_norm(P, "fusion_encoder.1", F.linear(h, P["fusion_encoder.0.weight"], P["fusion_encoder.0.bias"]), ctx), SLOPE_HEADS)
     enc = F.linear(h, P["fusion_encoder.3.weight"], P["fusion_encoder.3.bias"])
     mu = F.linear(enc, P["z_mean.weight"], P["z_mean.bias"])
     logvar = F.linear(enc, P["z_log_var.weight"], P["z_log_var.bias"])
@@ -368,10 +395,8 @@ def mm_forward(P, data1, data2, source_labels, class_labels, eps, ctx):
     zc = torch.cat([z, semb, cemb], dim=1)
     recs = []
     for mod in ("mod1", "mod2"):
-        d = F.leaky_relu(F.linear(zc, P[f"decoder_fc_{mod}.0.weight"], P[f"decoder_fc_{mod}.0.bias"]), SLOPE_HEADS)
-        ctx.tap(f"decoder_fc_{mod}.0", d)
-        d = F.leaky_relu(batch_norm(P, f"decoder_fc_{mod}.3", F.linear(d, P[f"decoder_fc_{mod}.2.weight"], P[f"decoder_fc_{mod}.2.bias"]), ctx), SLOPE_HEADS)
-        ctx.tap(f"decoder_fc_{mod}.3", d)
+        d = ctx.lrelu(f"decoder_fc_{mod}.0", F.linear(zc, P[f"decoder_fc_{mod}.0.weight"], P[f"decoder_fc_{mod}.0.bias"]), SLOPE_HEADS)
+        d = ctx.lrelu(f"decoder_fc_{mod}.3", batch_norm(P, f"decoder_fc_{mod}.3", F.linear(d, P[f"decoder_fc_{mod}.2.weight"], P[f"decoder_fc_{mod}.2.bias"]), ctx), SLOPE_HEADS)
         recs.append(dec_forward(P, f"decoder_{mod}.", d, ctx))
     return enc, mu, logvar, recs[0], recs[1]
 
@@ -454,8 +479,9 @@ class OracleModel:
                 if k in self.state:
                     self.state[k].copy_(v.to(self.state[k].dtype))
 
-    def forward(self, batch, eps, training=True, taps=None):
-        ctx = Ctx(training, taps)
+    def forward(self, batch, eps, training=True, taps=None, masks=None):
+        """masks: {site -> bool tensor}: leaky-ReLU branches forced (see _MaskedLeakyReLU); None = sign(x)."""
+        ctx = Ctx(training, taps, masks)
         if self.kind == "unimodal":
             data, src, cls = batch
             return cvae_forward(self.state, data, src, cls, eps, ctx)

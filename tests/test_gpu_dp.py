@@ -98,8 +98,10 @@ def _sync_worker(rank, world, port, q):
     eng.backward()
     parallel.allreduce_mean_(eng.grads[: eng.plan.n_active])
     torch.cuda.synchronize()
+    from tests import helpers as H
     q.put((rank, enc.cpu().numpy(), rec.cpu().numpy(), {k: v.cpu().numpy() for k, v in eng.grad_dict().items()},
-           {k: v.cpu().numpy() for k, v in eng.state_dict().items() if "running" in k}))
+           {k: v.cpu().numpy() for k, v in eng.state_dict().items() if "running" in k},
+           {k: m.numpy() for k, m in H.engine_masks(eng).items()}))
     dist.destroy_process_group()
 
 
@@ -122,12 +124,14 @@ def test_sync_batchnorm_two_ranks_equal_global_batch_oracle():
     x, src, cls, eps = O.synth_inputs(world * B, L, z, salt=9)
     oms = [O.OracleModel("unimodal", z, L, salt=3, dtype=dt) for dt in (torch.float32, torch.float64)]
     outs = []
+    # the oracle runs the GLOBAL batch on the leaky-ReLU branches the two ranks took on their halves (tests/helpers.py)
+    masks = {k: torch.from_numpy(np.concatenate([r[5][k] for r in res], axis=0)) for k in res[0][5]}
     for om, dt in zip(oms, (torch.float32, torch.float64)):
-        o = om.forward((x.to(dt), src, None), eps.to(dt), True)
+        o = om.forward((x.to(dt), src, None), eps.to(dt), True, masks=masks)
         om.losses((x.to(dt), src, None), o)[0].backward()
         outs.append(o)
     n = lambda t: t.detach().numpy()
-    for rank, enc, rec, grads, running in res:
+    for rank, enc, rec, grads, running, _ in res:
         sl = slice(rank * B, (rank + 1) * B)
         H.parity(enc, n(outs[0][0])[sl], n(outs[1][0])[sl], f"rank {rank} enc")
         H.parity(rec, n(outs[0][3])[sl], n(outs[1][3])[sl], f"rank {rank} rec")
@@ -137,6 +141,6 @@ def test_sync_batchnorm_two_ranks_equal_global_batch_oracle():
         for k, g in g32.items():
             if g is None or re.search(H.ZERO_GRAD_RE, k):
                 continue
-            H.grad_parity(grads[k], g.numpy(), g64[k].numpy(), flips=1, msg=f"rank {rank} grad {k}")
+            H.parity(grads[k], g.numpy(), g64[k].numpy(), f"rank {rank} grad {k}")
     for k in res[0][3]:
         np.testing.assert_array_equal(res[0][3][k], res[1][3][k])        # identical after the all-reduce
