@@ -275,6 +275,36 @@ def cpu_baseline(steps=20, warm=3):
                        f"wave {times[0]*1e3:.0f} ms + time {times[1]*1e3:.0f} ms per step")
 
 
+def spawn_ranks(n):
+    """One child per GPU (rank r on device r), rendezvous on 127.0.0.1; returns the exit code for the parent."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    if any(codes):
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return 1
+    lines = [ln for ln in out0.decode().splitlines() if ln.startswith("{")]
+    if len(lines) != 1:
+        print(f"bench.py: expected one JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 1
+    print(lines[0], flush=True)
+    return 0
+
+
 def main():
     global BATCH, Z_DIM, N_UNITS
     ap = argparse.ArgumentParser()
@@ -295,6 +325,11 @@ def main():
     ap.add_argument("--time-len", type=int, default=100)
     ap.add_argument("--units", type=int, default=15631)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start one child process per GPU BEFORE anything in this
+        # process touches the GPU (a process that has initialised HIP must never exec / be replaced), forward rank
+        # 0's JSON line, fail if any rank fails.
+        raise SystemExit(spawn_ranks(args.gpus))
     # stdout carries exactly ONE line, the JSON: native libraries print there too (RCCL's version banner at
     # communicator creation), so fd 1 is pointed at stderr for the run and the JSON goes to the saved descriptor
     real_stdout = os.dup(1)
@@ -324,6 +359,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    n_ranks_seen = dist.get_world_size() if (world > 1 or force_dist) else 1      # what the communicator says, not the flag
+    dist_backend = dist.get_backend() if (world > 1 or force_dist) else None
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
     pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len), overlap=args.overlap, lockstep=args.lockstep)
     steps_per_epoch = N_UNITS // (BATCH * world)
@@ -374,7 +411,7 @@ def main():
             "metric": "pretrain samples/sec (waveform+time cVAE, batch 512) at 1/2/4/8 MI355X",
             "value": BATCH * world * args.steps / dt,
             "unit": "samples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -383,7 +420,7 @@ def main():
                                     "fp32 arithmetic on f32 MFMA (parity path; bf16 not used)")
                        if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
                        f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "hip_graph": use_graph, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired, "lockstep": pair.lockstep,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired, "lockstep": pair.lockstep,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic_from_pmc(),

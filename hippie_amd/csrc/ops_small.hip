@@ -523,7 +523,7 @@ __global__ void repeat_bwd_kernel(const float* g1, const float* g2, float* d, in
 }
 
 // ---- concat / embedding ----------------------------------------------------------
-struct ConcatArgs { float* out; const float* src[4]; const int64_t* idx[4]; int kind[4], w[4], ld[4]; int B, nseg, ldo; };
+struct ConcatArgs { float* out; const float* src[4]; const int64_t* idx[4]; int kind[4], w[4], ld[4], rows[4]; int B, nseg, ldo; };
 __global__ void concat_kernel(ConcatArgs p) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= p.B * p.ldo) return;
@@ -533,18 +533,23 @@ __global__ void concat_kernel(ConcatArgs p) {
   for (int j = 0; j < p.nseg; ++j) {
     if (col < p.w[j]) {
       if (p.kind[j] == 0) v = p.src[j][(size_t)b * p.ld[j] + col];
-      else if (p.kind[j] == 1) v = p.src[j][(size_t)p.idx[j][b] * p.ld[j] + col];
+      else if (p.kind[j] == 1) {
+        const int64_t row = p.idx[j][b];            // out-of-range label: zero row, no memory access
+        if (row >= 0 && row < (int64_t)p.rows[j]) v = p.src[j][(size_t)row * p.ld[j] + col];
+      }
       break;
     }
     col -= p.w[j];
   }
   p.out[id] = v;
 }
-__global__ void emb_bwd_kernel(const float* d, const int64_t* idx, float* dt, int B, int w, int ld, int col0) {
+__global__ void emb_bwd_kernel(const float* d, const int64_t* idx, float* dt, int B, int w, int ld, int col0, int rows) {
   const int id = blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= B * w) return;
   const int b = id / w, k = id - b * w;
-  atomic_add_f32(dt + (size_t)idx[b] * w + k, d[(size_t)b * ld + col0 + k]);
+  const int64_t row = idx[b];
+  if (row < 0 || row >= (int64_t)rows) return;      // never write outside the table's gradient
+  atomic_add_f32(dt + (size_t)row * w + k, d[(size_t)b * ld + col0 + k]);
 }
 
 // ---- Linear ----------------------------------------------------------------------
@@ -1095,7 +1100,7 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       ConcatArgs a{};
       a.out = ptr<float>(op, 0, bases); a.B = I[0]; a.nseg = I[1]; a.ldo = I[2];
       for (int j = 0; j < 4; ++j) {
-        a.kind[j] = I[4 + 3 * j]; a.w[j] = I[5 + 3 * j]; a.ld[j] = I[6 + 3 * j];
+        a.kind[j] = I[4 + 3 * j]; a.w[j] = I[5 + 3 * j]; a.ld[j] = I[6 + 3 * j]; a.rows[j] = I[16 + j];
         a.src[j] = ptr<const float>(op, 1 + 2 * j, bases); a.idx[j] = ptr<const int64_t>(op, 2 + 2 * j, bases);
       }
       hipLaunchKernelGGL(concat_kernel, dim3(blocks_for((int64_t)a.B * a.ldo)), dim3(256), 0, s, a);
@@ -1104,7 +1109,7 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     case HP_OP_EMB_BWD:
       hipLaunchKernelGGL(emb_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1])), dim3(256), 0, s,
                          ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases),
-                         I[0], I[1], I[2], I[3]);
+                         I[0], I[1], I[2], I[3], I[4]);
       break;
     case HP_OP_LINEAR_FWD: {
       LinArgs a{};

@@ -69,7 +69,119 @@ hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
   return dispatch(op, p->bases, s);
 }
 
-// number of buffer slots each op may reference (for validation)
+// Bytes each op touches behind every buffer slot it uses (0 = slot unused / unchecked): the planner fixes all
+// offsets at lowering time, so a mis-lowered op is caught here, on the host, instead of writing out of bounds.
+// Returns the number of (slot, bytes) pairs written.
+int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
+  for (auto& v : need) v = 0;
+  const int32_t* I = op.i;
+  const int64_t f4 = 4, f8 = 8;
+  const int64_t stat = (int64_t)HP_STAT_REPL * 2 * f8;      // per channel
+  auto rows_in = [&]() { return (int64_t)(I[3] > 0 ? I[0] / I[3] : 0) * I[4]; };      // (M / Lout) * Lin
+  auto max_tapw = [&]() { int m = 0; for (int j = 0; j < I[9] && j < HP_MAX_TAPS; ++j) m = I[16 + j] > m ? I[16 + j] : m; return (int64_t)m + 1; };
+  auto strided = [&](int64_t rows, int64_t ld, int64_t w) { return rows > 0 ? ((rows - 1) * ld + w) * f4 : 0; };
+  switch (op.op) {
+    case HP_OP_CONV_TAPS: {
+      const int64_t M = I[0], N = I[1], K = I[2];
+      need[0] = rows_in() * K * f4; need[1] = max_tapw() * N * K * f4; need[2] = M * N * f4;
+      if (op.flags & 2) need[3] = N * f4;
+      if (op.flags & 4) need[4] = N * stat;
+      if (op.flags & 8) { need[5] = need[6] = need[7] = need[8] = N * f4; if (op.buf[9] != HP_NULL) need[9] = M * N * f4; }
+      break;
+    }
+    case HP_OP_WGRAD_TAPS: {
+      const int64_t M = I[0], N = I[1], K = I[2];
+      need[0] = M * N * f4; need[1] = rows_in() * K * f4;
+      need[2] = (op.flags & 1) ? max_tapw() * N * K * f4 : ((int64_t)(I[22] - 1) * I[24] + max_tapw() * N * K) * f4;
+      break;
+    }
+    case HP_OP_SLAB_REDUCE: need[0] = ((int64_t)(I[1] - 1) * I[2] + I[0]) * f4; need[1] = (int64_t)I[0] * f4; break;
+    case HP_OP_BN_APPLY: {
+      const int64_t MC = (int64_t)I[0] * I[1] * f4, C = (int64_t)I[1] * f4;
+      need[0] = need[1] = MC; if (I[3]) need[2] = I[1] * stat;
+      need[3] = need[4] = need[5] = need[6] = C; need[7] = 2 * C;
+      if (I[2]) need[8] = MC;
+      if (I[2] == 2) { if (I[3]) need[9] = I[1] * stat; need[10] = need[11] = need[12] = need[13] = C; need[14] = 2 * C; }
+      break;
+    }
+    case HP_OP_BN_BWD_REDUCE: {
+      const int64_t MC = (int64_t)I[0] * I[1] * f4, C = (int64_t)I[1] * f4;
+      need[0] = need[2] = need[3] = need[4] = MC; if (I[2]) need[1] = MC;
+      need[5] = 2 * C; need[6] = I[1] * stat;
+      if (I[3]) { need[7] = MC; need[8] = 2 * C; need[9] = I[1] * stat; }
+      break;
+    }
+    case HP_OP_BN_BWD_APPLY: {
+      const int64_t MC = (int64_t)I[0] * I[1] * f4, C = (int64_t)I[1] * f4;
+      need[0] = need[1] = need[5] = MC; need[2] = 2 * C; need[3] = I[1] * stat; need[4] = need[6] = need[7] = C;
+      break;
+    }
+    case HP_OP_STEM_FWD:
+      need[0] = (int64_t)I[0] * I[1] * f4; need[1] = (int64_t)I[3] * 3 * f4; need[2] = (int64_t)I[0] * I[2] * I[3] * f4;
+      if (op.buf[3] != HP_NULL) need[3] = I[3] * stat;
+      break;
+    case HP_OP_STEM_WGRAD:
+      need[0] = (int64_t)I[0] * I[2] * I[3] * f4; need[1] = (int64_t)I[0] * I[1] * f4; need[2] = (int64_t)I[3] * 3 * f4; break;
+    case HP_OP_POOL_FWD: case HP_OP_REPEAT_BWD: {
+      const int big = op.op == HP_OP_POOL_FWD ? 0 : 0;
+      need[big] = (int64_t)I[0] * I[1] * I[2] * f4;
+      if (op.op == HP_OP_REPEAT_BWD) { if (I[3]) need[1] = need[0]; need[2] = (int64_t)I[0] * I[2] * f4; }
+      else need[1] = (int64_t)I[0] * I[2] * f4;
+      break;
+    }
+    case HP_OP_POOL_BWD: case HP_OP_REPEAT_FWD:
+      need[0] = (int64_t)I[0] * I[2] * f4; need[1] = (int64_t)I[0] * I[1] * I[2] * f4; break;
+    case HP_OP_CONCAT: {
+      need[0] = (int64_t)I[0] * I[2] * f4;
+      for (int j = 0; j < I[1] && j < 4; ++j) {
+        const int kind = I[4 + 3 * j], w = I[5 + 3 * j], ld = I[6 + 3 * j];
+        if (kind == 0) need[1 + 2 * j] = strided(I[0], ld, w);
+        else if (kind == 1) { need[1 + 2 * j] = strided(I[16 + j], ld, w); need[2 + 2 * j] = (int64_t)I[0] * f8; }
+      }
+      break;
+    }
+    case HP_OP_EMB_BWD:
+      need[0] = strided(I[0], I[2], I[3] + I[1]); need[1] = (int64_t)I[0] * f8; need[2] = (int64_t)I[4] * I[1] * f4; break;
+    case HP_OP_LINEAR_FWD:
+      need[0] = strided(I[0], I[3], I[2]); need[1] = (int64_t)I[1] * I[2] * f4; if (op.buf[2] != HP_NULL) need[2] = (int64_t)I[1] * f4;
+      need[3] = strided(I[0], I[4], I[1]); if (I[6]) need[4] = I[1] * stat;
+      break;
+    case HP_OP_LINEAR_BWD_X:
+      need[0] = strided(I[0], I[3], I[1]); need[1] = (int64_t)I[1] * I[2] * f4; need[2] = strided(I[0], I[4], I[2]);
+      if (I[5]) need[3] = strided(I[0], I[6], I[2]);
+      break;
+    case HP_OP_LINEAR_BWD_W:
+      need[0] = strided(I[0], I[3], I[1]); need[1] = strided(I[0], I[4], I[2]); need[2] = (int64_t)I[1] * I[2] * f4;
+      if (op.buf[3] != HP_NULL) need[3] = (int64_t)I[1] * f4;
+      break;
+    case HP_OP_REPARAM_KL_FWD:
+      need[0] = (int64_t)I[0] * 2 * I[1] * f4; need[1] = need[2] = (int64_t)I[0] * I[1] * f4; need[3] = 4 * f8; break;
+    case HP_OP_REPARAM_KL_BWD:
+      need[0] = need[3] = (int64_t)I[0] * 2 * I[1] * f4; need[1] = (int64_t)I[0] * I[1] * f4; need[2] = strided(I[0], I[2], I[1]); break;
+    case HP_OP_MSE_FWD_BWD: need[0] = need[1] = need[2] = (int64_t)I[0] * f4; need[3] = 4 * f8; break;
+    case HP_OP_TAIL_FWD:
+      need[0] = (int64_t)I[0] * I[1] * I[2] * f4; need[1] = (int64_t)I[2] * 3 * f4; need[2] = f4; need[3] = (int64_t)I[0] * 2 * I[1] * f4; break;
+    case HP_OP_TAIL_BWD_X:
+      need[0] = (int64_t)I[0] * 2 * I[1] * f4; need[1] = (int64_t)I[2] * 3 * f4; need[2] = (int64_t)I[0] * I[1] * I[2] * f4; break;
+    case HP_OP_TAIL_BWD_W:
+      need[0] = (int64_t)I[0] * 2 * I[1] * f4; need[1] = (int64_t)I[0] * I[1] * I[2] * f4; need[2] = (int64_t)I[2] * 3 * f4; need[3] = f4; break;
+    case HP_OP_LOSS_FINALIZE: need[0] = 4 * f8; need[1] = 4 * f4; break;
+    case HP_OP_GRADNORM: need[0] = (int64_t)I[0] * f4; need[1] = f8; break;
+    case HP_OP_ADAMW:
+      need[0] = need[1] = need[2] = need[3] = (int64_t)I[0] * f4; need[4] = f8; if (op.f[5] > 0.f) need[5] = f8; break;
+    case HP_OP_ADAMW_SF:
+      need[0] = need[1] = need[2] = need[3] = (int64_t)I[0] * f4; need[4] = f8; need[5] = 4 * f8; if (op.f[4] > 0.f) need[6] = f8; break;
+    case HP_OP_SF_SCHEDULE: need[0] = f8; need[1] = 4 * f8; break;
+    case HP_OP_LERP: need[0] = need[1] = (int64_t)I[0] * f4; break;
+    case HP_OP_STEP_INC: need[0] = f8; break;
+    case HP_OP_ZERO: need[0] = (int64_t)(uint32_t)I[0] + ((int64_t)(uint32_t)I[1] << 32); break;
+    case HP_OP_RESAMPLE_LINEAR: need[0] = (int64_t)I[0] * I[1] * f4; need[1] = (int64_t)I[0] * I[2] * f4; break;
+    case HP_OP_STATS_SYNC: need[0] = (int64_t)I[0] * f8; break;
+    default: break;
+  }
+  return 0;
+}
+
 int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& why) {
   char buf[256];
   if (op.op <= 0 || op.op >= HP_OP__COUNT) {
@@ -77,14 +189,23 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
     why = buf;
     return 1;
   }
+  int64_t need[HP_OP_NB];
+  op_extents(op, need);
   for (int k = 0; k < HP_OP_NB; ++k) {
     const int64_t r = op.buf[k];
-    if (r == HP_NULL) continue;
+    if (r == HP_NULL) {
+      if (need[k] > 0) {
+        snprintf(buf, sizeof buf, "op %d (opcode %d): buffer slot %d is required (%lld bytes) but NULL", index, op.op, k, (long long)need[k]);
+        why = buf;
+        return 1;
+      }
+      continue;
+    }
     const int sp = hp::space_of(r);
     const int64_t off = hp::offset_of(r);
-    if (sp < 0 || sp >= HP_NUM_SPACES || off < 0 || off >= sizes[sp] || (off & 3)) {
-      snprintf(buf, sizeof buf, "op %d (opcode %d): buffer slot %d out of range (space %d offset %lld size %lld)", index,
-               op.op, k, sp, (long long)off, (long long)(sp >= 0 && sp < HP_NUM_SPACES ? sizes[sp] : -1));
+    if (sp < 0 || sp >= HP_NUM_SPACES || off < 0 || off >= sizes[sp] || (off & 3) || need[k] < 0 || off + need[k] > sizes[sp]) {
+      snprintf(buf, sizeof buf, "op %d (opcode %d): buffer slot %d out of range (space %d offset %lld extent %lld arena size %lld)", index,
+               op.op, k, sp, (long long)off, (long long)need[k], (long long)(sp >= 0 && sp < HP_NUM_SPACES ? sizes[sp] : -1));
       why = buf;
       return 1;
     }

@@ -131,11 +131,32 @@ class Engine:
             raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}… unexpected {unexpected[:5]}…")
         return missing, unexpected
 
+    def reset_optimizer_state(self):
+        """A fresh torch.optim.AdamW: exp_avg = exp_avg_sq = 0, step = 0 (and the schedule-free scalars)."""
+        self.m.zero_()
+        self.v.zero_()
+        self.io("adam_step").zero_()
+        self.io("sf_state").zero_()
+
     def grad_dict(self):
         return OrderedDict((k, self.param_view(k, self.grads).contiguous().clone()) for k in self.plan.params)
 
     # ---- inputs ------------------------------------------------------------------
-    def set_inputs(self, x, src, cls=None, eps=None, x2=None):
+    def check_labels(self, src, cls=None):
+        """nn.Embedding raises IndexError for an index outside its table (hippie/model.py:65-66); so does this
+        engine, before anything reaches the kernels (which additionally treat such a row as zeros).  One small
+        reduction + one host sync per call; callers that have validated their label tables once (Trainer.fit)
+        pass validate=False to set_inputs."""
+        for name, t, rows in (("source", src, self.cfg.num_sources), ("class", cls, self.cfg.num_classes)):
+            if t is None or t.numel() == 0:
+                continue
+            lo, hi = (int(v) for v in torch.aminmax(t))
+            if lo < 0 or hi >= rows:
+                raise IndexError(f"{name} label out of range: values span [{lo}, {hi}] but the {name} embedding has {rows} rows")
+
+    def set_inputs(self, x, src, cls=None, eps=None, x2=None, validate=True):
+        if validate:
+            self.check_labels(src, cls if self.with_class else None)
         self.io("x").copy_(x.reshape(self.io("x").shape), non_blocking=True)
         if x2 is not None:
             self.io("x2").copy_(x2.reshape(self.io("x2").shape), non_blocking=True)

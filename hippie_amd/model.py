@@ -54,15 +54,20 @@ class _Net:
             self._engines[key] = eng
         return eng
 
-    def configure_training(self, train_cfg: planner.TrainCfg):
+    def configure_training(self, train_cfg: planner.TrainCfg, reset_optimizer=False):
         """(Re)lower the optimiser / loss constants (lr, weight decay, beta, clip, modality weights).
-        Parameters, BatchNorm buffers and AdamW state are kept."""
+        Parameters and BatchNorm buffers are kept.  The optimiser state (exp_avg, exp_avg_sq, step; schedule-free
+        scalars) is kept by default — re-lowerings inside one training module, e.g. set_gradient_clip — and
+        ZEROED with reset_optimizer=True: a new train module over an existing network owns a fresh
+        torch.optim.AdamW in the reference (hippie/model.py:93; the label-free fine-tune stage re-wraps the
+        pretrained network, scripts/train_model_with_multimodal.py:263-268)."""
         self._train_cfg = train_cfg
         keep = self._root
         self._engines = {}
         if keep is not None:
             eng = Engine(self.cfg, keep.B, train_cfg, with_class=keep.with_class, device=self.device, share_params_from=keep)
-            eng.io("adam_step").copy_(keep.io("adam_step"))
+            if reset_optimizer:
+                eng.reset_optimizer_state()
             self._root = eng
             self._engines[(keep.B, keep.with_class)] = eng
         self._generation += 1
@@ -260,10 +265,10 @@ class _TrainModule:
         self.trainer = None
         self.gradient_clip_val = 0.0
         self.training = True
-        self._apply_cfg()
+        self._apply_cfg(reset_optimizer=True)
         self.optimizer = _Optimizer(self)
 
-    def _apply_cfg(self):
+    def _apply_cfg(self, reset_optimizer=False):
         opt = getattr(self, "optimizer", None)
         if opt is not None and not isinstance(opt, _Optimizer):
             # a user-installed optimiser (AdamWScheduleFree) owns lr / weight decay; keep its settings
@@ -271,7 +276,8 @@ class _TrainModule:
                                                   w1=self.mod1_weight, w2=self.mod2_weight))
             return
         self.model.configure_training(planner.TrainCfg(lr=self.lr, weight_decay=self.weight_decay, beta=self.beta,
-                                                       clip=self.gradient_clip_val or 0.0, w1=self.mod1_weight, w2=self.mod2_weight))
+                                                       clip=self.gradient_clip_val or 0.0, w1=self.mod1_weight, w2=self.mod2_weight),
+                                      reset_optimizer=reset_optimizer)
 
     def set_gradient_clip(self, val):
         """Lightning's Trainer(gradient_clip_val=...): folded into the fused AdamW launch."""

@@ -614,26 +614,30 @@ class Lowering:
 
     # ---- heads: shared pieces --------------------------------------------------
     def concat(self, out, ldo, segs, note):
-        """segs: list of (kind, width, ld, src_ref, idx_ref)"""
+        """segs: list of (kind, width, ld, src_ref, idx_ref[, table rows])"""
         ii = [self.B, len(segs), ldo, 0]
         bufs = [out]
-        for (kind, w, ld, src, idx) in segs:
+        rows = []
+        for sg in segs:
+            kind, w, ld, src, idx = sg[:5]
             ii += [kind, w, ld]
             bufs += [src, idx]
+            rows.append(sg[5] if len(sg) > 5 else 0)
         ii += [0] * (16 - len(ii))
+        ii += rows + [0] * (4 - len(rows))
         self.o.add(P.CONCAT, 0, i=ii, buf=bufs, note=note)
 
     def emb_segs(self):
         H = self.cfg.class_hidden_dim
-        segs = [(1, H, H, self.semb.ref, self.src)]
-        segs.append((1, H, H, self.cemb.ref, self.cls) if self.with_class else (2, H, 0, None, None))
+        segs = [(1, H, H, self.semb.ref, self.src, self.cfg.num_sources)]
+        segs.append((1, H, H, self.cemb.ref, self.cls, self.cfg.num_classes) if self.with_class else (2, H, 0, None, None))
         return segs
 
     def emb_bwd(self, dcat, ld, col0):
         H = self.cfg.class_hidden_dim
-        self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0], buf=[dcat, self.src, self.semb.gref], note="source_embedding grad")
+        self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0, self.cfg.num_sources], buf=[dcat, self.src, self.semb.gref], note="source_embedding grad")
         if self.with_class:
-            self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0 + H], buf=[dcat, self.cls, self.cemb.gref], note="class_embedding grad")
+            self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0 + H, self.cfg.num_classes], buf=[dcat, self.cls, self.cemb.gref], note="class_embedding grad")
 
     def flush_wgrads(self, seg, only_if=True):
         """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, in their own segment
@@ -834,6 +838,9 @@ class Lowering:
             self.o.begin("opt")
             n = pl.n_active
             if self.train.clip > 0:
+                # the accumulator is zeroed HERE (not only by the forward's statistics memset): optimizer.step() may
+                # run more than once per forward (a closure, a second step()) and must not double-count the norm
+                self.o.add(P.ZERO, 0, i=[8, 0], buf=[norm2], note="zero the gradient-norm accumulator")
                 self.o.add(P.GRADNORM, 0, i=[n], buf=[Ref(P.GRAD, 0), norm2], note="clip_grad_norm: total norm")
             t = self.train
             arenas = [Ref(P.PARAM, 0), Ref(P.GRAD, 0), Ref(P.ADAM_M, 0), Ref(P.ADAM_V, 0)]

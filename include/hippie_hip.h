@@ -136,11 +136,13 @@ enum {
   HP_OP_REPEAT_BWD = 12,
   /* torch.cat([...], dim=1) with nn.Embedding gathers (model.py:53,60,65-66).
    * up to 4 segments j: kind i[4+3j] (0 dense, 1 embedding rows, 2 zeros), width
-   * i[5+3j], ld i[6+3j].  i[0]=B i[1]=nseg i[2]=ldo.
+   * i[5+3j], ld i[6+3j].  i[0]=B i[1]=nseg i[2]=ldo.  i[16+j] = number of rows of segment j's embedding table:
+   * an index outside [0, rows) yields a zero row and never touches memory (the host raises IndexError first, as
+   * nn.Embedding does; the device-side guard only makes a bad label harmless).
    * buf: 0 OUT; 1+2j SRC/TABLE; 2+2j IDX(int64) */
   HP_OP_CONCAT = 13,
-  /* embedding gradient: DT[idx[b]][k] += D[b*ld + col0 + k] (fp32 atomics).
-   * i[0]=B i[1]=w i[2]=ld i[3]=col0.  buf: 0 D 1 IDX 2 DT */
+  /* embedding gradient: DT[idx[b]][k] += D[b*ld + col0 + k] (fp32 atomics); rows with idx[b] outside
+   * [0, rows) are skipped.  i[0]=B i[1]=w i[2]=ld i[3]=col0 i[4]=rows.  buf: 0 D 1 IDX 2 DT */
   HP_OP_EMB_BWD = 14,
   /* nn.Linear (model.py:21-41, backbones.py:84,102,111,118,129,138):
    * Y[m*ldy+n] = act(sum_k X[m*ldx+k]*W[n*K+k] + b[n]) (+stats on the pre-activation).

@@ -247,18 +247,21 @@ def run(ops, A: Arenas, first=0, count=None):
                     out[:, col: col + w] = A.f32(b[1 + 2 * j], B * ld).reshape(B, ld)[:, :w]
                 elif kind == 1:
                     idx = A.i64(b[2 + 2 * j], B)
-                    tab = A.f32(b[1 + 2 * j], (int(idx.max()) + 1) * ld).reshape(-1, ld)
-                    out[:, col: col + w] = tab[idx][:, :w]
+                    rows = int(i[16 + j])
+                    ok = (idx >= 0) & (idx < rows)           # out-of-range label: zero row (device-side guard)
+                    tab = A.f32(b[1 + 2 * j], rows * ld).reshape(rows, ld)
+                    out[:, col: col + w] = np.where(ok[:, None], tab[np.where(ok, idx, 0)][:, :w], np.float32(0))
                 else:
                     out[:, col: col + w] = 0
                 col += w
             assert col == ldo
         elif op == 14:   # EMB_BWD
-            B, w, ld, col0 = [int(v) for v in i[:4]]
+            B, w, ld, col0, rows = [int(v) for v in i[:5]]
             d = A.f32(b[0], B * ld).reshape(B, ld)[:, col0: col0 + w]
             idx = A.i64(b[1], B)
-            dt = A.f32(b[2], (int(idx.max()) + 1) * w).reshape(-1, w)
-            np.add.at(dt, idx, d)
+            ok = (idx >= 0) & (idx < rows)                   # out-of-range label: skipped
+            dt = A.f32(b[2], rows * w).reshape(rows, w)
+            np.add.at(dt, idx[ok], d[ok])
         elif op == 15:   # LINEAR_FWD
             M, N, K, ldx, ldy, act, stats = [int(v) for v in i[:7]]
             X = A.f32(b[0], (M - 1) * ldx + K)

@@ -67,6 +67,22 @@ def test_planner_programs_validate_without_gpu(kind):
     bad[k]["i"][2] = 30          # K not a multiple of 32
     rc, msg = _create(bad, sizes)
     assert rc != 0 and "tap-map" in msg
+    # extents, not only start offsets: an output tensor that starts inside the arena but runs past its end
+    bad = ops.copy()
+    k = [i for i, r in enumerate(bad) if int(r["op"]) == P.CONV_TAPS][0]
+    bad[k]["buf"][2] = (P.WS << 56) | (plan.ws_bytes - 256)
+    rc, msg = _create(bad, sizes)
+    assert rc != 0 and "out of range" in msg and "extent" in msg
+    bad = ops.copy()
+    k = [i for i, r in enumerate(bad) if int(r["op"]) == P.ADAMW][0]
+    bad[k]["i"][0] = plan.n_param_floats + 4          # optimiser arena overrun
+    rc, msg = _create(bad, sizes)
+    assert rc != 0 and "out of range" in msg
+    bad = ops.copy()
+    k = [i for i, r in enumerate(bad) if int(r["op"]) == P.BN_APPLY][0]
+    bad[k]["buf"][0] = P.NULL                          # a required operand missing
+    rc, msg = _create(bad, sizes)
+    assert rc != 0 and "required" in msg
     segs = plan.ops.segments
     assert set(segs) == {"fwd_train", "bwd", "bwd_a", "wg_a", "bwd_b", "wg_b", "opt", "fwd_eval", "enc_eval"}
     assert sum(c for k, (_, c) in segs.items() if k not in ("bwd", "enc_eval")) == len(ops)

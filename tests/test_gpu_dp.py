@@ -144,3 +144,28 @@ def test_sync_batchnorm_two_ranks_equal_global_batch_oracle():
             H.parity(grads[k], g.numpy(), g64[k].numpy(), f"rank {rank} grad {k}")
     for k in res[0][3]:
         np.testing.assert_array_equal(res[0][3][k], res[1][3][k])        # identical after the all-reduce
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` without a launcher: the parent must start the ranks itself (before touching the
+    GPU), forward exactly one JSON line and report the communicator's world size.  Rehearsed on the one GPU of
+    the test box with gloo (RCCL refuses two ranks per device)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(HIPPIE_SINGLE_DEVICE="1", HIPPIE_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["config"]["global_batch"] == 1024
+    assert out["value"] > 0 and np.isfinite(out["config"]["final_loss_wave"])
+    # a failing rank makes the parent fail
+    env["HIPPIE_DIST_BACKEND"] = "no-such-backend"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and not r.stdout.strip()

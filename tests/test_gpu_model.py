@@ -90,7 +90,8 @@ def test_two_column_labels_and_lr_rewrap():
     mod2.optimizer.step()
     after = net.state_dict()["class_embedding.weight"]
     assert not torch.equal(before, after)          # class embedding trains when class labels are given
-    assert net._any_engine().adam_step == 2
+    # a new train module owns a FRESH AdamW (hippie/model.py:93): step counter and moments restart
+    assert net._any_engine().adam_step == 1
     enc, mu, lv, dec = mod2((b[0], b[1]))
     assert enc.shape == (16, z) and dec.shape == (16, 1, L)
     with pytest.raises(ValueError):
@@ -164,3 +165,97 @@ def test_encoder_only_path_equals_full_forward():
     assert torch.equal(mod.embed(batch), enc)
     seg = net.engine(B, True).plan.ops.segments
     assert seg["enc_eval"][1] < 0.6 * seg["fwd_eval"][1]
+
+
+def test_rewrapped_module_starts_from_a_fresh_adamw():
+    """scripts/train_model_with_multimodal.py:263-268 re-wraps the pretrained network in a new LightningModule, whose
+    constructor builds a new torch.optim.AdamW (hippie/model.py:93): the first fine-tune step must be Adam's step 1
+    on zero moments, whatever the pretraining left behind.  Checked against the oracle's first AdamW step."""
+    z, L, B = 10, 50, 16
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    om = O.OracleModel("unimodal", z, L, salt=6)
+    net.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    x, src, cls, eps = O.synth_inputs(B, L, z, salt=6)
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3)
+    for _ in range(3):                                  # "pretraining": leaves non-zero moments and step = 3
+        mod.training_step((x.cuda(), src.cuda()), 0).backward()
+        mod.optimizer.step()
+    eng = net._any_engine()
+    assert eng.adam_step == 3 and float(eng.m.abs().max()) > 0
+    mod2 = hippieUnimodalEmbeddingModelCVAE(mod.model, learning_rate=1e-4)
+    eng = net._any_engine()
+    assert eng.adam_step == 0 and float(eng.m.abs().max()) == 0 and float(eng.v.abs().max()) == 0
+    # set_gradient_clip re-lowers inside ONE module: state must survive that
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+    e = net.engine(B, False)
+    net.train()
+    e.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+    e.forward(True)
+    e.backward()
+    e.optimizer_step()
+    torch.cuda.synchronize()
+    assert e.adam_step == 1
+    mod2.set_gradient_clip(1.0)
+    assert net._any_engine().adam_step == 1 and float(net._any_engine().m.abs().max()) > 0
+    # oracle: same parameters, same batch, masked to the engine's branches, ONE AdamW step from zero state at lr 1e-4
+    om2 = O.OracleModel("unimodal", z, L, salt=6)
+    om2.load({k: v.cpu() for k, v in sd0.items()})
+    masks = H.engine_masks(e)
+    outs = om2.forward((x, src, None), eps, True, masks=masks)
+    om2.losses((x, src, None), outs)[0].backward()
+    with torch.no_grad():
+        g = om2.grads()
+        for k in om2.param_keys:
+            if g[k] is not None:
+                om2.exp_avg[k] = torch.zeros_like(om2.state[k])
+                om2.exp_avg_sq[k] = torch.zeros_like(om2.state[k])
+        O.adamw_step({k: om2.state[k] for k in om2.param_keys}, g, om2.exp_avg, om2.exp_avg_sq, 1, 1e-4, 0.01)
+    sd = net.state_dict()
+    import re
+    for k in om2.param_keys:
+        if g[k] is None or re.search(H.ZERO_GRAD_RE, k):
+            continue
+        H.assert_adam_close(sd[k].cpu().numpy(), om2.state[k].detach().numpy(), 1e-4, k, grad=g[k].numpy())
+
+
+def test_out_of_range_labels_raise_index_error():
+    """nn.Embedding semantics at the boundary (hippie/model.py:65-66): IndexError, nothing launched."""
+    z, L = 10, 50
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=3)
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3)
+    x = torch.zeros(8, 1, L).cuda()
+    ok = torch.tensor([1, 2, 3, 4, 1, 2, 3, 4]).cuda()
+    with pytest.raises(IndexError, match="source label"):
+        mod.training_step((x, torch.tensor([1, 2, 3, 5, 1, 2, 3, 4]).cuda()), 0)
+    with pytest.raises(IndexError, match="source label"):
+        net(x, source_labels=ok - 2)
+    with pytest.raises(IndexError, match="class label"):
+        mod.training_step((x, torch.stack([torch.full((8,), 3), ok.cpu()], 1).cuda()), 0)       # class id 3 of 3
+    loss = mod.training_step((x + 0.1, torch.stack([torch.full((8,), 2), ok.cpu()], 1).cuda()), 0)
+    assert np.isfinite(loss.item())
+
+
+def test_second_optimizer_step_does_not_double_count_the_gradient_norm():
+    """clip_grad_norm_'s accumulator is zeroed inside the optimiser segment: stepping twice on the same gradients
+    applies the same clip coefficient twice (= two torch AdamW steps on an unchanged .grad)."""
+    z, L, B = 10, 50, 16
+    from hippie_amd import planner
+    from hippie_amd.engine import Engine
+    om = O.OracleModel("unimodal", z, L, salt=8)
+    x, src, cls, eps = O.synth_inputs(B, L, z, salt=8)
+    res = []
+    for steps in (1, 2):
+        eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-3, clip=0.05))
+        eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
+        eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+        eng.forward(True)
+        eng.backward()
+        for _ in range(steps):
+            eng.optimizer_step()
+        torch.cuda.synchronize()
+        res.append((eng.m.clone(), eng.grads.clone()))
+    # exp_avg after two steps on the same clipped gradient g_c: (1 - 0.9^2) g_c = 1.9 x the one-step value 0.1 g_c
+    m1, m2 = res[0][0], res[1][0]
+    big = m1.abs() > 1e-3 * m1.abs().max()
+    ratio = (m2[big] / m1[big])
+    assert float((ratio - 1.9).abs().max()) < 1e-3, float((ratio - 1.9).abs().max())

@@ -347,9 +347,9 @@ def test_concat_embedding_reparam_mse_loss():
     x, rec, drec = img.f32(Bn * 50), img.f32(Bn * 50), img.f32(Bn * 50, zero=True)
     scal = img.f32(4, zero=True)
     ol = P.OpList()
-    ol.add(P.CONCAT, 0, [Bn, 3, ld, 0, 0, 2 * z, 2 * z, 1, H, H, 1, H, H], (), [c0, h, None, semb, src, cemb, cls])
-    ol.add(P.CONCAT, 0, [Bn, 3, ld, 0, 0, 2 * z, 2 * z, 1, H, H, 2, H, 0], (), [c0z, h, None, semb, src, None, None])
-    ol.add(P.EMB_BWD, 0, [Bn, H, ld, 2 * z], (), [dcat, src, dsemb])
+    ol.add(P.CONCAT, 0, [Bn, 3, ld, 0, 0, 2 * z, 2 * z, 1, H, H, 1, H, H, 0, 0, 0, 0, 5, 7], (), [c0, h, None, semb, src, cemb, cls])
+    ol.add(P.CONCAT, 0, [Bn, 3, ld, 0, 0, 2 * z, 2 * z, 1, H, H, 2, H, 0, 0, 0, 0, 0, 5, 0], (), [c0z, h, None, semb, src, None, None])
+    ol.add(P.EMB_BWD, 0, [Bn, H, ld, 2 * z, 5], (), [dcat, src, dsemb])
     ol.add(P.REPARAM_KL_FWD, 0, [Bn, z], (), [mulv, eps, zz, loss])
     ol.add(P.REPARAM_KL_BWD, 0, [Bn, z, ld], [0.7], [mulv, eps, dcat, dmulv])
     ol.add(P.MSE_FWD_BWD, 0, [Bn * 50, 1], [0.5], [x, rec, drec, loss])
@@ -359,6 +359,34 @@ def test_concat_embedding_reparam_mse_loss():
                        (dmulv, Bn * 2 * z, "dmulv"), (drec, Bn * 50, "drec"), (scal, 4, "scalars")):
         check(gpu, cpu, ref, n, rel=3e-5, what=nm)
     check(gpu, cpu, loss, 4, np.float64, rel=1e-5, what="loss slots")
+
+
+def test_out_of_range_labels_are_harmless_on_the_device():
+    """nn.Embedding raises IndexError on a bad index (the host side does too: Engine.check_labels); the kernels
+    themselves must never fault on one: the gathered row is zeros and its gradient contribution is dropped, and the
+    words behind the table stay untouched."""
+    Bn, H, rows = 16, 5, 5
+    img = Img(12)
+    h = img.f32(Bn * 4)
+    semb = img.f32(rows * H)
+    guard = img.f32(64)                       # sits right behind the table: must not be read into the output ...
+    labels = np.array([0, 1, 2, 3, 4, 5, 7, -1, 2**40, -2**40, 4, 3, 2, 1, 0, 100], dtype=np.int64)
+    src = img.i64(labels)
+    ld = 4 + H
+    out = img.f32(Bn * ld, zero=True)
+    dcat = img.f32(Bn * ld)
+    dsemb = img.f32(rows * H, zero=True)
+    guard2 = img.f32(64, zero=True)           # ... and this one sits behind the gradient table: must stay zero
+    ol = P.OpList()
+    ol.add(P.CONCAT, 0, [Bn, 2, ld, 0, 0, 4, 4, 1, H, H, 0, 0, 0, 0, 0, 0, 0, rows], (), [out, h, None, semb, src])
+    ol.add(P.EMB_BWD, 0, [Bn, H, ld, 4, rows], (), [dcat, src, dsemb])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, out, Bn * ld, what="concat with bad labels")
+    check(gpu, cpu, dsemb, rows * H, rel=3e-5, what="emb bwd with bad labels")
+    o = view(gpu, out, np.float32, Bn * ld).reshape(Bn, ld)
+    bad = (labels < 0) | (labels >= rows)
+    assert np.all(o[bad, 4:] == 0) and np.all(o[~bad, 4:] != 0)
+    assert np.all(view(gpu, guard2, np.float32, 64) == 0)
 
 
 @pytest.mark.parametrize("n", [1027, 8056614 // 16])

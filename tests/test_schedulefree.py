@@ -131,7 +131,7 @@ def test_planner_lowers_schedulefree_segments():
     plan = planner.lower(cfg, 4, planner.TrainCfg(optimizer="schedulefree", warmup_steps=5, clip=1.0))
     first, count = plan.ops.segments["opt"]
     ops = [int(plan.ops.array()[k]["op"]) for k in range(first, first + count)]
-    assert ops == [P.GRADNORM, P.SF_SCHEDULE, P.ADAMW_SF, P.STEP_INC]
+    assert ops == [P.ZERO, P.GRADNORM, P.SF_SCHEDULE, P.ADAMW_SF, P.STEP_INC]       # ZERO: the norm accumulator, per optimiser step
     for seg in ("sf_eval", "sf_train"):
         f, c = plan.ops.segments[seg]
         assert c == 1 and int(plan.ops.array()[f]["op"]) == P.LERP
