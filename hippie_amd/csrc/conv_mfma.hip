@@ -16,16 +16,23 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct TapMap {
-  int M, N, K, Lout, Lin, P, a, sh, even, ntaps;
+  int M, N, K, Lout, Lin, P, a, sh, ntaps;
   int tap_o[HP_MAX_TAPS];
   int tap_w[HP_MAX_TAPS];
+  int tap_src[HP_MAX_TAPS];     // CONV_TAPS: 0 = (A, W), 1 = (A2, W2)
+  int out_Lfull, out_a, out_o;  // CONV_TAPS: output row of GEMM row (b, l) is b*out_Lfull + out_a*l + out_o (Lfull 0: dense)
 };
 
 static TapMap tapmap_from(const HpOp& op) {
   TapMap t;
   t.M = op.i[0]; t.N = op.i[1]; t.K = op.i[2]; t.Lout = op.i[3]; t.Lin = op.i[4];
-  t.P = op.i[5]; t.a = op.i[6]; t.sh = op.i[7]; t.even = op.i[8]; t.ntaps = op.i[9];
-  for (int j = 0; j < HP_MAX_TAPS; ++j) { t.tap_o[j] = op.i[10 + j]; t.tap_w[j] = op.i[16 + j]; }
+  t.P = op.i[5]; t.a = op.i[6]; t.sh = op.i[7]; t.ntaps = op.i[9];
+  for (int j = 0; j < HP_MAX_TAPS; ++j) { t.tap_o[j] = op.i[10 + j]; t.tap_w[j] = op.i[16 + j]; t.tap_src[j] = 0; }
+  t.out_Lfull = t.out_a = t.out_o = 0;
+  if (op.op == HP_OP_CONV_TAPS) {
+    for (int j = 0; j < HP_MAX_TAPS; ++j) t.tap_src[j] = op.i[22 + j];
+    t.out_Lfull = op.i[28]; t.out_a = op.i[29]; t.out_o = op.i[30];
+  }
   return t;
 }
 
@@ -48,14 +55,27 @@ __device__ __forceinline__ int xcd_remap(int id, int nblk) {
 // ------------------------------------------------------------------------------------
 struct ConvArgs {
   const float* A; const float* W; float* out; const float* bias; double* stats;
-  // eval-mode BatchNorm epilogue (flag 8): running statistics, optional residual tensor, optional leaky_relu
-  const float* gamma; const float* beta; const float* rmean; const float* rvar; const float* res;
+  const float* A2; const float* W2;     // second (source, weight) pair for taps with tap_src == 1
+  // eval-mode BatchNorm epilogue (HP_CONV_BN_EVAL): running statistics, optional residual tensor, optional leaky_relu;
+  // with HP_CONV_IN_BN the same four pointers are the INPUT BatchNorm's parameters / running statistics
+  const float* gamma; const float* beta; float* rmean; float* rvar; const float* res;
   float eps, slope;
   int bn_eval, act;
+  // HP_CONV_IN_BN: training-mode BatchNorm + leaky_relu of the input, applied in the A loader
+  int in_bn, in_Mstat;
+  const double* in_stats; float* in_save; float* in_coef;
+  float in_slope, in_eps, in_mom;
+  // HP_CONV_EPI_BNRED: BatchNorm-backward reduction of the output, fused into the epilogue
+  int epi;
+  const float* e_g2; const float* e_act; const float* e_raw; const float* e_save; const float* e_coef;
+  const float* e_raw2; const float* e_save2;
+  double* e_bs; double* e_bs2;
+  float e_slope;
   TapMap t;
 };
 
 constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
+constexpr int kConvCoef = 2 * 512;      // + (scale, shift) of up to 512 input channels (HP_CONV_IN_BN)
 constexpr int kConvThreads = 512;
 
 // One 64x64 output tile per 512-thread workgroup: 8 waves = 4 tile quadrants (32x32 MFMA tiles) x 2 K-halves.
@@ -63,7 +83,7 @@ constexpr int kConvThreads = 512;
 // sit on the same SIMD pair-wise, so one wave's global loads / LDS traffic / address arithmetic overlap
 // the other's MFMAs — at batch 512 a layer has only ~256 tiles for 1024 SIMDs, so this is the only way to
 // get two waves per SIMD.  Their partial accumulators are summed once, through LDS, in the epilogue.
-template <bool W_KN>
+template <bool W_KN, bool IN_BN>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
   constexpr int LDBK = 68;   // [k][n] image row stride
@@ -93,17 +113,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   // Two register sets (plain structs so they stay in VGPRs): slice s+1 waits in one while slice s+2 is being
   // fetched into the other.  Loads are UNCONDITIONAL (a padded / out-of-range row reads 16 bytes of zeros):
   // branch-free loads let the compiler wait with counted vmcnt(N).
-  struct Pref { float4 a, b; };
+  // (IN_BN: kq = channel offset of the slice in the coefficient table, va = 0 for a padded row: the padding is
+  // zeros of the ACTIVATION, not of the raw tensor it is computed from)
+  struct Pref { float4 a, b; int kq; float va; };
   // Per-tap load state: pointers advanced by a constant per K-slice, recomputed only at tap boundaries.
   const float* pa; const float* pb;
   int ia, ib;
   int n_tap = 0, kc = 0;
   auto set_tap = [&](int tap) {
     const int to = t.tap_o[tap];
-    const float* wp = p.W + (size_t)t.tap_w[tap] * wslab;
+    const bool second = t.tap_src[tap] != 0;
+    const float* wp = (second ? p.W2 : p.W) + (size_t)t.tap_w[tap] * wslab;
+    const float* ap = second ? p.A2 : p.A;
     const int pos = rl + to;
-    const bool oa = rvalid && pos >= 0 && pos < t.P && (!t.even || !(pos & 1));
-    pa = oa ? p.A + (size_t)(rbase + (pos >> t.sh)) * t.K + aq : hp_zero16;
+    const bool oa = rvalid && pos >= 0 && pos < t.P;
+    pa = oa ? ap + (size_t)(rbase + (pos >> t.sh)) * t.K + aq : hp_zero16;
     ia = oa ? 32 : 0;
     bool ob;
     if (!W_KN) {
@@ -128,12 +152,27 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     Pref r;
     r.a = *reinterpret_cast<const float4*>(pa);
     r.b = *reinterpret_cast<const float4*>(pb);
+    if (IN_BN) { r.kq = kc * 32 + aq; r.va = ia ? 1.f : 0.f; }
     advance();
     return r;
   };
-  auto stash = [&](int buf, const Pref r) {
+  const float* s_coef = smem + kConvLds;
+  const bool in_bn = IN_BN && p.in_bn;
+  const float in_slope = p.in_slope;
+  auto stash = [&](int buf, Pref r) {
     float* As = smem + buf * TILE;
     float* Bs = smem + 2 * TILE + buf * TILE;
+    if (IN_BN) {
+      if (in_bn) {
+        // a = leaky_relu(fma(x, scale, shift)): the same two operations, on the same operands, as HP_OP_BN_APPLY
+        const float4 sc = *reinterpret_cast<const float4*>(s_coef + r.kq);
+        const float4 sh = *reinterpret_cast<const float4*>(s_coef + t.K + r.kq);
+        r.a.x = lrelu(fmaf(r.a.x, sc.x, sh.x), in_slope) * r.va;
+        r.a.y = lrelu(fmaf(r.a.y, sc.y, sh.y), in_slope) * r.va;
+        r.a.z = lrelu(fmaf(r.a.z, sc.z, sh.z), in_slope) * r.va;
+        r.a.w = lrelu(fmaf(r.a.w, sc.w, sh.w), in_slope) * r.va;
+      }
+    }
     *reinterpret_cast<float4*>(As + ar * LDA + aq) = r.a;
     if (!W_KN) *reinterpret_cast<float4*>(Bs + ar * LDA + aq) = r.b;
     else       *reinterpret_cast<float4*>(Bs + kr * LDBK + nq) = r.b;
@@ -170,6 +209,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     if (FETCH) {                                                                                        \
       LD.a = *reinterpret_cast<const float4*>(pa);                                                      \
       LD.b = *reinterpret_cast<const float4*>(pb);                                                      \
+      if (IN_BN) { LD.kq = kc * 32 + aq; LD.va = ia ? 1.f : 0.f; }                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                \
     }                                                                                                   \
     _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                     \
@@ -183,7 +223,22 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     __syncthreads();                                                                                    \
   }
 
-  Pref setA = fetch();                       // slice 0
+  Pref setA = fetch();                       // slice 0 (in flight while the coefficients are derived)
+  if (IN_BN) {
+    if (in_bn) {
+      // every workgroup derives (scale, shift) of the K input channels from the producer's statistics — the same
+      // code path as HP_OP_BN_APPLY (bn_coef), hence the same bits in every workgroup; workgroup 0 also performs
+      // the BatchNorm's side effects (saved mean / invstd, (scale, shift) for the backward pass, running statistics)
+      float* sc_w = smem + kConvLds;
+      for (int c = tid; c < t.K; c += kConvThreads) {
+        const BnCoef k = bn_coef(true, p.in_Mstat, p.in_stats, t.K, c, p.gamma, p.beta, p.rmean, p.rvar, p.in_eps);
+        sc_w[c] = k.scale;
+        sc_w[t.K + c] = k.shift;
+        if (bid == 0) bn_side_effects(k, p.in_Mstat, t.K, c, p.in_save, p.rmean, p.rvar, p.in_mom, p.in_coef);
+      }
+      __syncthreads();
+    }
+  }
   stash(0, setA);
   if (nsteps > 1) setA = fetch();            // slice 1 waits in set A
   Pref setB = setA;
@@ -223,6 +278,71 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
   const int n = n0 + wn * 32 + li;
   const bool nok = n < t.N;
+  // element offset of the output of this lane's GEMM row r (-1 = outside the problem).  out_Lfull > 0: the op
+  // writes a strided subset of the rows of a taller tensor.  (int: every tensor of a program is < 2^31 elements,
+  // checked by hp_program_validate.)
+  auto out_off = [&](int r) -> int {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (!nok || m >= t.M) return -1;
+    int o = m;
+    if (t.out_Lfull > 0) {
+      const int b = m / t.Lout;
+      o = b * t.out_Lfull + t.out_a * (m - b * t.Lout) + t.out_o;
+    }
+    return o * t.N + n;
+  };
+  if (p.epi) {
+    // HP_CONV_EPI_BNRED: HP_OP_BN_BWD_REDUCE on the accumulators (same expressions as bn_bwd_reduce_body)
+    float mean = 0.f, invstd = 0.f, mean2 = 0.f, invstd2 = 0.f, csc = 0.f, csh = 0.f;
+    const bool has_act = p.e_act != nullptr, has_g2 = p.e_g2 != nullptr, has_2 = p.e_raw2 != nullptr;
+    if (nok) {
+      mean = p.e_save[n]; invstd = p.e_save[t.N + n];
+      if (has_2) { mean2 = p.e_save2[n]; invstd2 = p.e_save2[t.N + n]; }
+      if (!has_act) { csc = p.e_coef[n]; csh = p.e_coef[t.N + n]; }
+    }
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // two batches of 8 rows: all loads of a batch in flight before the first use
+      int off[8];
+      float xr[8], av[8], g2[8], x2[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        off[q] = out_off(h * 8 + q);
+        const int o = off[q] >= 0 ? off[q] : 0;        // clamped, unconditional
+        xr[q] = p.e_raw[o];
+        av[q] = has_act ? p.e_act[o] : 0.f;
+        g2[q] = has_g2 ? p.e_g2[o] : 0.f;
+        x2[q] = has_2 ? p.e_raw2[o] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (off[q] < 0) continue;
+        float gv = acc[h * 8 + q];
+        if (has_g2) gv += g2[q];
+        const float pre = has_act ? av[q] : fmaf(xr[q], csc, csh);
+        gv *= lrelu_grad(pre, p.e_slope);
+        p.out[off[q]] = gv;
+        s1 += (double)gv;
+        s2 += (double)gv * (double)((xr[q] - mean) * invstd);
+        if (has_2) s3 += (double)gv * (double)((x2[q] - mean2) * invstd2);
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    s3 += __shfl_xor(s3, 32, 64);
+    if (lh == 0 && nok) {
+      double* b1 = stat_replica(p.e_bs, t.N, bid);
+      atomic_add_f64(b1 + n, s1);
+      atomic_add_f64(b1 + t.N + n, s2);
+      if (has_2) {
+        double* b2 = stat_replica(p.e_bs2, t.N, bid);
+        atomic_add_f64(b2 + n, s1);
+        atomic_add_f64(b2 + t.N + n, s3);
+      }
+    }
+    return;
+  }
   const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
   if (p.bn_eval) {
     // forward-only path: BatchNorm1d in eval mode (+ residual, + leaky_relu) applied to the accumulators; the
@@ -236,12 +356,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (nok && m < t.M) {
+      const int o = out_off(r);
+      if (o >= 0) {
         float v = fmaf(acc[r] + bv, sc, sh);
-        if (p.res != nullptr) v += p.res[(size_t)m * t.N + n];
+        if (p.res != nullptr) v += p.res[o];
         if (p.act) v = lrelu(v, p.slope);
-        p.out[(size_t)m * t.N + n] = v;
+        p.out[o] = v;
       }
     }
     return;
@@ -249,10 +369,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   double s1 = 0.0, s2 = 0.0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (nok && m < t.M) {
+    const int o = out_off(r);
+    if (o >= 0) {
       const float v = acc[r] + bv;
-      p.out[(size_t)m * t.N + n] = v;
+      p.out[o] = v;
       s1 += (double)v;
       s2 += (double)v * (double)v;
     }
@@ -268,20 +388,20 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   }
 }
 
-template <bool W_KN>
+template <bool W_KN, bool IN_BN>
 __global__ __launch_bounds__(kConvThreads) void conv_taps_kernel(ConvArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLds];
-  conv_body<W_KN>(p, blockIdx.x, smem);
+  __shared__ __attribute__((aligned(16))) float smem[kConvLds + (IN_BN ? kConvCoef : 0)];
+  conv_body<W_KN, IN_BN>(p, blockIdx.x, smem);
 }
 
-// HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, or a
-// block's conv1 and its shortcut) in ONE launch: twice the workgroups per launch at batch 512, where a
-// single layer only fills each CU with one workgroup.
-template <bool W_KN>
+// HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, a block's conv1
+// and its shortcut, or the even / odd output phases of a stride-2 input-gradient) in ONE launch: twice the
+// workgroups per launch at batch 512, where a single layer only fills each CU with one workgroup.
+template <bool W_KN, bool IN_BN>
 __global__ __launch_bounds__(kConvThreads) void conv_taps_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLds];
-  if ((int)blockIdx.x < nblk_a) conv_body<W_KN>(a, blockIdx.x, smem);
-  else conv_body<W_KN>(b, blockIdx.x - nblk_a, smem);
+  __shared__ __attribute__((aligned(16))) float smem[kConvLds + (IN_BN ? kConvCoef : 0)];
+  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, IN_BN>(a, blockIdx.x, smem);
+  else conv_body<W_KN, IN_BN>(b, blockIdx.x - nblk_a, smem);
 }
 
 static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
@@ -290,17 +410,33 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   a.A = hp::ptr<const float>(op, 0, bases);
   a.W = hp::ptr<const float>(op, 1, bases);
   a.out = hp::ptr<float>(op, 2, bases);
-  a.bias = (op.flags & 2) ? hp::ptr<const float>(op, 3, bases) : nullptr;
-  a.stats = (op.flags & 4) ? hp::ptr<double>(op, 4, bases) : nullptr;
-  a.bn_eval = (op.flags & 8) ? 1 : 0;
-  a.act = (op.flags & 16) ? 1 : 0;
-  a.gamma = a.beta = a.rmean = a.rvar = a.res = nullptr;
+  a.bias = (op.flags & HP_CONV_BIAS) ? hp::ptr<const float>(op, 3, bases) : nullptr;
+  a.stats = (op.flags & HP_CONV_STATS) ? hp::ptr<double>(op, 4, bases) : nullptr;
+  a.A2 = hp::ptr<const float>(op, 10, bases);
+  a.W2 = hp::ptr<const float>(op, 11, bases);
+  a.bn_eval = (op.flags & HP_CONV_BN_EVAL) ? 1 : 0;
+  a.act = (op.flags & HP_CONV_ACT) ? 1 : 0;
+  a.gamma = a.beta = a.res = nullptr;
+  a.rmean = a.rvar = nullptr;
   a.eps = op.f[0]; a.slope = op.f[1];
-  if (a.bn_eval) {
+  if (a.bn_eval || (op.flags & HP_CONV_IN_BN)) {
     a.gamma = hp::ptr<const float>(op, 5, bases); a.beta = hp::ptr<const float>(op, 6, bases);
-    a.rmean = hp::ptr<const float>(op, 7, bases); a.rvar = hp::ptr<const float>(op, 8, bases);
-    a.res = hp::ptr<const float>(op, 9, bases);
+    a.rmean = hp::ptr<float>(op, 7, bases); a.rvar = hp::ptr<float>(op, 8, bases);
   }
+  if (a.bn_eval) a.res = hp::ptr<const float>(op, 9, bases);
+  a.in_bn = (op.flags & HP_CONV_IN_BN) ? 1 : 0;
+  a.in_Mstat = op.i[31] * (op.i[32] > 1 ? op.i[32] : 1);
+  a.in_stats = hp::ptr<const double>(op, 12, bases);
+  a.in_save = hp::ptr<float>(op, 13, bases);
+  a.in_coef = hp::ptr<float>(op, 14, bases);
+  a.in_slope = op.f[2]; a.in_eps = op.f[3]; a.in_mom = op.f[4];
+  a.epi = (op.flags & HP_CONV_EPI_BNRED) ? 1 : 0;
+  a.e_g2 = hp::ptr<const float>(op, 15, bases); a.e_act = hp::ptr<const float>(op, 16, bases);
+  a.e_raw = hp::ptr<const float>(op, 17, bases); a.e_save = hp::ptr<const float>(op, 18, bases);
+  a.e_coef = hp::ptr<const float>(op, 19, bases); a.e_bs = hp::ptr<double>(op, 20, bases);
+  a.e_raw2 = hp::ptr<const float>(op, 21, bases); a.e_save2 = hp::ptr<const float>(op, 22, bases);
+  a.e_bs2 = hp::ptr<double>(op, 23, bases);
+  a.e_slope = op.f[5];
   return a;
 }
 
@@ -308,16 +444,23 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
   if ((opa.flags & 1) != (opb.flags & 1)) return hipErrorInvalidValue;
   const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
   const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
-  if (opa.flags & 1) hipLaunchKernelGGL(conv_taps_pair_kernel<true>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
-  else               hipLaunchKernelGGL(conv_taps_pair_kernel<false>, dim3(na + nb), dim3(kConvThreads), 0, s, a, b, na);
+  const bool kn = opa.flags & 1, inbn = (opa.flags | opb.flags) & HP_CONV_IN_BN;
+  const dim3 g(na + nb), th(kConvThreads);
+  if (kn && inbn)       hipLaunchKernelGGL((conv_taps_pair_kernel<true, true>), g, th, 0, s, a, b, na);
+  else if (kn)          hipLaunchKernelGGL((conv_taps_pair_kernel<true, false>), g, th, 0, s, a, b, na);
+  else if (inbn)        hipLaunchKernelGGL((conv_taps_pair_kernel<false, true>), g, th, 0, s, a, b, na);
+  else                  hipLaunchKernelGGL((conv_taps_pair_kernel<false, false>), g, th, 0, s, a, b, na);
   return hipGetLastError();
 }
 
 hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
   const ConvArgs a = conv_args_from(op, bases);
-  const int nblk = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64);
-  if (op.flags & 1) hipLaunchKernelGGL(conv_taps_kernel<true>, dim3(nblk), dim3(kConvThreads), 0, s, a);
-  else              hipLaunchKernelGGL(conv_taps_kernel<false>, dim3(nblk), dim3(kConvThreads), 0, s, a);
+  const dim3 g(hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64)), th(kConvThreads);
+  const bool kn = op.flags & 1, inbn = op.flags & HP_CONV_IN_BN;
+  if (kn && inbn)       hipLaunchKernelGGL((conv_taps_kernel<true, true>), g, th, 0, s, a);
+  else if (kn)          hipLaunchKernelGGL((conv_taps_kernel<true, false>), g, th, 0, s, a);
+  else if (inbn)        hipLaunchKernelGGL((conv_taps_kernel<false, true>), g, th, 0, s, a);
+  else                  hipLaunchKernelGGL((conv_taps_kernel<false, false>), g, th, 0, s, a);
   return hipGetLastError();
 }
 
@@ -328,6 +471,8 @@ hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t 
 // ------------------------------------------------------------------------------------
 struct WgradArgs {
   const float* DY; const float* X; float* slab;
+  const float* coef;   // HP_CONV_IN_BN: X is a raw BatchNorm input; the operand is leaky_relu(fma(x, scale, shift))
+  float slope;
   TapMap t;
   int nsplit, rows_per_split, slab_stride;
   int atomic;   // 1: accumulate into `slab` (= the zeroed gradient tensor) with fp32 atomics, no slabs
@@ -365,6 +510,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
     rl_[j] = m - rb_[j] * t.Lout;
   }
   const int q32 = 32 / t.Lout, r32 = 32 - q32 * t.Lout;
+  // input BatchNorm coefficients of this thread's four channels (fixed for the whole block)
+  const bool x_bn = p.coef != nullptr;
+  float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x_bn && c0 + cq < t.K) {
+    xsc = gload4(p.coef + c0 + cq);
+    xsh = gload4(p.coef + t.K + c0 + cq);
+  }
+  const float xslope = p.slope;
   auto load_regs = [&](int mb) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -379,9 +532,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
 #pragma unroll
       for (int tau = 0; tau < NT; ++tau) {
         const int pos = al + t.tap_o[tau];
-        const bool ok = mv && pos >= 0 && pos < t.P && (!t.even || !(pos & 1)) && (c0 + cq < t.K);
+        const bool ok = mv && pos >= 0 && pos < t.P && (c0 + cq < t.K);
         rx[tau][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) rx[tau][j] = gload4(gX + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
+        if (ok) {
+          float4 v = gload4(gX + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
+          if (x_bn) {     // the activation the forward conv consumed, re-evaluated bit for bit
+            v.x = lrelu(fmaf(v.x, xsc.x, xsh.x), xslope); v.y = lrelu(fmaf(v.y, xsc.y, xsh.y), xslope);
+            v.z = lrelu(fmaf(v.z, xsc.z, xsh.z), xslope); v.w = lrelu(fmaf(v.w, xsc.w, xsh.w), xslope);
+          }
+          rx[tau][j] = v;
+        }
       }
     }
   };
@@ -479,6 +639,8 @@ static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {
   a.DY = hp::ptr<const float>(op, 0, bases);
   a.X = hp::ptr<const float>(op, 1, bases);
   a.slab = hp::ptr<float>(op, 2, bases);
+  a.coef = (op.flags & HP_CONV_IN_BN) ? hp::ptr<const float>(op, 3, bases) : nullptr;
+  a.slope = op.f[0];
   a.nsplit = op.i[22];
   a.rows_per_split = op.i[23];
   a.slab_stride = op.i[24];

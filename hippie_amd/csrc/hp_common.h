@@ -40,40 +40,86 @@ __device__ __forceinline__ void atomic_add_f32_global(float* p, float v) {
   __builtin_amdgcn_global_atomic_fadd_f32((float __attribute__((address_space(1)))*)p, v);
 }
 
-// sum of one entry of a replicated statistics slot double[HP_STAT_REPL][2][C]
-// Both entries (which = 0, 1) of channel c summed over the replicas.  All 2*HP_STAT_REPL loads are issued
-// before anything consumes them (sched_barrier: otherwise the scheduler interleaves the adds and the prologue
-// of every BatchNorm kernel becomes a chain of dependent L2 round trips, ~5 us), then two pairwise trees.
-__device__ __forceinline__ void stat_sum2(const double* st, int C, int c, double& s0, double& s1) {
+// Replicated statistics slot double[R][2][C], R = hp_stat_repl(C) (include/hippie_hip.h).
+// Both entries (which = 0, 1) of channel c summed over the replicas.  All 2*R loads are issued before anything
+// consumes them (sched_barrier: otherwise the scheduler interleaves the adds and the prologue of every BatchNorm
+// consumer becomes a chain of dependent L2 round trips, ~5 us), then two pairwise trees.
+template <int R>
+__device__ __forceinline__ void stat_sum2_r(const double* st, int C, int c, double& s0, double& s1) {
   const double* p = st + c;
   const size_t stride = (size_t)2 * C;
-  double a[HP_STAT_REPL], b[HP_STAT_REPL];
+  double a[R], b[R];
 #pragma unroll
-  for (int r = 0; r < HP_STAT_REPL; ++r) {
+  for (int r = 0; r < R; ++r) {
     a[r] = p[r * stride];
     b[r] = p[r * stride + C];
   }
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int w = HP_STAT_REPL / 2; w > 0; w >>= 1) {
+  for (int w = R / 2; w > 0; w >>= 1) {
 #pragma unroll
     for (int r = 0; r < w; ++r) { a[r] += a[r + w]; b[r] += b[r + w]; }
   }
   s0 = a[0];
   s1 = b[0];
 }
-__device__ __forceinline__ double stat_sum(const double* st, int C, int which, int c) {
-  double s0, s1;
-  stat_sum2(st, C, c, s0, s1);
-  return which ? s1 : s0;
+__device__ __forceinline__ void stat_sum2(const double* st, int C, int c, double& s0, double& s1) {
+  switch (hp_stat_repl(C)) {          // uniform: one of 2, 4, 8, 16
+    case 2: stat_sum2_r<2>(st, C, c, s0, s1); break;
+    case 4: stat_sum2_r<4>(st, C, c, s0, s1); break;
+    case 8: stat_sum2_r<8>(st, C, c, s0, s1); break;
+    default: stat_sum2_r<16>(st, C, c, s0, s1); break;
+  }
 }
 __device__ __forceinline__ double* stat_replica(double* st, int C, int key) {
-  return st + (size_t)(key % HP_STAT_REPL) * 2 * C;
+  return st + (size_t)(key % hp_stat_repl(C)) * 2 * C;
 }
 
 __device__ __forceinline__ float lrelu(float x, float slope) { return x > 0.f ? x : x * slope; }
 // derivative expressed on the OUTPUT of leaky_relu (sign(out) == sign(in) for slope > 0)
 __device__ __forceinline__ float lrelu_grad(float out, float slope) { return out > 0.f ? 1.f : slope; }
+
+// ---- BatchNorm coefficients: ONE derivation shared by every kernel that normalises (HP_OP_BN_APPLY, the
+// HP_CONV_IN_BN operand loader): identical inputs -> bit-identical (scale, shift) wherever they are re-derived.
+struct BnCoef { float mean, invstd, scale, shift, rm, rv; double var; };
+
+// every global load (gamma, beta, running stats, all statistic replicas) is issued before the first use: one
+// memory round trip instead of one per operand
+__device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* stats, int C, int c, const float* gamma,
+                                          const float* beta, const float* rmean, const float* rvar, float eps) {
+  BnCoef k;
+  const float g = gamma[c], b = beta[c];
+  k.rm = rmean[c]; k.rv = rvar[c];
+  double mean, var;
+  if (training) {
+    double s0, s1;
+    stat_sum2(stats, C, c, s0, s1);
+    mean = s0 / (double)M;
+    var = s1 / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+  } else {
+    mean = (double)k.rm;
+    var = (double)k.rv;
+  }
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double sc = (double)g * invstd;
+  k.mean = (float)mean; k.invstd = (float)invstd; k.var = var;
+  k.scale = (float)sc; k.shift = (float)((double)b - mean * sc);
+  return k;
+}
+
+// training-mode side effects of one channel: saved (mean, invstd) for the backward pass, running statistics
+// (momentum update, unbiased variance); optionally the (scale, shift) pair for consumers that re-evaluate the
+// activation from the raw tensor
+__device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, int c, float* save, float* rmean,
+                                                float* rvar, float momentum, float* coef = nullptr) {
+  save[c] = k.mean;
+  save[C + c] = k.invstd;
+  if (coef != nullptr) { coef[c] = k.scale; coef[C + c] = k.shift; }
+  const double unb = M > 1 ? k.var * (double)M / (double)(M - 1) : k.var;
+  rmean[c] = (float)((1.0 - (double)momentum) * (double)k.rm + (double)momentum * (double)k.mean);
+  rvar[c] = (float)((1.0 - (double)momentum) * (double)k.rv + (double)momentum * unb);
+}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -8,6 +8,8 @@
 // one fp64 atomic per block.  Consecutive lanes touch consecutive channels (coalesced).
 #include "hp_common.h"
 
+#include <algorithm>
+
 namespace {
 
 constexpr int kRowsPerLane = 16;
@@ -54,33 +56,6 @@ __device__ __forceinline__ void fold_rowlanes(const ColMap& m, double (&v)[NV], 
       v[k] = s;
     }
   }
-}
-
-struct BnCoef { float mean, invstd, scale, shift, rm, rv; double var; };
-
-// every global load of the prologue (gamma, beta, running stats, all statistic replicas) is issued before the
-// first use: one memory round trip instead of one per operand
-__device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* stats, int C, int c, const float* gamma,
-                                          const float* beta, const float* rmean, const float* rvar, float eps) {
-  BnCoef k;
-  const float g = gamma[c], b = beta[c];
-  k.rm = rmean[c]; k.rv = rvar[c];
-  double mean, var;
-  if (training) {
-    double s0, s1;
-    stat_sum2(stats, C, c, s0, s1);
-    mean = s0 / (double)M;
-    var = s1 / (double)M - mean * mean;
-    if (var < 0.0) var = 0.0;
-  } else {
-    mean = (double)k.rm;
-    var = (double)k.rv;
-  }
-  const double invstd = 1.0 / sqrt(var + (double)eps);
-  const double sc = (double)g * invstd;
-  k.mean = (float)mean; k.invstd = (float)invstd; k.var = var;
-  k.scale = (float)sc; k.shift = (float)((double)b - mean * sc);
-  return k;
 }
 
 // ---- BN apply --------------------------------------------------------------------
@@ -143,15 +118,6 @@ struct BnApplyArgs {
   int Mstat;          // rows behind the statistics: M, or M * world under sync-BatchNorm (HP_OP_STATS_SYNC)
   float slope, eps, momentum;
 };
-
-__device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, int c, float* save, float* rmean,
-                                                float* rvar, float momentum) {
-  save[c] = k.mean;
-  save[C + c] = k.invstd;
-  const double unb = M > 1 ? k.var * (double)M / (double)(M - 1) : k.var;
-  rmean[c] = (float)((1.0 - (double)momentum) * (double)k.rm + (double)momentum * (double)k.mean);
-  rvar[c] = (float)((1.0 - (double)momentum) * (double)k.rv + (double)momentum * unb);
-}
 
 template <int V>
 __device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
@@ -250,6 +216,7 @@ struct BnBwdReduceArgs {
   const float* g1; const float* g2; const float* act; float* gout;
   const float* raw; const float* save; double* bs;
   const float* raw2; const float* save2; double* bs2;
+  const float* coef;     // act == nullptr: the activation was never stored; its sign is that of fma(raw, scale, shift)
   int M, C, has_second;
   float slope;
 };
@@ -262,19 +229,21 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
 #pragma unroll
   for (int j = 0; j < 3 * V; ++j) v[j] = 0.0;
   if (m.active) {
-    float mean[V], invstd[V], mean2[V], invstd2[V];
+    float mean[V], invstd[V], mean2[V], invstd2[V], csc[V], csh[V];
+    const bool from_raw = p.act == nullptr;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       mean[j] = p.save[m.c + j]; invstd[j] = p.save[p.C + m.c + j];
-      mean2[j] = 0.f; invstd2[j] = 0.f;
+      mean2[j] = 0.f; invstd2[j] = 0.f; csc[j] = 0.f; csh[j] = 0.f;
       if (p.has_second) { mean2[j] = p.save2[m.c + j]; invstd2[j] = p.save2[p.C + m.c + j]; }
+      if (from_raw) { csc[j] = p.coef[m.c + j]; csh[j] = p.coef[p.C + m.c + j]; }
     }
     auto accumulate = [&](T g, T a, T x, T gg, T x2, size_t idx) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float gv = at<V>(g, j);
         if (p.g2 != nullptr) gv += at<V>(gg, j);
-        gv *= lrelu_grad(at<V>(a, j), p.slope);
+        gv *= lrelu_grad(from_raw ? fmaf(at<V>(x, j), csc[j], csh[j]) : at<V>(a, j), p.slope);
         at<V>(g, j) = gv;
         v[3 * j + 0] += (double)gv;
         v[3 * j + 1] += (double)gv * (double)((at<V>(x, j) - mean[j]) * invstd[j]);
@@ -296,8 +265,11 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
         for (int k = 0; k < NR; ++k) {
           idx[k] = (size_t)min(m.row + k * m.rstep, rlast) * p.C + m.c;
           g[k] = *reinterpret_cast<const T*>(p.g1 + idx[k]);
-          a[k] = *reinterpret_cast<const T*>(p.act + idx[k]);
           x[k] = *reinterpret_cast<const T*>(p.raw + idx[k]);
+        }
+        if (!from_raw) {
+#pragma unroll
+          for (int k = 0; k < NR; ++k) a[k] = *reinterpret_cast<const T*>(p.act + idx[k]);
         }
         if (p.g2 != nullptr) {
 #pragma unroll
@@ -318,8 +290,9 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
       for (int r = m.row; r < m.rend; r += m.rstep) {
         const size_t idx = (size_t)r * p.C + m.c;
         T g = *reinterpret_cast<const T*>(p.g1 + idx);
-        T a = *reinterpret_cast<const T*>(p.act + idx);
         T x = *reinterpret_cast<const T*>(p.raw + idx);
+        T a = x;
+        if (!from_raw) a = *reinterpret_cast<const T*>(p.act + idx);
         T gg = g, x2 = x;
         if (p.g2 != nullptr) gg = *reinterpret_cast<const T*>(p.g2 + idx);
         if (p.has_second) x2 = *reinterpret_cast<const T*>(p.raw2 + idx);
@@ -964,6 +937,15 @@ __global__ void resample_linear_kernel(const float* in, float* out, int N, int W
   if (log1) { a = logf(a + 1.f); b = logf(b + 1.f); }
   out[id] = w0 * a + w1 * b;
 }
+// HP_OP_ZERO as a plain kernel node (not hipMemsetAsync): inside a captured hipGraph a memset node is executed by
+// a different engine than the kernel nodes around it, and replays of graphs that START with memset nodes were
+// observed to race with the previous replay's tail on this runtime (wrong gradients on the second replay of the
+// zipped two-model program, tools/debug/pair_probe.py).  A kernel is ordered like every other node.
+__global__ __launch_bounds__(256) void zero_kernel(uint4* p16, size_t n16, uint8_t* tail, int ntail) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
 __global__ void step_inc_kernel(int64_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
 
 inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / per); }
@@ -991,6 +973,7 @@ BnBwdReduceArgs bn_bwd_reduce_args(const HpOp& op, void* const* bases) {
   a.act = ptr<const float>(op, 2, bases); a.gout = ptr<float>(op, 3, bases);
   a.raw = ptr<const float>(op, 4, bases); a.save = ptr<const float>(op, 5, bases); a.bs = ptr<double>(op, 6, bases);
   a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
+  a.coef = ptr<const float>(op, 10, bases);
   a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
   return a;
 }
@@ -1218,8 +1201,16 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     case HP_OP_STEP_INC:
       hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, ptr<int64_t>(op, 0, bases));
       break;
-    case HP_OP_ZERO:
-      return hipMemsetAsync(ptr<void>(op, 0, bases), 0, (size_t)(uint32_t)I[0] + ((size_t)(uint32_t)I[1] << 32), s);
+    case HP_OP_ZERO: {
+      uint8_t* dst = ptr<uint8_t>(op, 0, bases);
+      const size_t nbytes = (size_t)(uint32_t)I[0] + ((size_t)(uint32_t)I[1] << 32);
+      if (nbytes == 0) return hipSuccess;
+      if (((uintptr_t)dst & 15) != 0) return hipMemsetAsync(dst, 0, nbytes, s);      // never the case for planner output
+      const size_t n16 = nbytes >> 4;
+      const int grid = (int)std::min<size_t>(2048, std::max<size_t>(1, (n16 + 255) / 256));
+      hipLaunchKernelGGL(zero_kernel, dim3(grid), dim3(256), 0, s, reinterpret_cast<uint4*>(dst), n16, dst + (n16 << 4), (int)(nbytes & 15));
+      break;
+    }
     default:
       return hipErrorInvalidValue;
   }

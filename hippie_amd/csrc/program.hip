@@ -76,49 +76,68 @@ int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
   for (auto& v : need) v = 0;
   const int32_t* I = op.i;
   const int64_t f4 = 4, f8 = 8;
-  const int64_t stat = (int64_t)HP_STAT_REPL * 2 * f8;      // per channel
+  auto stat = [&](int64_t C) { return (int64_t)hp_stat_repl((int)C) * 2 * C * f8; };      // replicated slot of C channels
   auto rows_in = [&]() { return (int64_t)(I[3] > 0 ? I[0] / I[3] : 0) * I[4]; };      // (M / Lout) * Lin
   auto max_tapw = [&]() { int m = 0; for (int j = 0; j < I[9] && j < HP_MAX_TAPS; ++j) m = I[16 + j] > m ? I[16 + j] : m; return (int64_t)m + 1; };
   auto strided = [&](int64_t rows, int64_t ld, int64_t w) { return rows > 0 ? ((rows - 1) * ld + w) * f4 : 0; };
   switch (op.op) {
     case HP_OP_CONV_TAPS: {
       const int64_t M = I[0], N = I[1], K = I[2];
-      need[0] = rows_in() * K * f4; need[1] = max_tapw() * N * K * f4; need[2] = M * N * f4;
+      const int64_t out_rows = I[28] > 0 ? (int64_t)(I[3] > 0 ? M / I[3] : 0) * I[28] : M;     // rows of the (taller) output tensor
+      bool src0 = false, src1 = false;
+      int64_t w0 = 0, w1 = 0;
+      for (int j = 0; j < I[9] && j < HP_MAX_TAPS; ++j) {
+        if (I[22 + j]) { src1 = true; w1 = I[16 + j] + 1 > w1 ? I[16 + j] + 1 : w1; }
+        else { src0 = true; w0 = I[16 + j] + 1 > w0 ? I[16 + j] + 1 : w0; }
+      }
+      if (src0) { need[0] = rows_in() * K * f4; need[1] = w0 * N * K * f4; }
+      if (src1) { need[10] = rows_in() * K * f4; need[11] = w1 * N * K * f4; }
+      need[2] = out_rows * N * f4;
+      if (op.flags & HP_CONV_IN_BN) { need[5] = need[6] = need[7] = need[8] = K * f4; need[12] = stat(K); need[13] = need[14] = 2 * K * f4; }
+      if (op.flags & HP_CONV_EPI_BNRED) {
+        const int64_t ON = out_rows * N * f4;
+        need[17] = ON; need[18] = 2 * N * f4; need[20] = stat(N);
+        if (op.buf[15] != HP_NULL) need[15] = ON;
+        if (op.buf[16] != HP_NULL) need[16] = ON; else need[19] = 2 * N * f4;
+        if (op.buf[21] != HP_NULL) { need[21] = ON; need[22] = 2 * N * f4; need[23] = stat(N); }
+      }
       if (op.flags & 2) need[3] = N * f4;
-      if (op.flags & 4) need[4] = N * stat;
+      if (op.flags & 4) need[4] = stat(N);
       if (op.flags & 8) { need[5] = need[6] = need[7] = need[8] = N * f4; if (op.buf[9] != HP_NULL) need[9] = M * N * f4; }
       break;
     }
     case HP_OP_WGRAD_TAPS: {
       const int64_t M = I[0], N = I[1], K = I[2];
       need[0] = M * N * f4; need[1] = rows_in() * K * f4;
+      if (op.flags & HP_CONV_IN_BN) need[3] = 2 * K * f4;
       need[2] = (op.flags & 1) ? max_tapw() * N * K * f4 : ((int64_t)(I[22] - 1) * I[24] + max_tapw() * N * K) * f4;
       break;
     }
     case HP_OP_SLAB_REDUCE: need[0] = ((int64_t)(I[1] - 1) * I[2] + I[0]) * f4; need[1] = (int64_t)I[0] * f4; break;
     case HP_OP_BN_APPLY: {
       const int64_t MC = (int64_t)I[0] * I[1] * f4, C = (int64_t)I[1] * f4;
-      need[0] = need[1] = MC; if (I[3]) need[2] = I[1] * stat;
+      need[0] = need[1] = MC; if (I[3]) need[2] = stat(I[1]);
       need[3] = need[4] = need[5] = need[6] = C; need[7] = 2 * C;
       if (I[2]) need[8] = MC;
-      if (I[2] == 2) { if (I[3]) need[9] = I[1] * stat; need[10] = need[11] = need[12] = need[13] = C; need[14] = 2 * C; }
+      if (I[2] == 2) { if (I[3]) need[9] = stat(I[1]); need[10] = need[11] = need[12] = need[13] = C; need[14] = 2 * C; }
       break;
     }
     case HP_OP_BN_BWD_REDUCE: {
       const int64_t MC = (int64_t)I[0] * I[1] * f4, C = (int64_t)I[1] * f4;
       need[0] = need[2] = need[3] = need[4] = MC; if (I[2]) need[1] = MC;
-      need[5] = 2 * C; need[6] = I[1] * stat;
-      if (I[3]) { need[7] = MC; need[8] = 2 * C; need[9] = I[1] * stat; }
+      need[5] = 2 * C; need[6] = stat(I[1]);
+      if (I[3]) { need[7] = MC; need[8] = 2 * C; need[9] = stat(I[1]); }
+      if (op.buf[2] == HP_NULL) { need[2] = 0; need[10] = 2 * C; }
       break;
     }
     case HP_OP_BN_BWD_APPLY: {
       const int64_t MC = (int64_t)I[0] * I[1] * f4, C = (int64_t)I[1] * f4;
-      need[0] = need[1] = need[5] = MC; need[2] = 2 * C; need[3] = I[1] * stat; need[4] = need[6] = need[7] = C;
+      need[0] = need[1] = need[5] = MC; need[2] = 2 * C; need[3] = stat(I[1]); need[4] = need[6] = need[7] = C;
       break;
     }
     case HP_OP_STEM_FWD:
       need[0] = (int64_t)I[0] * I[1] * f4; need[1] = (int64_t)I[3] * 3 * f4; need[2] = (int64_t)I[0] * I[2] * I[3] * f4;
-      if (op.buf[3] != HP_NULL) need[3] = I[3] * stat;
+      if (op.buf[3] != HP_NULL) need[3] = stat(I[3]);
       break;
     case HP_OP_STEM_WGRAD:
       need[0] = (int64_t)I[0] * I[2] * I[3] * f4; need[1] = (int64_t)I[0] * I[1] * f4; need[2] = (int64_t)I[3] * 3 * f4; break;
@@ -144,7 +163,7 @@ int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
       need[0] = strided(I[0], I[2], I[3] + I[1]); need[1] = (int64_t)I[0] * f8; need[2] = (int64_t)I[4] * I[1] * f4; break;
     case HP_OP_LINEAR_FWD:
       need[0] = strided(I[0], I[3], I[2]); need[1] = (int64_t)I[1] * I[2] * f4; if (op.buf[2] != HP_NULL) need[2] = (int64_t)I[1] * f4;
-      need[3] = strided(I[0], I[4], I[1]); if (I[6]) need[4] = I[1] * stat;
+      need[3] = strided(I[0], I[4], I[1]); if (I[6]) need[4] = stat(I[1]);
       break;
     case HP_OP_LINEAR_BWD_X:
       need[0] = strided(I[0], I[3], I[1]); need[1] = (int64_t)I[1] * I[2] * f4; need[2] = strided(I[0], I[4], I[2]);
@@ -214,7 +233,13 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
     const int M = op.i[0], N = op.i[1], K = op.i[2], nt = op.i[9];
     bool ok = M > 0 && N > 0 && K > 0 && (K % 4) == 0 && (N % 4) == 0 && op.i[3] > 0 && op.i[4] > 0 && nt >= 1 &&
               nt <= HP_MAX_TAPS && op.i[6] >= 1 && op.i[7] >= 0 && op.i[7] <= 1;
-    if (op.op == HP_OP_CONV_TAPS) ok = ok && (K % 32) == 0;
+    if (op.op == HP_OP_CONV_TAPS) {
+      ok = ok && (K % 32) == 0 && op.i[28] >= 0;
+      if (op.i[28] > 0) ok = ok && op.i[29] >= 1 && op.i[30] >= 0 && (int64_t)op.i[29] * (op.i[3] - 1) + op.i[30] < op.i[28];
+      if (op.flags & HP_CONV_IN_BN) ok = ok && K <= 512 && op.i[31] > 0 && !(op.flags & HP_CONV_BN_EVAL);     // coefficient table in LDS
+      if (op.flags & HP_CONV_EPI_BNRED) ok = ok && !(op.flags & (HP_CONV_BIAS | HP_CONV_STATS | HP_CONV_BN_EVAL));
+      for (int j = 0; j < nt && j < HP_MAX_TAPS; ++j) ok = ok && (op.i[22 + j] == 0 || op.i[22 + j] == 1);
+    }
     if (op.op == HP_OP_WGRAD_TAPS)
       ok = ok && (nt == 1 || nt == 3) && op.i[22] >= 1 && op.i[23] > 0 && (op.i[23] % 32) == 0 &&
            (int64_t)op.i[22] * op.i[23] >= M;

@@ -26,7 +26,6 @@ SLOPE_HEADS = 0.2
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 ALIGN = 256
-STAT_REPL = 16          # HP_STAT_REPL
 
 
 @dataclass
@@ -55,6 +54,10 @@ class TrainCfg:
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
     fold_eval_bn: bool = True           # eval forward: BatchNorm (+residual, +leaky_relu) folded into the producing conv's epilogue
+    fuse_bn: bool = True                # training: a block's inner BatchNorm + leaky_relu is evaluated in its consumers' operand
+                                        # loaders (HP_CONV_IN_BN: the activation tensor is never written) and the BatchNorm-backward
+                                        # reduction runs in the epilogue of the input-gradient conv that produces its operand
+                                        # (HP_CONV_EPI_BNRED).  False: one launch per BatchNorm pass (HP_OP_BN_APPLY / BN_BWD_REDUCE)
     sync_bn_world: int = 0              # > 1: sync-BatchNorm over that many data-parallel ranks (HP_OP_STATS_SYNC markers)
     split_backward: bool = False        # emit the deferred wgrad GEMMs in two groups (decoder | encoder side) so that
                                         # Engine.backward(overlap=True) can run the first under the encoder-side chain
@@ -110,6 +113,7 @@ class Plan:
         self._boff = 0
         self._ws = 0
         self.stats_bytes = 0
+        self.act_sites = []                  # leaky-ReLU sites of the training forward (tests read the branches taken back)
         self.slab_need = 0                   # floats
         self.flops_fwd = 0                   # 2*MAC of conv + linear, forward
 
@@ -144,10 +148,10 @@ class Plan:
         return self.ws(4 * n, name, shape if shape is not None else (n,), "f4")
 
     def stat(self, ndoubles, replicated=True):
-        """fp64 accumulator slots inside the zeroed-every-step statistics region; per-channel slots
-        are replicated STAT_REPL times (double[STAT_REPL][2][C])."""
+        """fp64 accumulator slots inside the zeroed-every-step statistics region; per-channel slots (ndoubles = 2*C)
+        are replicated hp_stat_repl(C) times (double[R][2][C])."""
         if replicated:
-            ndoubles *= STAT_REPL
+            ndoubles *= P.stat_repl(ndoubles // 2)
         off = _round_up(self.stats_bytes, 64)
         self.stats_bytes = off + 8 * ndoubles
         assert self.stats_bytes <= self.stats_cap, "statistics region overflow"
@@ -252,9 +256,38 @@ class Lowering:
         return dict(w=wm, b=bm, N=2 * z, K=z)
 
     # ---- op emitters --------------------------------------------------------------
-    def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note=""):
+    def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note="", a2=None, w2: PInfo = None,
+             in_bn=None, epi=None):
+        """One HP_OP_CONV_TAPS record.  in_bn = dict(bn, stats, M): the A operand is leaky_relu(bn(a)) evaluated in
+        the loader (HP_CONV_IN_BN).  epi = a reduction spec (red_spec): HP_OP_BN_BWD_REDUCE fused into the epilogue,
+        `out` must be the spec's g tensor."""
         flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias is not None else 0) | (P.CONV_STATS if stats is not None else 0)
-        self.o.add(P.CONV_TAPS, flags, i=tm.ints(), buf=[a, w.ref, out, bias.ref if bias is not None else None, stats], note=note)
+        ii = tm.conv_ints() + [0, 0]
+        ff = [0.0] * 6
+        bufs = [a, w.ref, out, bias.ref if bias is not None else None, stats] + [None] * 19
+        if a2 is not None:
+            bufs[10], bufs[11] = a2, w2.ref
+        if in_bn is not None:
+            bn = in_bn["bn"]
+            flags |= P.CONV_IN_BN
+            bn["save"], bn["coef"] = self.pl.f32(2 * bn["C"]), self.pl.f32(2 * bn["C"])
+            W = self.train.sync_bn_world
+            if W > 1:
+                self.stats_sync(in_bn["stats"], bn["C"], bn["prefix"])
+            ii[31], ii[32] = in_bn["M"], W
+            ff[2], ff[3], ff[4] = SLOPE_BACKBONE, BN_EPS, BN_MOMENTUM
+            bufs[5:9] = [bn["gamma"].ref, bn["beta"].ref, bn["rmean"].ref, bn["rvar"].ref]
+            bufs[12:15] = [in_bn["stats"], bn["save"], bn["coef"]]
+            self.pl.act_sites.append(dict(key=bn["prefix"], M=in_bn["M"], C=bn["C"], kind="raw", raw=a, coef=bn["coef"]))
+            note += " <- lrelu(" + bn["prefix"] + ") in the loader"
+        if epi is not None:
+            assert out is epi["g"]
+            flags |= P.CONV_EPI_BNRED
+            ff[5] = epi["slope"]
+            bufs[15:24] = [epi["g2"], epi["act"], epi["raw"], epi["bn"]["save"], epi["coef"], epi["bs"], epi["raw_b"],
+                           epi["bn_b"]["save"] if epi["bn_b"] is not None else None, epi["bs_b"]]
+            note += " + " + epi["bn"]["prefix"] + " bwd-reduce"
+        self.o.add(P.CONV_TAPS, flags, i=ii, f=ff, buf=bufs, note=note)
         self.conv_rec_of[out.encode()] = len(self.o.recs) - 1
         if self.count_flops and not w_kn:
             self.pl.flops_fwd += 2 * tm.M * tm.N * tm.K * len(tm.taps)
@@ -272,7 +305,10 @@ class Lowering:
         rb["flags"] = int(rb["flags"]) | P.FLAG_MEMBER
         self.o.add(P.PAIR, 0, i=[a, b], note=note)
 
-    def wgrad(self, tm: TapMap, dy, x, w: PInfo, note=""):
+    def wgrad(self, tm: TapMap, dy, x, w: PInfo, note="", coef=None):
+        """coef: x is the raw input of a BatchNorm whose activation was never stored (HP_CONV_IN_BN on the forward
+        conv): the kernel re-evaluates leaky_relu(fma(x, scale, shift)) from (scale, shift) = coef."""
+        xf = P.CONV_IN_BN if coef is not None else 0
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
         if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
             # deferred: all wgrads of the backward pass run in one grouped launch at its end.  With the
@@ -284,7 +320,7 @@ class Lowering:
                 nsplit = max(nsplit, -(-tm.M // 512))
             rps = _round_up(-(-tm.M // nsplit), 32)
             nsplit = -(-tm.M // rps)
-            self.pending_wgrads.append((tm, nsplit, rps, dy, x, w, note))
+            self.pending_wgrads.append((tm, nsplit, rps, dy, x, w, note, coef))
             return
         # enough workgroups to fill 256 CUs, but at least 256 rows (8 K-slices) per split so that the
         # tile's atomics / slab traffic stays small next to its MFMA work
@@ -292,10 +328,10 @@ class Lowering:
         rps = _round_up(-(-tm.M // nsplit), 32)
         nsplit = -(-tm.M // rps)
         if not self.train.deterministic_wgrad:
-            self.o.add(P.WGRAD_TAPS, 1, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
+            self.o.add(P.WGRAD_TAPS, 1 | xf, i=tm.ints() + [nsplit, rps, w.numel], f=[SLOPE_BACKBONE], buf=[dy, x, w.gref, coef], note=note)
             return
         self.pl.slab_need = max(self.pl.slab_need, nsplit * w.numel)
-        self.o.add(P.WGRAD_TAPS, 0, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, self.slab], note=note)
+        self.o.add(P.WGRAD_TAPS, xf, i=tm.ints() + [nsplit, rps, w.numel], f=[SLOPE_BACKBONE], buf=[dy, x, self.slab, coef], note=note)
         self.o.add(P.SLAB_REDUCE, 0, i=[w.numel, nsplit, w.numel], buf=[self.slab, w.gref], note=note + " reduce")
 
     def foldable(self, raw):
@@ -367,44 +403,74 @@ class Lowering:
             self.stats_sync(stats, bn["C"], bn["prefix"])
             if res_mode == 2:
                 self.stats_sync(stats2, bn2["C"], bn2["prefix"])
+        if training and act:
+            self.pl.act_sites.append(dict(key=bn["prefix"], M=M, C=bn["C"], kind="tensor", out=out))
         self.o.add(P.BN_APPLY, 0, i=[M, bn["C"], res_mode, 1 if training else 0, 1 if act else 0, W],
                    f=[slope, BN_EPS, BN_MOMENTUM], buf=bufs, note=bn["prefix"])
 
     def stats_sync(self, slot, C, prefix):
         """sync-BatchNorm: the replicated fp64 slot must be summed over the data-parallel ranks here."""
-        self.o.add(P.STATS_SYNC, 0, i=[STAT_REPL * 2 * C], buf=[slot], note=prefix + " statistics all-reduce")
+        self.o.add(P.STATS_SYNC, 0, i=[P.stat_repl(C) * 2 * C], buf=[slot], note=prefix + " statistics all-reduce")
 
-    def bn_bwd(self, M, bn, g1, g2, act, raw, slope, bn_b=None, raw_b=None):
-        """returns (g, dr, dr_b): masked upstream gradient and BN input gradients."""
+    # BatchNorm backward = a reduction (mask, sum g, sum g*xhat) + an apply.  The reduction either runs as its own
+    # launch (reduce_op) or in the epilogue of the input-gradient conv that produces its operand (conv(epi=spec)).
+    def red_spec(self, M, bn, act, raw, g2=None, bn_b=None, raw_b=None, slope=SLOPE_BACKBONE):
+        """act None: the activation was never stored (HP_CONV_IN_BN consumer); its sign comes from raw + bn["coef"]."""
         C = bn["C"]
-        g = self.pl.f32(M * C)
-        bs = self.pl.stat(2 * C)
-        bufs = [g1, g2, act, g, raw, bn["save"], bs]
-        bs_b = None
-        if bn_b is not None:
-            bs_b = self.pl.stat(2 * C)
-            bufs += [raw_b, bn_b["save"], bs_b]
-        self.o.add(P.BN_BWD_REDUCE, 0, i=[M, C, 1 if g2 is not None else 0, 1 if bn_b is not None else 0], f=[slope],
-                   buf=bufs, note=bn["prefix"] + " bwd-reduce")
-        W = self.train.sync_bn_world
-        if W > 1:
-            self.stats_sync(bs, C, bn["prefix"] + " bwd")
-            if bn_b is not None:
-                self.stats_sync(bs_b, C, bn_b["prefix"] + " bwd")
+        return dict(M=M, C=C, bn=bn, act=act, raw=raw, g2=g2, bn_b=bn_b, raw_b=raw_b, slope=slope,
+                    coef=bn["coef"] if act is None else None,
+                    g=self.pl.f32(M * C), bs=self.pl.stat(2 * C), bs_b=self.pl.stat(2 * C) if bn_b is not None else None)
+
+    def reduce_sync(self, sp):
+        if self.train.sync_bn_world > 1:
+            self.stats_sync(sp["bs"], sp["C"], sp["bn"]["prefix"] + " bwd")
+            if sp["bn_b"] is not None:
+                self.stats_sync(sp["bs_b"], sp["C"], sp["bn_b"]["prefix"] + " bwd")
+
+    def reduce_op(self, sp, g1):
+        bn, bn_b = sp["bn"], sp["bn_b"]
+        bufs = [g1, sp["g2"], sp["act"], sp["g"], sp["raw"], bn["save"], sp["bs"],
+                sp["raw_b"], bn_b["save"] if bn_b is not None else None, sp["bs_b"], sp["coef"]]
+        self.o.add(P.BN_BWD_REDUCE, 0, i=[sp["M"], sp["C"], 1 if sp["g2"] is not None else 0, 1 if bn_b is not None else 0],
+                   f=[sp["slope"]], buf=bufs, note=bn["prefix"] + " bwd-reduce")
+        self.reduce_sync(sp)
+
+    def apply_op(self, sp):
+        """-> (dr, dr_b): gradients of the BatchNorm inputs (conv outputs)."""
+        M, C, bn, bn_b, W = sp["M"], sp["C"], sp["bn"], sp["bn_b"], self.train.sync_bn_world
         dr = self.pl.f32(M * C)
-        self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[g, raw, bn["save"], bs, bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
+        self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[sp["g"], sp["raw"], bn["save"], sp["bs"], bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
                    note=bn["prefix"] + " bwd-apply")
         dr_b = None
         if bn_b is not None:
             dr_b = self.pl.f32(M * C)
-            self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[g, raw_b, bn_b["save"], bs_b, bn_b["gamma"].ref, dr_b,
+            self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[sp["g"], sp["raw_b"], bn_b["save"], sp["bs_b"], bn_b["gamma"].ref, dr_b,
                                                          bn_b["gamma"].gref, bn_b["beta"].gref], note=bn_b["prefix"] + " bwd-apply")
             self.pair_last_two("pair " + bn["prefix"] + " + shortcut bwd-apply")
-        return g, dr, dr_b
+        return dr, dr_b
+
+    def bn_bwd(self, M, bn, g1, g2, act, raw, slope, bn_b=None, raw_b=None):
+        """standalone reduce + apply; returns (g, dr, dr_b): masked upstream gradient and BN input gradients."""
+        sp = self.red_spec(M, bn, act, raw, g2, bn_b, raw_b, slope)
+        self.reduce_op(sp, g1)
+        dr, dr_b = self.apply_op(sp)
+        return sp["g"], dr, dr_b
+
+    def dgrad_reduce(self, tm, dr, w, sp, note):
+        """Input-gradient conv whose output feeds the BatchNorm-backward reduction `sp` (fused when fuse_bn)."""
+        if self.train.fuse_bn:
+            self.conv(tm, dr, w, sp["g"], w_kn=True, epi=sp, note=note)
+            self.reduce_sync(sp)
+        else:
+            tmp = self.pl.f32(tm.out_rows * tm.N)
+            self.conv(tm, dr, w, tmp, w_kn=True, note=note)
+            self.reduce_op(sp, tmp)
 
     def linear_fwd(self, M, lin, x, ldx, y, ldy, act=False, stats=None, note=""):
         self.o.add(P.LINEAR_FWD, 0, i=[M, lin["N"], lin["K"], ldx, ldy, 1 if act else 0, 1 if stats is not None else 0],
                    f=[SLOPE_HEADS], buf=[x, lin["w"].ref, lin["b"].ref, y, stats], note=note)
+        if act and self.count_flops:        # (count_flops marks the training forward)
+            self.pl.act_sites.append(dict(key=note.split(" ")[0], M=M, C=lin["N"], kind="tensor", out=y))
         if self.count_flops:
             self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
 
@@ -422,21 +488,31 @@ class Lowering:
         else:
             Lout = (Lin - 1) // stride + 1
             taps = [(0, 0)]
-        return TapMap(self.B * Lout, cout, cin, Lout, Lin, Lin, stride, 0, 0, taps), Lout
+        return TapMap(self.B * Lout, cout, cin, Lout, Lin, Lin, stride, 0, taps), Lout
 
     def map_fwd_up(self, Lin, cin, cout):
         Lout = 2 * Lin
-        return TapMap(self.B * Lout, cout, cin, Lout, Lin, 2 * Lin, 1, 1, 0, [(t - 1, t) for t in range(3)]), Lout
+        return TapMap(self.B * Lout, cout, cin, Lout, Lin, 2 * Lin, 1, 1, [(t - 1, t) for t in range(3)]), Lout
 
-    def map_dgrad(self, Lx, Ly, cin, cout, stride, k=3):
-        taps = [(1 - t, t) for t in range(3)] if k == 3 else [(0, 0)]
-        if stride == 1:
-            return TapMap(self.B * Lx, cin, cout, Lx, Ly, Ly, 1, 0, 0, taps)
-        return TapMap(self.B * Lx, cin, cout, Lx, Ly, 2 * Ly, 1, 1, 1, taps)
+    def map_dgrad(self, Lx, Ly, cin, cout):
+        """input-gradient of a stride-1 k=3 conv: dx[p] = sum_t dy[p + 1 - t] . w[t]"""
+        return TapMap(self.B * Lx, cin, cout, Lx, Ly, Ly, 1, 0, [(1 - t, t) for t in range(3)])
+
+    def map_dgrad_s2_phases(self, Lx, Ly, cin, cout):
+        """Input-gradient of an encoder stride-2 block with respect to its input x (length Lx), both paths at once:
+        conv1 (k=3, s=2, p=1: y[l] = sum_t x[2l+t-1] w[t], source 0) and the 1x1 stride-2 shortcut (ys[l] = x[2l] ws,
+        source 1).  By output parity, with only the taps that can contribute (no masked MFMA work):
+            dx[2l]   = dy[l] w[1] + dys[l] ws            dx[2l+1] = dy[l+1] w[0] + dy[l] w[2]
+        Two ops writing the interleaved rows of ONE tensor [B*Lx][cin]; the odd one is absent when Lx == 1."""
+        out = []
+        for q, n, taps in ((0, (Lx + 1) // 2, [(0, 1, 0), (0, 0, 1)]), (1, Lx // 2, [(1, 0, 0), (0, 2, 0)])):
+            if n > 0:
+                out.append(TapMap(self.B * n, cin, cout, n, Ly, Ly, 1, 0, taps, out_Lfull=Lx, out_a=2, out_o=q))
+        return out
 
     def map_dgrad_up(self, Lx, cin, cout):
         Ly = 2 * Lx
-        return TapMap(self.B * Lx, cin, cout, Lx, Ly, Ly, 2, 0, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)])
+        return TapMap(self.B * Lx, cin, cout, Lx, Ly, Ly, 2, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)])
 
     # ---- encoder ------------------------------------------------------------------
     def encoder_fwd(self, e, x, L, training):
@@ -465,12 +541,17 @@ class Lowering:
                 sts = pl.stat(2 * cout) if training else None
                 self.conv(tms, cur, blk["sc"], rs, stats=sts, note=blk["prefix"] + "shortcut.0")
                 self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut.0")
-            a1 = pl.f32(Mo * cout)
-            self.bn_apply(Mo, blk["bn1"], r1, a1, st1, training, True, SLOPE_BACKBONE)
             tm2, _ = self.map_fwd(Lo, cout, cout, 1)
             r2 = pl.f32(Mo * cout)
             st2 = pl.stat(2 * cout) if training else None
-            self.conv(tm2, a1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
+            if training and self.train.fuse_bn:
+                # lrelu(bn1(r1)) has exactly one consumer, conv2: evaluated in its operand loader, never stored
+                a1 = None
+                self.conv(tm2, r1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2", in_bn=dict(bn=blk["bn1"], stats=st1, M=Mo))
+            else:
+                a1 = pl.f32(Mo * cout)
+                self.bn_apply(Mo, blk["bn1"], r1, a1, st1, training, True, SLOPE_BACKBONE)
+                self.conv(tm2, a1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
             out = pl.f32(Mo * cout)
             blk.update(x=cur, Lin=Lc, Lout=Lo, r1=r1, a1=a1, r2=r2, out=out, tm1=tm1, tm2=tm2)
             if s == 1:
@@ -484,40 +565,64 @@ class Lowering:
         e.update(pooled=pooled, Llast=Lc, last=cur)
         return pooled
 
+    def enc_out_spec(self, e, bi, g2):
+        """reduction spec of the BatchNorm that produced the INPUT of encoder block bi (block bi-1's bn2 [+ shortcut
+        BN], or the stem's bn1 for bi == 0); g2 = the gradient arriving over the identity shortcut, if any."""
+        B = self.B
+        if bi == 0:
+            return self.red_spec(B * e["L1"], e["bn1"], e["a0"], e["raw0"], g2)
+        blk = e["blocks"][bi - 1]
+        M = B * blk["Lout"]
+        if blk["stride"] == 1:
+            return self.red_spec(M, blk["bn2"], blk["out"], blk["r2"], g2)
+        return self.red_spec(M, blk["bn2"], blk["out"], blk["r2"], g2, blk["scbn"], blk["rs"])
+
     def encoder_bwd(self, e, dpooled):
         """dpooled: [B][512] gradient of the pooled features."""
         pl, B = self.pl, self.B
         Lc = e["Llast"]
         G1 = pl.f32(B * Lc * 512)
         self.o.add(P.POOL_BWD, 0, i=[B, Lc, 512], buf=[dpooled, G1], note=e["prefix"] + "avgpool bwd")
-        G2 = None
-        for blk in reversed(e["blocks"]):
+        blocks = e["blocks"]
+        sp = self.enc_out_spec(e, len(blocks), None)          # the last block's output BatchNorm
+        self.reduce_op(sp, G1)
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk = blocks[bi]
             cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
             Lo, Li = blk["Lout"], blk["Lin"]
-            Mo, Mi = B * Lo, B * Li
+            Mo = B * Lo
+            p = blk["prefix"]
+            dr2, drs = self.apply_op(sp)
+            stored = blk["a1"] is not None
+            self.wgrad(blk["tm2"], dr2, blk["a1"] if stored else blk["r1"], blk["conv2"], note=p + "conv2 wgrad",
+                       coef=None if stored else blk["bn1"]["coef"])
+            sp1 = self.red_spec(Mo, blk["bn1"], blk["a1"], blk["r1"])
+            self.dgrad_reduce(self.map_dgrad(Lo, Lo, cout, cout), dr2, blk["conv2"], sp1, p + "conv2 dgrad")
+            dr1, _ = self.apply_op(sp1)
+            self.wgrad(blk["tm1"], dr1, blk["x"], blk["conv1"], note=p + "conv1 wgrad")
             if s == 1:
-                g, dr2, drs = self.bn_bwd(Mo, blk["bn2"], G1, G2, blk["out"], blk["r2"], SLOPE_BACKBONE)
+                # d/dx = conv1 path + identity shortcut (this block's masked gradient)
+                spp = self.enc_out_spec(e, bi, sp["g"])
+                self.dgrad_reduce(self.map_dgrad(Li, Lo, cin, cout), dr1, blk["conv1"], spp, p + "conv1 dgrad")
             else:
-                g, dr2, drs = self.bn_bwd(Mo, blk["bn2"], G1, G2, blk["out"], blk["r2"], SLOPE_BACKBONE, blk["scbn"], blk["rs"])
-            self.wgrad(blk["tm2"], dr2, blk["a1"], blk["conv2"], note=blk["prefix"] + "conv2 wgrad")
-            da1 = pl.f32(Mo * cout)
-            self.conv(self.map_dgrad(Lo, Lo, cout, cout, 1), dr2, blk["conv2"], da1, w_kn=True, note=blk["prefix"] + "conv2 dgrad")
-            _, dr1, _ = self.bn_bwd(Mo, blk["bn1"], da1, None, blk["a1"], blk["r1"], SLOPE_BACKBONE)
-            self.wgrad(blk["tm1"], dr1, blk["x"], blk["conv1"], note=blk["prefix"] + "conv1 wgrad")
-            dxa = pl.f32(Mi * cin)
-            if s != 1:
-                self.wgrad(blk["tms"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut wgrad")
-            self.conv(self.map_dgrad(Li, Lo, cin, cout, s), dr1, blk["conv1"], dxa, w_kn=True, note=blk["prefix"] + "conv1 dgrad")
-            if s == 1:
-                G1, G2 = dxa, g
-            else:
-                dxs = pl.f32(Mi * cin)
-                self.conv(self.map_dgrad(Li, Lo, cin, cout, s, k=1), drs, blk["sc"], dxs, w_kn=True, note=blk["prefix"] + "shortcut dgrad")
-                if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
-                    self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut dgrad")
-                G1, G2 = dxa, dxs
-        M = B * e["L1"]
-        _, dr0, _ = self.bn_bwd(M, e["bn1"], G1, G2, e["a0"], e["raw0"], SLOPE_BACKBONE)
+                self.wgrad(blk["tms"], drs, blk["x"], blk["sc"], note=p + "shortcut wgrad")
+                # conv1 and the 1x1 shortcut both differentiate w.r.t. the same x: one tensor, written by an even-row
+                # and an odd-row op (paired into one launch), each with only the taps that contribute
+                spp = self.enc_out_spec(e, bi, None)
+                fuse = self.train.fuse_bn
+                dst = spp["g"] if fuse else pl.f32(B * Li * cin)
+                tms = self.map_dgrad_s2_phases(Li, Lo, cin, cout)
+                for q, tm in enumerate(tms):
+                    self.conv(tm, dr1, blk["conv1"], dst, w_kn=True, a2=drs, w2=blk["sc"], epi=spp if fuse else None,
+                              note=p + "conv1 + shortcut dgrad, " + ("even" if tm.out_o == 0 else "odd") + " rows")
+                if len(tms) == 2:
+                    self.pair_last_two("pair " + p + "conv1 + shortcut dgrad (even | odd rows)")
+                if fuse:
+                    self.reduce_sync(spp)
+                else:
+                    self.reduce_op(spp, dst)
+            sp = spp
+        dr0, _ = self.apply_op(sp)
         self.o.add(P.STEM_WGRAD, 0, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
 
     # ---- decoder ------------------------------------------------------------------
@@ -538,14 +643,19 @@ class Lowering:
             r2 = pl.f32(Mi * cin)
             st2 = pl.stat(2 * cin) if training else None
             self.conv(tm2, cur, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
-            a2 = pl.f32(Mi * cin)
-            self.bn_apply(Mi, blk["bn2"], r2, a2, st2, training, True, SLOPE_BACKBONE)
+            if training and self.train.fuse_bn:
+                a2, src2 = None, r2                 # lrelu(bn2(r2)) is evaluated in conv1's operand loader
+                ib = dict(bn=blk["bn2"], stats=st2, M=Mi)
+            else:
+                a2 = src2 = pl.f32(Mi * cin)
+                ib = None
+                self.bn_apply(Mi, blk["bn2"], r2, a2, st2, training, True, SLOPE_BACKBONE)
             blk.update(x=cur, Lin=Lc, r2=r2, a2=a2, tm2=tm2)
             if s == 1:
                 tm1, Lo = self.map_fwd(Lc, cin, cout, 1)
                 r1 = pl.f32(Mi * cout)
                 st1 = pl.stat(2 * cout) if training else None
-                self.conv(tm1, a2, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1")
+                self.conv(tm1, src2, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1", in_bn=ib)
                 out = pl.f32(Mi * cout)
                 self.bn_apply(Mi, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 1, cur)
             else:
@@ -553,7 +663,7 @@ class Lowering:
                 Mo = B * Lo
                 r1 = pl.f32(Mo * cout)
                 st1 = pl.stat(2 * cout) if training else None
-                self.conv(tm1, a2, blk["conv1"], r1, bias=blk["conv1_b"], stats=st1, note=blk["prefix"] + "conv1 (resize)")
+                self.conv(tm1, src2, blk["conv1"], r1, bias=blk["conv1_b"], stats=st1, note=blk["prefix"] + "conv1 (resize)", in_bn=ib)
                 rs = pl.f32(Mo * cout)
                 sts = pl.stat(2 * cout) if training else None
                 self.conv(tm1, cur, blk["sc"], rs, bias=blk["sc_b"], stats=sts, note=blk["prefix"] + "shortcut (resize)")
@@ -582,32 +692,59 @@ class Lowering:
         self.o.add(P.TAIL_BWD_W, 0, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
         G1 = pl.f32(B * 32 * 64)
         self.o.add(P.TAIL_BWD_X, 0, i=[B, 32, 64], buf=[dt, d["tail_w"].ref, G1], note=d["prefix"] + "tail dX")
+        blocks = d["blocks"]
+
+        def out_spec(bi, g2):
+            blk = blocks[bi]
+            M = B * blk["Lout"]
+            if blk["stride"] == 1:
+                return self.red_spec(M, blk["bn1"], blk["out"], blk["r1"], g2)
+            return self.red_spec(M, blk["bn1"], blk["out"], blk["r1"], g2, blk["scbn"], blk["rs"])
+
+        sp = out_spec(len(blocks) - 1, None)
+        self.reduce_op(sp, G1)
         G2 = None
-        for blk in reversed(d["blocks"]):
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk = blocks[bi]
             cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
             Li, Lo = blk["Lin"], blk["Lout"]
-            Mi, Mo = B * Li, B * Lo
+            Mi = B * Li
+            p = blk["prefix"]
+            dr1, drs = self.apply_op(sp)
+            stored = blk["a2"] is not None
+            x1, c1 = (blk["a2"], None) if stored else (blk["r2"], blk["bn2"]["coef"])
+            sp2 = self.red_spec(Mi, blk["bn2"], blk["a2"], blk["r2"])
             if s == 1:
-                g, dr1, _ = self.bn_bwd(Mo, blk["bn1"], G1, G2, blk["out"], blk["r1"], SLOPE_BACKBONE)
-                self.wgrad(blk["tm1"], dr1, blk["a2"], blk["conv1"], note=blk["prefix"] + "conv1 wgrad")
-                da2 = pl.f32(Mi * cin)
-                self.conv(self.map_dgrad(Li, Lo, cin, cout, 1), dr1, blk["conv1"], da2, w_kn=True, note=blk["prefix"] + "conv1 dgrad")
-                side = g
+                self.wgrad(blk["tm1"], dr1, x1, blk["conv1"], note=p + "conv1 wgrad", coef=c1)
+                self.dgrad_reduce(self.map_dgrad(Li, Lo, cin, cout), dr1, blk["conv1"], sp2, p + "conv1 dgrad")
+                side = sp["g"]
             else:
-                g, dr1, drs = self.bn_bwd(Mo, blk["bn1"], G1, G2, blk["out"], blk["r1"], SLOPE_BACKBONE, blk["scbn"], blk["rs"])
-                self.wgrad(blk["tm1"], dr1, blk["a2"], blk["conv1"], note=blk["prefix"] + "conv1 (resize) wgrad")
-                self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=blk["prefix"] + "shortcut (resize) wgrad")
-                da2 = pl.f32(Mi * cin)
-                self.conv(self.map_dgrad_up(Li, cin, cout), dr1, blk["conv1"], da2, w_kn=True, note=blk["prefix"] + "conv1 (resize) dgrad")
+                self.wgrad(blk["tm1"], dr1, x1, blk["conv1"], note=p + "conv1 (resize) wgrad", coef=c1)
+                self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=p + "shortcut (resize) wgrad")
+                fuse = self.train.fuse_bn
+                da2 = sp2["g"] if fuse else pl.f32(Mi * cin)
+                self.conv(self.map_dgrad_up(Li, cin, cout), dr1, blk["conv1"], da2, w_kn=True, epi=sp2 if fuse else None,
+                          note=p + "conv1 (resize) dgrad")
                 side = pl.f32(Mi * cin)
-                self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, note=blk["prefix"] + "shortcut (resize) dgrad")
-                if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
-                    self.pair_last_two("pair " + blk["prefix"] + "resize dgrads")
-            _, dr2, _ = self.bn_bwd(Mi, blk["bn2"], da2, None, blk["a2"], blk["r2"], SLOPE_BACKBONE)
-            self.wgrad(blk["tm2"], dr2, blk["x"], blk["conv2"], note=blk["prefix"] + "conv2 wgrad")
-            dxa = pl.f32(Mi * cin)
-            self.conv(self.map_dgrad(Li, Li, cin, cin, 1), dr2, blk["conv2"], dxa, w_kn=True, note=blk["prefix"] + "conv2 dgrad")
-            G1, G2 = dxa, side
+                self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, note=p + "shortcut (resize) dgrad")
+                self.pair_last_two("pair " + p + "resize dgrads")
+                if fuse:
+                    self.reduce_sync(sp2)
+                else:
+                    self.reduce_op(sp2, da2)
+            dr2, _ = self.apply_op(sp2)
+            self.wgrad(blk["tm2"], dr2, blk["x"], blk["conv2"], note=p + "conv2 wgrad")
+            tm = self.map_dgrad(Li, Li, cin, cin)
+            if bi > 0:
+                # the block's input is the previous block's output: its BatchNorm-backward reduction takes this
+                # conv's result plus the gradient arriving over the shortcut path
+                spp = out_spec(bi - 1, side)
+                self.dgrad_reduce(tm, dr2, blk["conv2"], spp, p + "conv2 dgrad")
+                sp = spp
+            else:
+                G1 = pl.f32(Mi * cin)
+                self.conv(tm, dr2, blk["conv2"], G1, w_kn=True, note=p + "conv2 dgrad")
+                G2 = side
         dy = pl.f32(B * 512)
         self.o.add(P.REPEAT_BWD, 0, i=[B, 4, 512, 1], buf=[G1, G2, dy], note=d["prefix"] + "interpolate x4 bwd")
         self.linear_bwd(B, d["lin"], dy, 512, d["din"], 2 * z, ddin, 2 * z, accumulate=accumulate, note=d["prefix"] + "linear")
@@ -648,8 +785,9 @@ class Lowering:
             if not mem:
                 continue
             first = len(self.o.recs)
-            for (tm, nsplit, rps, dy, x, w, note) in mem:
-                self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER, i=tm.ints() + [nsplit, rps, w.numel], buf=[dy, x, w.gref], note=note)
+            for (tm, nsplit, rps, dy, x, w, note, coef) in mem:
+                self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0), i=tm.ints() + [nsplit, rps, w.numel],
+                           f=[SLOPE_BACKBONE], buf=[dy, x, w.gref, coef], note=note)
             self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
         if only_if:
             self.pending_wgrads = []

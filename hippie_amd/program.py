@@ -16,11 +16,11 @@ WS, PARAM, GRAD, BUF, ADAM_M, ADAM_V = range(6)
 NUM_SPACES = 6
 NULL = -1
 MAX_TAPS = 6
-NI, NF, NB = 28, 8, 16
+NI, NF, NB = 40, 8, 24
 
 OP_DTYPE = np.dtype([("op", "<i4"), ("flags", "<i4"), ("i", "<i4", (NI,)), ("f", "<f4", (NF,)),
                      ("buf", "<i8", (NB,))], align=True)
-assert OP_DTYPE.itemsize == 280
+assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
 
 (CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
  POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
@@ -29,8 +29,17 @@ assert OP_DTYPE.itemsize == 280
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
-CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT = 1, 2, 4, 8, 16
+CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED = 1, 2, 4, 8, 16, 64, 128
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP launch
+STAT_REPL_MAX = 16       # HP_STAT_REPL_MAX
+
+
+def stat_repl(C: int) -> int:
+    """hp_stat_repl (include/hippie_hip.h): replicas of a per-channel fp64 statistics slot of C channels."""
+    r = 2
+    while r < STAT_REPL_MAX and r * 2 * C <= 1024:
+        r *= 2
+    return r
 
 
 @dataclass(frozen=True)
@@ -61,13 +70,25 @@ class TapMap:
     P: int
     a: int = 1
     sh: int = 0
-    even: int = 0
-    taps: list = field(default_factory=list)   # [(offset, weight_slab)]
+    taps: list = field(default_factory=list)   # [(offset, weight_slab)] or [(offset, weight_slab, source 0/1)]
+    out_Lfull: int = 0                         # CONV_TAPS: > 0 = GEMM row (b, l) is output row b*out_Lfull + out_a*l + out_o
+    out_a: int = 1
+    out_o: int = 0
 
     def ints(self):
-        o = [t[0] for t in self.taps] + [0] * (MAX_TAPS - len(self.taps))
-        w = [t[1] for t in self.taps] + [0] * (MAX_TAPS - len(self.taps))
-        return [self.M, self.N, self.K, self.Lout, self.Lin, self.P, self.a, self.sh, self.even, len(self.taps)] + o + w
+        pad = [0] * (MAX_TAPS - len(self.taps))
+        o = [t[0] for t in self.taps] + pad
+        w = [t[1] for t in self.taps] + pad
+        return [self.M, self.N, self.K, self.Lout, self.Lin, self.P, self.a, self.sh, 0, len(self.taps)] + o + w
+
+    def conv_ints(self):
+        """i[0..30] of a CONV_TAPS record (adds the per-tap source selector and the output row mapping)."""
+        src = [(t[2] if len(t) > 2 else 0) for t in self.taps] + [0] * (MAX_TAPS - len(self.taps))
+        return self.ints() + src + [self.out_Lfull, self.out_a if self.out_Lfull else 0, self.out_o if self.out_Lfull else 0]
+
+    @property
+    def out_rows(self):
+        return (self.M // self.Lout) * self.out_Lfull if self.out_Lfull else self.M
 
 
 class OpList:
@@ -108,7 +129,7 @@ class OpList:
 
 # ---- shared library ---------------------------------------------------------------
 _LIB = None
-ABI_VERSION = 2          # include/hippie_hip.h: HP_ABI_VERSION
+ABI_VERSION = 3          # include/hippie_hip.h: HP_ABI_VERSION
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")
 
 EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 2
+#define HP_ABI_VERSION 3
 
 enum {
   HP_SPACE_WS = 0, HP_SPACE_PARAM = 1, HP_SPACE_GRAD = 2, HP_SPACE_BUF = 3,
@@ -45,13 +45,26 @@ enum {
 #define HP_NULL ((int64_t)-1)
 #define HP_MAX_TAPS 6
 /* Every per-channel statistics slot ("STATS", "BS": sum / sum-of-squares style fp64 accumulators) is
- * replicated HP_STAT_REPL times: double[HP_STAT_REPL][2][C].  Producers add into any replica (they pick
- * one by block index, so concurrent atomics spread over 16x more cache lines); consumers use the sum over
- * replicas.  The whole statistics region is zeroed at the start of every forward. */
-#define HP_STAT_REPL 16
-#define HP_OP_NI 28
+ * replicated R = hp_stat_repl(C) times: double[R][2][C].  Producers add into any replica (they pick one by
+ * block index, so concurrent same-address atomics spread over R cache lines); consumers use the sum over
+ * replicas, taken in replica order.  R shrinks as C grows (R*C ~ 1024): a wide layer has few row tiles per
+ * channel, hence little contention, and a consumer that derives the BatchNorm coefficients in its own prologue
+ * (HP_CONV_IN_BN) reads R*2*C doubles per workgroup.  The whole statistics region is zeroed at the start of
+ * every forward. */
+#define HP_STAT_REPL_MAX 16
+#if defined(__HIPCC__)
+#define HP_HD __host__ __device__
+#else
+#define HP_HD
+#endif
+static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 1024 / C, clamped to [2, 16] */
+  int r = 2;
+  while (r < HP_STAT_REPL_MAX && r * 2 * C <= 1024) r *= 2;
+  return r;
+}
+#define HP_OP_NI 40
 #define HP_OP_NF 8
-#define HP_OP_NB 16
+#define HP_OP_NB 24
 
 /* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op: the program executor skips it
  * (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
@@ -68,32 +81,61 @@ typedef struct HpOp {
 
 /* ---- opcodes ------------------------------------------------------------------
  * Row mapping shared by CONV_TAPS / WGRAD_TAPS (an implicit-GEMM view of every
- * Conv1d variant of the reference):  output row m -> (b = m / Lout, l = m % Lout);
- * for tap j:  pos = a*l + tap_o[j];  the tap contributes iff 0 <= pos < P and
- * (!even || pos % 2 == 0);  source row = b*Lin + (pos >> sh);  weight slab tap_w[j].
- *   i[0]=M  i[1]=N  i[2]=K  i[3]=Lout  i[4]=Lin  i[5]=P  i[6]=a  i[7]=sh  i[8]=even
- *   i[9]=ntaps  i[10..15]=tap_o  i[16..21]=tap_w
+ * Conv1d variant of the reference):  GEMM row m -> (b = m / Lout, l = m % Lout);
+ * for tap j:  pos = a*l + tap_o[j];  the tap contributes iff 0 <= pos < P;
+ * source row = b*Lin + (pos >> sh) of source tensor tap_src[j];  weight slab tap_w[j] of weight tensor tap_src[j].
+ *   i[0]=M  i[1]=N  i[2]=K  i[3]=Lout  i[4]=Lin  i[5]=P  i[6]=a  i[7]=sh  i[8]=0 (reserved)
+ *   i[9]=ntaps  i[10..15]=tap_o  i[16..21]=tap_w  i[22..27]=tap_src (CONV_TAPS only: 0 = (A, W), 1 = (A2, W2))
+ * CONV_TAPS output rows:  i[28]=Lfull.  Lfull == 0: GEMM row m is output row m.  Lfull > 0: GEMM row m is output
+ * row b*Lfull + i[29]*l + i[30] (a strided subset of a taller tensor: the even / odd output positions of a
+ * stride-2 input-gradient are two ops writing interleaved rows of one tensor, each with only its own taps).
  */
+/* CONV_TAPS flags */
+#define HP_CONV_W_KN     1     /* weight slab is [K][N] (else [N][K]) */
+#define HP_CONV_BIAS     2
+#define HP_CONV_STATS    4     /* per-column sum / sum of squares of the output into STATS (for the following BatchNorm) */
+#define HP_CONV_BN_EVAL  8     /* eval-mode BatchNorm folded into the epilogue */
+#define HP_CONV_ACT      16    /* ... followed by leaky_relu */
+#define HP_CONV_IN_BN    64    /* training-mode BatchNorm + leaky_relu of the INPUT applied in the operand loader */
+#define HP_CONV_EPI_BNRED 128  /* BatchNorm-backward reduction fused into the epilogue (input-gradient convs) */
 enum {
-  /* out[m][n] = sum_taps sum_k A[src(m,tap)][k] * W[tap_w][..] (+bias[n]);  f32 MFMA.
+  /* out[m][n] = sum_taps sum_k A_src[row(m,tap)][k] * W_src[tap_w][..] (+bias[n]);  f32 MFMA.
    * Replaces nn.Conv1d forward (backbones.py:24,26,33,50,55), ResizeConv1d =
    * F.interpolate(nearest)+Conv1d (backbones.py:13-16) with the upsample folded into
    * the row mapping, and their input-gradients (ATen convolution_backward) with
-   * transposed weights.  flags: 1 = weight slab is [K][N] (else [N][K]); 2 = bias;
-   * 4 = accumulate per-column sum / sum of squares (fp64 atomics) into buf[4] for the
-   * following BatchNorm;  8 = eval-mode BatchNorm1d folded into the epilogue (running statistics: the forward-only
-   * path has no batch-wide dependency, so conv + BN (+ residual tensor) (+ leaky_relu with flag 16) is one launch):
-   *   out = act( (acc + bias) * gamma/sqrt(rvar + f[0]) + (beta - rmean * gamma/sqrt(rvar + f[0])) + RES ),
+   * transposed weights; a stride-2 block's conv1 and 1x1-shortcut input-gradients (both with respect to the same
+   * tensor) are ONE op pair over two sources.  Requires K % 32 == 0 and N % 4 == 0 (every conv of the backbones).
+   *
+   * HP_CONV_BN_EVAL (forward-only path: no batch-wide dependency, so conv + BN (+ residual) (+ leaky_relu) is one
+   * launch):  out = act( (acc + bias) * gamma/sqrt(rvar + f[0]) + (beta - rmean * gamma/sqrt(rvar + f[0])) + RES ),
    * the same arithmetic, in the same order, as HP_OP_BN_APPLY in eval mode on this conv's output.  f[0]=eps f[1]=slope.
-   * Requires K % 32 == 0 and N % 4 == 0 (every conv of the backbones: 64..512).
-   * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[HP_STAT_REPL][2][N]), 5 GAMMA 6 BETA 7 RMEAN 8 RVAR 9 RES(or NULL) */
+   *
+   * HP_CONV_IN_BN (training): the A operand is  a = leaky_relu(fma(x, scale[k], shift[k]), f[2])  of the stored
+   * tensor x (zero for padded rows), i.e. `F.leaky_relu(bn(conv(...)))` of backbones.py:37,66 evaluated in the
+   * consumer: the activation tensor is never written.  (scale, shift) are derived — identically in every workgroup,
+   * exactly as HP_OP_BN_APPLY derives them — from IN_STATS (sums over i[31] rows; over i[31]*i[32] rows when
+   * i[32] > 1), GAMMA, BETA, f[3]=eps.  Workgroup 0 also performs that BatchNorm's side effects: IN_SAVE :=
+   * (mean, invstd), IN_COEF := (scale, shift) for the backward pass, running statistics update with f[4]=momentum.
+   *
+   * HP_CONV_EPI_BNRED (input-gradient convs): instead of storing acc,
+   *   g = (acc [+ E_G2]) * leaky_relu'(pre),  pre = E_ACT (the activation tensor) or, when E_ACT is NULL,
+   *   fma(E_RAW, scale, shift) from E_COEF;  OUT := g;  E_BS[0][n] += sum g;  E_BS[1][n] += sum g*xhat(E_RAW, E_SAVE)
+   *   (and the same sums for a second BatchNorm fed by the same g: E_RAW2, E_SAVE2, E_BS2)  —  HP_OP_BN_BWD_REDUCE
+   *   on this conv's output, fused.  f[5]=slope of that leaky_relu.
+   *
+   * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[R][2][N]), 5 GAMMA 6 BETA 7 RMEAN 8 RVAR (of the epilogue BN with
+   *      BN_EVAL, of the input BN with IN_BN), 9 RES(or NULL), 10 A2, 11 W2,
+   *      12 IN_STATS(double[R][2][K]) 13 IN_SAVE(float[2][K]) 14 IN_COEF(float[2][K]),
+   *      15 E_G2 16 E_ACT 17 E_RAW 18 E_SAVE 19 E_COEF 20 E_BS 21 E_RAW2 22 E_SAVE2 23 E_BS2 */
   HP_OP_CONV_TAPS = 1,
   /* slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]; f32 MFMA.
    * Replaces the weight-gradient half of ATen convolution_backward.
    * i[22]=nsplit i[23]=rows_per_split (multiple of 32) i[24]=slab stride per split (floats).
    * flags: 1 = no slabs: every split adds its tile into buf[2] (the zeroed gradient tensor
    * [tap_w][N][K]) with fp32 atomics (faster, summation order not reproducible bit for bit).
-   * buf: 0 DY, 1 X, 2 SLAB (or gradient) */
+   * flags: HP_CONV_IN_BN = X is the raw BatchNorm input of the forward conv: the operand is
+   * leaky_relu(fma(x, scale[k], shift[k]), f[0]) with (scale, shift) = COEF (written by the forward conv).
+   * buf: 0 DY, 1 X, 2 SLAB (or gradient), 3 COEF(float[2][K]) */
   HP_OP_WGRAD_TAPS = 2,
   /* out[j] = sum_s slab[s*stride + j], j < n.  i[0]=n i[1]=nsplit i[2]=stride. buf: 0 SLAB 1 OUT */
   HP_OP_SLAB_REDUCE = 3,
@@ -110,8 +152,10 @@ enum {
   /* g = (G1 [+ G2]) * leaky_relu'(ACT);  BS[0][c] += sum g;  BS[1][c] += sum g*xhat
    * (xhat = (raw-mean)*invstd), optionally for a second BN fed by the same g.
    * First half of ATen native_batch_norm_backward + leaky_relu_backward + residual fan-out.
+   * ACT NULL: the activation was never stored (HP_CONV_IN_BN consumer); its sign is that of fma(RAW, scale, shift)
+   * with (scale, shift) = COEF, bit for bit what the forward consumer evaluated.
    * i[0]=M i[1]=C i[2]=has_g2 i[3]=has_second  f[0]=slope
-   * buf: 0 G1 1 G2 2 ACT 3 GOUT 4 RAW 5 SAVE 6 BS(double[2][C]) 7 RAW2 8 SAVE2 9 BS2 */
+   * buf: 0 G1 1 G2 2 ACT 3 GOUT 4 RAW 5 SAVE 6 BS(double[R][2][C]) 7 RAW2 8 SAVE2 9 BS2 10 COEF(float[2][C]) */
   HP_OP_BN_BWD_REDUCE = 5,
   /* dr = gamma*invstd*(g - BS0/M - xhat*BS1/M);  dgamma = BS1;  dbeta = BS0.
    * i[0]=M i[1]=C i[2]=world (sync-BatchNorm: BS summed over ranks, divisor M*world, dgamma/dbeta scaled by

@@ -12,8 +12,17 @@ from __future__ import annotations
 import numpy as np
 
 NULL = -1
-STAT_REPL = 16    # HP_STAT_REPL: per-channel fp64 slots are double[STAT_REPL][2][C]; this interpreter adds into replica 0
+STAT_REPL_MAX = 16
 MASK = (1 << 56) - 1
+CONV_IN_BN, CONV_EPI_BNRED = 64, 128
+
+
+def stat_repl(C):
+    """hp_stat_repl (include/hippie_hip.h): per-channel fp64 slots are double[R][2][C]; this interpreter adds into replica 0."""
+    r = 2
+    while r < STAT_REPL_MAX and r * 2 * C <= 1024:
+        r *= 2
+    return r
 
 
 class Arenas:
@@ -39,21 +48,33 @@ class Arenas:
         return self.view(ref, np.int64, n)
 
 
-def _tapmap(i):
-    M, N, K, Lout, Lin, Pb, a, sh, even, nt = [int(v) for v in i[:10]]
-    taps = [(int(i[10 + j]), int(i[16 + j])) for j in range(nt)]
-    return M, N, K, Lout, Lin, Pb, a, sh, even, taps
+def _tapmap(i, conv=False):
+    M, N, K, Lout, Lin, Pb, a, sh, _, nt = [int(v) for v in i[:10]]
+    taps = [(int(i[10 + j]), int(i[16 + j]), int(i[22 + j]) if conv else 0) for j in range(nt)]
+    return M, N, K, Lout, Lin, Pb, a, sh, taps
 
 
-def _src_rows(M, Lout, Lin, Pb, a, sh, even, off):
+def _src_rows(M, Lout, Lin, Pb, a, sh, off):
     m = np.arange(M)
     b, l = m // Lout, m % Lout
     pos = a * l + off
     ok = (pos >= 0) & (pos < Pb)
-    if even:
-        ok &= (pos % 2 == 0)
     src = b * Lin + (np.where(ok, pos, 0) >> sh)
     return src, ok
+
+
+def _out_rows(i, M, Lout):
+    """output row of every GEMM row of a CONV_TAPS record, and the row count of the output tensor"""
+    Lfull, oa, oo = int(i[28]), int(i[29]), int(i[30])
+    m = np.arange(M)
+    if Lfull == 0:
+        return m, M
+    return (m // Lout) * Lfull + oa * (m % Lout) + oo, (M // Lout) * Lfull
+
+
+def _fma32(x, sc, sh):
+    """fmaf(x, sc, sh) on float32 arrays (product exact in float64; the sum is rounded once to float64, then to float32)"""
+    return (x.astype(np.float64) * sc.astype(np.float64) + sh.astype(np.float64)).astype(np.float32)
 
 
 def _torch_lerp(a, b, w):
@@ -72,7 +93,7 @@ def _lrelu_grad(out, s):
 
 def _bn_coef(A, training, M, C, stats, gamma, beta, rmean, rvar, eps):
     if training:
-        st = A.f64(stats, STAT_REPL * 2 * C).reshape(STAT_REPL, 2 * C).sum(0)
+        st = A.f64(stats, stat_repl(C) * 2 * C).reshape(stat_repl(C), 2 * C).sum(0)
         mean = st[:C] / M
         var = np.maximum(st[C:] / M - mean * mean, 0.0)
     else:
@@ -85,10 +106,13 @@ def _bn_coef(A, training, M, C, stats, gamma, beta, rmean, rvar, eps):
     return mean, var, invstd, sc.astype(np.float32), sh.astype(np.float32)
 
 
-def _bn_side(A, M, C, mean, var, invstd, save, rmean, rvar, mom):
+def _bn_side(A, M, C, mean, var, invstd, save, rmean, rvar, mom, coef=NULL, sc=None, sh=None):
     sv = A.f32(save, 2 * C)
     sv[:C] = mean.astype(np.float32)
     sv[C:] = invstd.astype(np.float32)
+    if int(coef) != NULL:
+        cf = A.f32(coef, 2 * C)
+        cf[:C], cf[C:] = sc, sh
     unb = var * M / (M - 1) if M > 1 else var
     rm, rv = A.f32(rmean, C), A.f32(rvar, C)
     mom = np.float64(np.float32(mom))
@@ -101,48 +125,81 @@ def run(ops, A: Arenas, first=0, count=None):
     for r in ops[first: first + count]:
         op, flags, i, f, b = int(r["op"]), int(r["flags"]), r["i"], r["f"], r["buf"]
         if op == 1:      # CONV_TAPS
-            M, N, K, Lout, Lin, Pb, a, sh, even, taps = _tapmap(i)
+            M, N, K, Lout, Lin, Pb, a, sh, taps = _tapmap(i, conv=True)
             nin = (M // Lout) * Lin
-            X = A.f32(b[0], nin * K).reshape(nin, K)
-            nslab = max(w for _, w in taps) + 1
-            W = A.f32(b[1], nslab * N * K)
+            orow, nout = _out_rows(i, M, Lout)
             acc = np.zeros((M, N), dtype=np.float64)
-            for off, w in taps:
-                src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, even, off)
-                Ag = np.where(ok[:, None], X[src], 0).astype(np.float64)
+            coefs = None
+            if flags & CONV_IN_BN:      # training-mode BatchNorm + leaky_relu of the input, evaluated in the loader
+                Ms = int(i[31]) * max(1, int(i[32]))
+                mean, var, invstd, sc_in, sh_in = _bn_coef(A, True, Ms, K, b[12], b[5], b[6], b[7], b[8], f[3])
+                coefs = (sc_in, sh_in)
+            for off, w, srcsel in taps:
+                X = A.f32(b[10] if srcsel else b[0], nin * K).reshape(nin, K)
+                W = A.f32(b[11] if srcsel else b[1], (w + 1) * N * K)
+                src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, off)
+                Xs = X[src]
+                if coefs is not None:
+                    Xs = _lrelu(_fma32(Xs, coefs[0][None, :], coefs[1][None, :]), f[2])
+                Ag = np.where(ok[:, None], Xs, 0).astype(np.float64)
                 Ws = W[w * N * K: (w + 1) * N * K]
                 Wm = Ws.reshape(K, N) if flags & 1 else Ws.reshape(N, K).T
                 acc += Ag @ Wm.astype(np.float64)
+            if coefs is not None:       # the input BatchNorm's side effects (workgroup 0 of the kernel)
+                _bn_side(A, Ms, K, mean, var, invstd, b[13], b[7], b[8], f[4], b[14], coefs[0], coefs[1])
             out = acc.astype(np.float32)
+            dst = A.f32(b[2], nout * N).reshape(nout, N)
+            if flags & CONV_EPI_BNRED:      # HP_OP_BN_BWD_REDUCE on the output
+                raw = A.f32(b[17], nout * N).reshape(nout, N)[orow]
+                if int(b[15]) != NULL:
+                    out = out + A.f32(b[15], nout * N).reshape(nout, N)[orow]
+                if int(b[16]) != NULL:
+                    pre = A.f32(b[16], nout * N).reshape(nout, N)[orow]
+                else:
+                    cf = A.f32(b[19], 2 * N)
+                    pre = _fma32(raw, cf[None, :N], cf[None, N:])
+                g = (out * _lrelu_grad(pre, f[5])).astype(np.float32)
+                dst[orow] = g
+                for (raw_r, save_r, bs_r) in ([(b[17], b[18], b[20])] + ([(b[21], b[22], b[23])] if int(b[21]) != NULL else [])):
+                    rw = A.f32(raw_r, nout * N).reshape(nout, N)[orow]
+                    sv = A.f32(save_r, 2 * N)
+                    xh = ((rw - sv[None, :N]) * sv[None, N:]).astype(np.float32)
+                    bs = A.f64(bs_r, 2 * N)
+                    bs[:N] += g.astype(np.float64).sum(0)
+                    bs[N:] += (g.astype(np.float64) * xh.astype(np.float64)).sum(0)
+                continue
             if flags & 2:
                 out = out + A.f32(b[3], N)[None, :]
             if flags & 8:     # eval-mode BatchNorm (+ residual tensor, + leaky_relu with flag 16) folded into the epilogue
-                _, _, _, sc, sh = _bn_coef(A, False, M, N, NULL, b[5], b[6], b[7], b[8], f[0])
-                out = out * sc[None, :] + sh[None, :]
+                _, _, _, sc, shf = _bn_coef(A, False, M, N, NULL, b[5], b[6], b[7], b[8], f[0])
+                out = out * sc[None, :] + shf[None, :]
                 if int(b[9]) != NULL:
-                    out = out + A.f32(b[9], M * N).reshape(M, N)
+                    out = out + A.f32(b[9], nout * N).reshape(nout, N)[orow]
                 if flags & 16:
                     out = _lrelu(out, f[1])
                 out = out.astype(np.float32)
-            A.f32(b[2], M * N)[:] = out.reshape(-1)
+            dst[orow] = out
             if flags & 4:
                 st = A.f64(b[4], 2 * N)
                 st[:N] += out.astype(np.float64).sum(0)
                 st[N:] += (out.astype(np.float64) ** 2).sum(0)
         elif op == 2:    # WGRAD_TAPS
-            M, N, K, Lout, Lin, Pb, a, sh, even, taps = _tapmap(i)
+            M, N, K, Lout, Lin, Pb, a, sh, taps = _tapmap(i)
             nsplit, rps, stride = int(i[22]), int(i[23]), int(i[24])
             nin = (M // Lout) * Lin
             DY = A.f32(b[0], M * N).reshape(M, N).astype(np.float64)
             X = A.f32(b[1], nin * K).reshape(nin, K)
+            if flags & CONV_IN_BN:
+                cf = A.f32(b[3], 2 * K)
+                X = _lrelu(_fma32(X, cf[None, :K], cf[None, K:]), f[0])
             atomic = flags & 1
             slab = A.f32(b[2], stride if atomic else nsplit * stride)
             if not atomic:
                 slab[:] = 0  # the kernel writes every tile of every split it owns
             for s in range(nsplit):
                 lo, hi = s * rps, min(M, (s + 1) * rps)
-                for off, w in taps:
-                    src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, even, off)
+                for off, w, _ in taps:
+                    src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, off)
                     Xg = np.where(ok[:, None], X[src], 0).astype(np.float64)
                     part = DY[lo:hi].T @ Xg[lo:hi]
                     if atomic:
@@ -181,7 +238,12 @@ def run(ops, A: Arenas, first=0, count=None):
             g = A.f32(b[0], M * C).reshape(M, C).copy()
             if has_g2:
                 g = g + A.f32(b[1], M * C).reshape(M, C)
-            g = (g * _lrelu_grad(A.f32(b[2], M * C).reshape(M, C), f[0])).astype(np.float32)
+            if int(b[2]) != NULL:
+                pre = A.f32(b[2], M * C).reshape(M, C)
+            else:       # the activation was never stored: sign of fma(raw, scale, shift)
+                cf = A.f32(b[10], 2 * C)
+                pre = _fma32(A.f32(b[4], M * C).reshape(M, C), cf[None, :C], cf[None, C:])
+            g = (g * _lrelu_grad(pre, f[0])).astype(np.float32)
             A.f32(b[3], M * C)[:] = g.reshape(-1)
             for (raw_r, save_r, bs_r) in ([(b[4], b[5], b[6])] + ([(b[7], b[8], b[9])] if has_second else [])):
                 raw = A.f32(raw_r, M * C).reshape(M, C)
@@ -195,7 +257,7 @@ def run(ops, A: Arenas, first=0, count=None):
             g = A.f32(b[0], M * C).reshape(M, C)
             raw = A.f32(b[1], M * C).reshape(M, C)
             sv = A.f32(b[2], 2 * C)
-            bs = A.f64(b[3], STAT_REPL * 2 * C).reshape(STAT_REPL, 2 * C).sum(0)
+            bs = A.f64(b[3], stat_repl(C) * 2 * C).reshape(stat_repl(C), 2 * C).sum(0)
             gamma = A.f32(b[4], C)
             xh = (raw - sv[None, :C]) * sv[None, C:]
             W = max(1, int(i[2]))

@@ -110,27 +110,24 @@ def parity(mine, ref32, ref64, msg="", rel=1e-4, slack=3.0):
     return e_mine, e_ref
 
 
-def activation_sites(plan, ops):
-    """Every leaky-ReLU site of the training forward: (oracle site name, M rows, C channels, byte offset of
-    the activation tensor in the workspace).  Site names are the oracle's (cvae_oracle.Ctx.lrelu)."""
-    s, c = plan.ops.segments["fwd_train"]
-    for k in range(s, s + c):
-        r = ops[k]
-        op, note = int(r["op"]), plan.ops.notes[k]
-        if op == P.BN_APPLY and int(r["i"][4]) == 1:
-            yield note, int(r["i"][0]), int(r["i"][1]), int(r["buf"][1]) & ((1 << 56) - 1)
-        elif op == P.LINEAR_FWD and int(r["i"][5]) == 1:
-            yield note.split(" ")[0], int(r["i"][0]), int(r["i"][1]), int(r["buf"][3]) & ((1 << 56) - 1)
-
-
 def activation_masks(plan, ops, read_f32, B):
     """{site -> bool tensor in the oracle's layout ([B,C,L] / [B,C])}: which branch of each leaky-ReLU the
-    implementation under test took (out > 0 <=> in > 0 for a positive slope), read back from its workspace.
+    implementation under test took, read back from its workspace.  Sites (Plan.act_sites, names = the oracle's
+    cvae_oracle.Ctx.lrelu) are either stored activations (out > 0 <=> in > 0 for a positive slope) or — where the
+    activation only ever exists inside the consumers' operand loaders (HP_CONV_IN_BN) — the raw BatchNorm input plus
+    the stored (scale, shift): the branch is the sign of fma(raw, scale, shift), which float64 evaluates exactly
+    (the product of two float32 is exact in float64 and the sum keeps its sign).
     read_f32(byte_offset, count) -> numpy float32 array."""
     masks = {}
-    for key, M, C, off in activation_sites(plan, ops):
-        a = np.asarray(read_f32(off, M * C)).reshape(B, M // B, C)
-        m = torch.from_numpy(np.ascontiguousarray((a > 0).transpose(0, 2, 1)))
+    for site in plan.act_sites:
+        key, M, C = site["key"], site["M"], site["C"]
+        if site["kind"] == "tensor":
+            pre = np.asarray(read_f32(site["out"].offset, M * C)).reshape(B, M // B, C)
+        else:
+            raw = np.asarray(read_f32(site["raw"].offset, M * C)).reshape(B, M // B, C).astype(np.float64)
+            cf = np.asarray(read_f32(site["coef"].offset, 2 * C)).astype(np.float64)
+            pre = raw * cf[None, None, :C] + cf[None, None, C:]
+        m = torch.from_numpy(np.ascontiguousarray((pre > 0).transpose(0, 2, 1)))
         masks[key] = m[:, :, 0] if M == B and key.split(".")[0] in HEAD_SITES else m
     return masks
 

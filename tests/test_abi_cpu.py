@@ -14,12 +14,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_header_symbols_are_exported():
     hdr = open(os.path.join(ROOT, "include", "hippie_hip.h")).read()
-    declared = set(re.findall(r"\b(hp_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(hp_[a-z_]+)\s*\(", hdr)) - {"hp_stat_repl"}       # a static inline helper, not an export
     assert declared == set(P.EXPORTS), declared ^ set(P.EXPORTS)
     lib = P.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hp_abi_version() == P.ABI_VERSION == 2
+    assert lib.hp_abi_version() == P.ABI_VERSION == 3
 
 
 def test_op_record_layout_matches_header():
@@ -29,7 +29,10 @@ def test_op_record_layout_matches_header():
     nb = int(re.search(r"#define HP_OP_NB (\d+)", hdr).group(1))
     assert (ni, nf, nb) == (P.NI, P.NF, P.NB)
     assert P.OP_DTYPE.itemsize == 8 + 4 * ni + 4 * nf + 8 * nb
-    assert int(re.search(r"#define HP_STAT_REPL (\d+)", hdr).group(1)) == planner.STAT_REPL
+    assert int(re.search(r"#define HP_STAT_REPL_MAX (\d+)", hdr).group(1)) == P.STAT_REPL_MAX
+    for name, val in re.findall(r"#define HP_CONV_([A-Z_]+)\s+(\d+)", hdr):
+        assert getattr(P, "CONV_" + name) == int(val), name
+    assert [P.stat_repl(c) for c in (5, 10, 64, 128, 256, 512, 1024)] == [16, 16, 16, 8, 4, 2, 2]
     for name, val in re.findall(r"HP_OP_([A-Z_]+) = (\d+)", hdr):
         assert getattr(P, name) == int(val), name
 

@@ -78,13 +78,13 @@ def check(gpu, cpu, ref, n, dtype=np.float32, rel=2e-5, what=""):
     assert np.isfinite(g).all() and err <= rel, f"{what}: rel err {err:.3e} (scale {scale:.3e})"
 
 
-R = interp.STAT_REPL
+R = P.stat_repl       # replicas of a per-channel statistics slot of C channels
 
 
 def check_stats(gpu, cpu, ref, C, rel=1e-5, what=""):
-    """replicated fp64 statistics slot double[R][2][C]: only the sum over replicas is defined"""
-    g = view(gpu, ref, np.float64, R * 2 * C).reshape(R, 2 * C).sum(0)
-    c = view(cpu, ref, np.float64, R * 2 * C).reshape(R, 2 * C).sum(0)
+    """replicated fp64 statistics slot double[R(C)][2][C]: only the sum over replicas is defined"""
+    g = view(gpu, ref, np.float64, R(C) * 2 * C).reshape(R(C), 2 * C).sum(0)
+    c = view(cpu, ref, np.float64, R(C) * 2 * C).reshape(R(C), 2 * C).sum(0)
     scale = max(np.abs(c).max(), 1e-20)
     err = np.abs(g - c).max() / scale
     assert np.isfinite(g).all() and err <= rel, f"{what}: rel err {err:.3e}"
@@ -93,16 +93,17 @@ def check_stats(gpu, cpu, ref, C, rel=1e-5, what=""):
 B = 3
 CONV_CASES = {
     # name: (tapmap builder, w_kn, bias, rows_in)
-    "fwd_s1": lambda: (TapMap(B * 7, 128, 64, 7, 7, 7, 1, 0, 0, [(t - 1, t) for t in range(3)]), False, False),
-    "fwd_s2_odd": lambda: (TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(t - 1, t) for t in range(3)]), False, False),
-    "fwd_1x1_s2": lambda: (TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(0, 0)]), False, False),
-    "fwd_up_bias": lambda: (TapMap(B * 16, 64, 128, 16, 8, 16, 1, 1, 0, [(t - 1, t) for t in range(3)]), False, True),
-    "dgrad_s1": lambda: (TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, 0, [(1 - t, t) for t in range(3)]), True, False),
-    "dgrad_s2": lambda: (TapMap(B * 25, 64, 128, 25, 13, 26, 1, 1, 1, [(1 - t, t) for t in range(3)]), True, False),
-    "dgrad_1x1_s2": lambda: (TapMap(B * 25, 64, 128, 25, 13, 26, 1, 1, 1, [(0, 0)]), True, False),
-    "dgrad_up": lambda: (TapMap(B * 8, 128, 64, 8, 16, 16, 2, 0, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)]), True, False),
-    "big_k": lambda: (TapMap(37 * 4, 512, 512, 4, 4, 4, 1, 0, 0, [(t - 1, t) for t in range(3)]), False, False),
-    "big_k_kn": lambda: (TapMap(37 * 4, 512, 512, 4, 4, 4, 1, 0, 0, [(1 - t, t) for t in range(3)]), True, False),
+    "fwd_s1": lambda: (TapMap(B * 7, 128, 64, 7, 7, 7, 1, 0, [(t - 1, t) for t in range(3)]), False, False),
+    "fwd_s2_odd": lambda: (TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, [(t - 1, t) for t in range(3)]), False, False),
+    "fwd_1x1_s2": lambda: (TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, [(0, 0)]), False, False),
+    "fwd_up_bias": lambda: (TapMap(B * 16, 64, 128, 16, 8, 16, 1, 1, [(t - 1, t) for t in range(3)]), False, True),
+    "dgrad_s1": lambda: (TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, [(1 - t, t) for t in range(3)]), True, False),
+    # stride-2 input-gradient by output parity, two sources (conv1 + 1x1 shortcut): planner.map_dgrad_s2_phases
+    "dgrad_s2_even": lambda: (TapMap(B * 13, 64, 128, 13, 13, 13, 1, 0, [(0, 1, 0), (0, 0, 1)], out_Lfull=25, out_a=2, out_o=0), True, False),
+    "dgrad_s2_odd": lambda: (TapMap(B * 12, 64, 128, 12, 13, 13, 1, 0, [(1, 0, 0), (0, 2, 0)], out_Lfull=25, out_a=2, out_o=1), True, False),
+    "dgrad_up": lambda: (TapMap(B * 8, 128, 64, 8, 16, 16, 2, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)]), True, False),
+    "big_k": lambda: (TapMap(37 * 4, 512, 512, 4, 4, 4, 1, 0, [(t - 1, t) for t in range(3)]), False, False),
+    "big_k_kn": lambda: (TapMap(37 * 4, 512, 512, 4, 4, 4, 1, 0, [(1 - t, t) for t in range(3)]), True, False),
 }
 
 
@@ -112,41 +113,178 @@ def test_conv_taps(name):
     img = Img(1)
     nb = tm.M // tm.Lout
     a = img.f32(nb * tm.Lin * tm.K)
-    nslab = max(w for _, w in tm.taps) + 1
+    nslab = max(t[1] for t in tm.taps) + 1
     w = img.f32(nslab * tm.N * tm.K, scale=0.1)
-    out = img.f32(tm.M * tm.N, zero=True)
+    two = any(len(t) > 2 and t[2] for t in tm.taps)
+    a2 = img.f32(nb * tm.Lin * tm.K) if two else None
+    w2 = img.f32(nslab * tm.N * tm.K, scale=0.1) if two else None
+    out = img.f32(tm.out_rows * tm.N, scale=3.0)       # pre-filled: rows the op does not own must survive
     bv = img.f32(tm.N) if bias else None
-    st = img.f64(R * 2 * tm.N)
+    st = img.f64(R(tm.N) * 2 * tm.N)
     flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_STATS
-    recs = rec_of(P.CONV_TAPS, flags, tm.ints(), (), [a, w, out, bv, st])
+    recs = rec_of(P.CONV_TAPS, flags, tm.conv_ints(), (), [a, w, out, bv, st, None, None, None, None, None, a2, w2])
     gpu, cpu = run_both(img, recs)
-    check(gpu, cpu, out, tm.M * tm.N, what=name + " out")
+    check(gpu, cpu, out, tm.out_rows * tm.N, what=name + " out")
     check_stats(gpu, cpu, st, tm.N, what=name + " stats")
+
+
+def test_conv_stride2_phases_equal_masked_reference():
+    """The even-row and odd-row ops of planner.map_dgrad_s2_phases together are the input-gradient of a k=3 stride-2
+    pad-1 conv plus that of a 1x1 stride-2 shortcut, written into ONE tensor — against a direct numpy transpose-conv."""
+    from hippie_amd import planner
+    Bn, Lx, cin, cout = 3, 25, 64, 128
+    Ly = (Lx - 1) // 2 + 1
+    low = planner.Lowering(planner.ModelCfg(), Bn)
+    tms = low.map_dgrad_s2_phases(Lx, Ly, cin, cout)
+    img = Img(31)
+    dy, dys = img.f32(Bn * Ly * cout), img.f32(Bn * Ly * cout)
+    w3, w1 = img.f32(3 * cout * cin, scale=0.1), img.f32(cout * cin, scale=0.1)      # [tap][cout][cin] read as [K][N]; [cout][cin]
+    dx = img.f32(Bn * Lx * cin, zero=True)
+    ol = P.OpList()
+    for tm in tms:
+        ol.add(P.CONV_TAPS, P.CONV_W_KN, tm.conv_ints(), (), [dy, w3, dx, None, None, None, None, None, None, None, dys, w1])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, dx, Bn * Lx * cin, what="phases vs interpreter")
+    DY = view(cpu, dy, np.float32, Bn * Ly * cout).reshape(Bn, Ly, cout).astype(np.float64)
+    DYS = view(cpu, dys, np.float32, Bn * Ly * cout).reshape(Bn, Ly, cout).astype(np.float64)
+    W3 = view(cpu, w3, np.float32, 3 * cout * cin).reshape(3, cout, cin).astype(np.float64)
+    W1 = view(cpu, w1, np.float32, cout * cin).reshape(cout, cin).astype(np.float64)
+    want = np.zeros((Bn, Lx, cin))
+    for l in range(Ly):
+        for t in range(3):
+            p_ = 2 * l + t - 1
+            if 0 <= p_ < Lx:
+                want[:, p_] += DY[:, l] @ W3[t]
+        want[:, 2 * l] += DYS[:, l] @ W1
+    got = view(gpu, dx, np.float32, Bn * Lx * cin).reshape(Bn, Lx, cin)
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+
+
+def _bn_setup(img, M, C):
+    """raw tensor + the statistics slot its producer would have accumulated + BatchNorm parameters / buffers"""
+    raw = img.f32(M * C)
+    gamma, beta, rm = img.f32(C), img.f32(C), img.f32(C, 0.1)
+    rv = img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5)
+    st = img.f64(R(C) * 2 * C)
+    return raw, gamma, beta, rm, rv, st
+
+
+def _chunk_array(img, ref):
+    o = 0
+    for pad, arr in img.chunks:
+        o += pad
+        if o == ref.offset:
+            return arr
+        o += arr.nbytes
+    raise KeyError
+
+
+@pytest.mark.parametrize("w_kn,up", [(False, False), (False, True), (True, False)])
+def test_conv_in_bn_equals_bn_apply_then_conv(w_kn, up):
+    """HP_CONV_IN_BN: conv over lrelu(bn(raw)) evaluated in the operand loader == HP_OP_BN_APPLY then the plain conv,
+    including the BatchNorm's side effects (saved mean / invstd, running statistics) and the stored (scale, shift)."""
+    Bn, Lin, K, N = 5, 9, 128, 64
+    tm = (TapMap(Bn * 2 * Lin, N, K, 2 * Lin, Lin, 2 * Lin, 1, 1, [(t - 1, t) for t in range(3)]) if up else
+          TapMap(Bn * Lin, N, K, Lin, Lin, Lin, 1, 0, [(t - 1, t) for t in range(3)]))
+    M = Bn * Lin
+    img = Img(41)
+    raw, gamma, beta, rm, rv, st = _bn_setup(img, M, K)
+    rm2 = img._put(_chunk_array(img, rm).copy())
+    rv2 = img._put(_chunk_array(img, rv).copy())
+    r = _chunk_array(img, raw).reshape(M, K).astype(np.float64)
+    _chunk_array(img, st)[:K] = r.sum(0)
+    _chunk_array(img, st)[K: 2 * K] = (r * r).sum(0)
+    w = img.f32(3 * N * K, scale=0.1)
+    act = img.f32(M * K, zero=True)
+    save_a, save_b, coef = img.f32(2 * K, zero=True), img.f32(2 * K, zero=True), img.f32(2 * K, zero=True)
+    out_a, out_b = img.f32(tm.M * N, zero=True), img.f32(tm.M * N, zero=True)
+    sta, stb = img.f64(R(N) * 2 * N), img.f64(R(N) * 2 * N)
+    fl = (P.CONV_W_KN if w_kn else 0) | P.CONV_STATS
+    ol = P.OpList()
+    ol.add(P.BN_APPLY, 0, [M, K, 0, 1, 1], [0.01, 1e-5, 0.1], [raw, act, st, gamma, beta, rm, rv, save_a])
+    ol.add(P.CONV_TAPS, fl, tm.conv_ints(), (), [act, w, out_a, None, sta])
+    ol.add(P.CONV_TAPS, fl | P.CONV_IN_BN, tm.conv_ints() + [M, 0], [0, 0, 0.01, 1e-5, 0.1],
+           [raw, w, out_b, None, stb, gamma, beta, rm2, rv2, None, None, None, st, save_b, coef])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, out_b, tm.M * N, what="in-bn conv vs interpreter")
+    check_stats(gpu, cpu, stb, N, what="in-bn conv stats")
+    for ref, n in ((save_b, 2 * K), (coef, 2 * K), (rm2, K), (rv2, K)):
+        check(gpu, cpu, ref, n, rel=1e-6, what="in-bn side effects")
+    g = lambda ref, n: view(gpu, ref, np.float32, n)
+    # on the GPU the fused op must reproduce the two-op sequence BIT FOR BIT (same coefficient code, same fma, same K order)
+    np.testing.assert_array_equal(g(out_a, tm.M * N), g(out_b, tm.M * N))
+    np.testing.assert_array_equal(g(save_a, 2 * K), g(save_b, 2 * K))
+    np.testing.assert_array_equal(g(rm, K), g(rm2, K))
+    np.testing.assert_array_equal(g(rv, K), g(rv2, K))
+
+
+@pytest.mark.parametrize("variant", ["act_g2", "coef", "second", "phases"])
+def test_conv_epilogue_bn_reduce_equals_conv_then_reduce(variant):
+    """HP_CONV_EPI_BNRED == plain input-gradient conv followed by HP_OP_BN_BWD_REDUCE."""
+    Bn, L, K, N = 4, 13, 128, 64
+    M = Bn * L
+    img = Img(43)
+    dy, w = img.f32(M * K), img.f32(3 * N * K, scale=0.1)
+    tm = TapMap(M, N, K, L, L, L, 1, 0, [(1 - t, t) for t in range(3)])
+    raw, raw2, act, g2 = img.f32(M * N), img.f32(M * N), img.f32(M * N), img.f32(M * N)
+    save, save2, coef = img.f32(2 * N), img.f32(2 * N), img.f32(2 * N)
+    tmp = img.f32(M * N, zero=True)
+    ga, gb = img.f32(M * N, zero=True), img.f32(M * N, zero=True)
+    bsa, bsb, bs2a, bs2b = (img.f64(R(N) * 2 * N) for _ in range(4))
+    has_g2 = variant == "act_g2"
+    use_coef = variant == "coef"
+    second = variant == "second"
+    ol = P.OpList()
+    tms = [tm]
+    if variant == "phases":         # two ops with scattered output rows accumulating into the same statistics slot
+        tms = [TapMap(Bn * 7, N, K, 7, L, L, 1, 0, [(0, 1)], out_Lfull=L, out_a=2, out_o=0),
+               TapMap(Bn * 6, N, K, 6, L, L, 1, 0, [(1, 0), (0, 2)], out_Lfull=L, out_a=2, out_o=1)]
+    for t_ in tms:
+        ol.add(P.CONV_TAPS, P.CONV_W_KN, t_.conv_ints(), (), [dy, w, tmp])
+    ol.add(P.BN_BWD_REDUCE, 0, [M, N, 1 if has_g2 else 0, 1 if second else 0], [0.01],
+           [tmp, g2 if has_g2 else None, None if use_coef else act, ga, raw, save, bsa,
+            raw2 if second else None, save2 if second else None, bs2a if second else None, coef if use_coef else None])
+    for t_ in tms:
+        ol.add(P.CONV_TAPS, P.CONV_W_KN | P.CONV_EPI_BNRED, t_.conv_ints(), [0, 0, 0, 0, 0, 0.01],
+               [dy, w, gb] + [None] * 12 + [g2 if has_g2 else None, None if use_coef else act, raw, save, coef if use_coef else None, bsb,
+                                            raw2 if second else None, save2 if second else None, bs2b if second else None])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, gb, M * N, what="fused g vs interpreter")
+    check_stats(gpu, cpu, bsb, N, what="fused bs vs interpreter")
+    g = lambda ref, n, dt=np.float32: view(gpu, ref, dt, n)
+    np.testing.assert_array_equal(g(ga, M * N), g(gb, M * N))           # same expressions on the same accumulators
+    sa = g(bsa, R(N) * 2 * N, np.float64).reshape(R(N), -1).sum(0)
+    sb = g(bsb, R(N) * 2 * N, np.float64).reshape(R(N), -1).sum(0)
+    np.testing.assert_allclose(sb, sa, rtol=1e-12, atol=1e-9)
+    if second:
+        s2a = g(bs2a, R(N) * 2 * N, np.float64).reshape(R(N), -1).sum(0)
+        s2b = g(bs2b, R(N) * 2 * N, np.float64).reshape(R(N), -1).sum(0)
+        np.testing.assert_allclose(s2b, s2a, rtol=1e-12, atol=1e-9)
 
 
 def test_conv_mfma_layout_identity():
     """A = I (per tap 1 of a 1-tap map) with an ASYMMETRIC weight matrix: catches transposed C/D or
     swapped operand layouts that random data with loose tolerance could hide."""
     K = N = 64
-    tm = TapMap(64, N, K, 64, 64, 64, 1, 0, 0, [(0, 0)])
+    tm = TapMap(64, N, K, 64, 64, 64, 1, 0, [(0, 0)])
     for w_kn in (False, True):
         img = Img(2)
         a = img._put(np.eye(64, dtype=np.float32).reshape(-1))
         wmat = (np.arange(N)[:, None] * 1000 + np.arange(K)[None, :]).astype(np.float32)   # W[n][k] = 1000n + k
         w = img._put((wmat.T.copy() if w_kn else wmat).reshape(-1))
         out = img.f32(64 * N, zero=True)
-        recs = rec_of(P.CONV_TAPS, P.CONV_W_KN if w_kn else 0, tm.ints(), (), [a, w, out, None, None])
+        recs = rec_of(P.CONV_TAPS, P.CONV_W_KN if w_kn else 0, tm.conv_ints(), (), [a, w, out, None, None])
         gpu, _ = run_both(img, recs)
         got = view(gpu, out, np.float32, 64 * N).reshape(64, N)
         np.testing.assert_array_equal(got, wmat.T)     # out[m][n] = sum_k I[m][k] W[n][k] = W[n][m]
 
 
 WGRAD_CASES = {
-    "s1": lambda: TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, 0, [(t - 1, t) for t in range(3)]),
-    "s2": lambda: TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(t - 1, t) for t in range(3)]),
-    "1x1": lambda: TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(0, 0)]),
-    "up": lambda: TapMap(B * 16, 64, 128, 16, 8, 16, 1, 1, 0, [(t - 1, t) for t in range(3)]),
-    "big": lambda: TapMap(50 * 7, 256, 256, 7, 7, 7, 1, 0, 0, [(t - 1, t) for t in range(3)]),
+    "s1": lambda: TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, [(t - 1, t) for t in range(3)]),
+    "s2": lambda: TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, [(t - 1, t) for t in range(3)]),
+    "1x1": lambda: TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, [(0, 0)]),
+    "up": lambda: TapMap(B * 16, 64, 128, 16, 8, 16, 1, 1, [(t - 1, t) for t in range(3)]),
+    "big": lambda: TapMap(50 * 7, 256, 256, 7, 7, 7, 1, 0, [(t - 1, t) for t in range(3)]),
 }
 
 
@@ -166,6 +304,31 @@ def test_wgrad_taps_atomic(name, nsplit):
     recs = rec_of(P.WGRAD_TAPS, 1, tm.ints() + [ns, rps, numel], (), [dy, x, grad])
     gpu, cpu = run_both(img, recs)
     check(gpu, cpu, grad, numel, rel=3e-5, what=f"wgrad atomic {name}")
+
+
+@pytest.mark.parametrize("name", ["s1", "up"])
+def test_wgrad_in_bn_equals_wgrad_of_the_stored_activation(name):
+    """WGRAD_TAPS with HP_CONV_IN_BN: X is the raw BatchNorm input, the operand lrelu(fma(x, scale, shift)) is
+    re-evaluated in the loader — bit-identical to the gradient computed from the stored activation."""
+    tm = WGRAD_CASES[name]()
+    img = Img(17)
+    nb = tm.M // tm.Lout
+    dy = img.f32(tm.M * tm.N)
+    raw = img.f32(nb * tm.Lin * tm.K)
+    coef = img.f32(2 * tm.K)
+    r = _chunk_array(img, raw).reshape(-1, tm.K)
+    cf = _chunk_array(img, coef)
+    pre = (r.astype(np.float64) * cf[None, :tm.K].astype(np.float64) + cf[None, tm.K:].astype(np.float64)).astype(np.float32)
+    act = img._put(np.where(pre > 0, pre, pre * np.float32(0.01)).astype(np.float32).reshape(-1))
+    numel = len(tm.taps) * tm.N * tm.K
+    rps = -(-tm.M // 32) * 32
+    sa, sb = img.f32(numel, zero=True), img.f32(numel, zero=True)
+    ol = P.OpList()
+    ol.add(P.WGRAD_TAPS, 0, tm.ints() + [1, rps, numel], [0.01], [dy, act, sa])
+    ol.add(P.WGRAD_TAPS, P.CONV_IN_BN, tm.ints() + [1, rps, numel], [0.01], [dy, raw, sb, coef])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, sb, numel, rel=3e-5, what="wgrad in-bn vs interpreter")
+    np.testing.assert_array_equal(view(gpu, sa, np.float32, numel), view(gpu, sb, np.float32, numel))
 
 
 @pytest.mark.parametrize("name", list(WGRAD_CASES))
@@ -190,7 +353,7 @@ def test_wgrad_taps(name, nsplit):
 
 def test_wgrad_mfma_layout_identity():
     """DY = I, X asymmetric: dW[n][k] = sum_m I[m][n] X[m][k] = X[n][k] exactly."""
-    tm = TapMap(64, 64, 64, 64, 64, 64, 1, 0, 0, [(0, 0)])
+    tm = TapMap(64, 64, 64, 64, 64, 64, 1, 0, [(0, 0)])
     img = Img(4)
     dy = img._put(np.eye(64, dtype=np.float32).reshape(-1))
     xm = (np.arange(64)[:, None] * 1000 + np.arange(64)[None, :]).astype(np.float32)
@@ -212,7 +375,7 @@ def test_bn_apply_and_backward(C, M, res_mode):
     rm, rm2 = img.f32(C, 0.1), img.f32(C, 0.1)
     rv, rv2 = img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5), img._put(np.abs(img.rng.standard_normal(C)).astype(np.float32) + 0.5)
     save, save2 = img.f32(2 * C, zero=True), img.f32(2 * C, zero=True)
-    st, st2 = img.f64(R * 2 * C), img.f64(R * 2 * C)
+    st, st2 = img.f64(R(C) * 2 * C), img.f64(R(C) * 2 * C)
     # statistics as the producing conv would have accumulated them (patched into the fp64 chunks)
     def chunk_array(ref):
         o = 0
@@ -228,7 +391,7 @@ def test_bn_apply_and_backward(C, M, res_mode):
         chunk_array(s_ref)[C: 2 * C] = (r * r).sum(0)
     g1, g2 = img.f32(M * C), img.f32(M * C)
     gout, dr, dr2 = img.f32(M * C, zero=True), img.f32(M * C, zero=True), img.f32(M * C, zero=True)
-    bs, bs2 = img.f64(R * 2 * C), img.f64(R * 2 * C)
+    bs, bs2 = img.f64(R(C) * 2 * C), img.f64(R(C) * 2 * C)
     dgam, dbet, dgam2, dbet2 = (img.f32(C, zero=True) for _ in range(4))
     ol = P.OpList()
     bufs = [raw, out, st, gamma, beta, rm, rv, save]
@@ -271,7 +434,7 @@ def test_stem(Bn, Lin):
     Lout = (Lin - 1) // 2 + 1
     img = Img(7)
     x, w = img.f32(Bn * Lin), img.f32(64 * 3)
-    out, st = img.f32(Bn * Lout * 64, zero=True), img.f64(R * 128)
+    out, st = img.f32(Bn * Lout * 64, zero=True), img.f64(R(64) * 128)
     dr, dw = img.f32(Bn * Lout * 64), img.f32(192, zero=True)
     ol = P.OpList()
     ol.add(P.STEM_FWD, 0, [Bn, Lin, Lout, 64], (), [x, w, out, st])
@@ -313,7 +476,7 @@ def test_linear_family(M, N, K):
     ldx, ldy = K + 3, N + 2
     x, w, bv = img.f32(M * ldx), img.f32(N * K, 0.2), img.f32(N)
     y = img.f32(M * ldy, zero=True)
-    st = img.f64(R * 2 * N)
+    st = img.f64(R(N) * 2 * N)
     dy = img.f32(M * ldy)
     dx = img.f32(M * ldx, zero=True)
     dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
@@ -440,16 +603,16 @@ def run_program_both(img, recs):
 def test_pair_conv_and_bn(w_kn):
     """HP_OP_PAIR: two different-shaped convs / BatchNorm passes in one launch each."""
     img = Img(21)
-    tms = [TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)]),
-           TapMap(5 * 50, 128, 64, 50, 50, 50, 1, 0, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)])]
+    tms = [TapMap(B * 25, 64, 64, 25, 25, 25, 1, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)]),
+           TapMap(5 * 50, 128, 64, 50, 50, 50, 1, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)])]
     ol = P.OpList()
     outs = []
     for tm in tms:
         a = img.f32((tm.M // tm.Lout) * tm.Lin * tm.K)
         w = img.f32(3 * tm.N * tm.K, scale=0.1)
         out = img.f32(tm.M * tm.N, zero=True)
-        st = img.f64(R * 2 * tm.N)
-        ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | P.CONV_STATS | P.FLAG_MEMBER, tm.ints(), (), [a, w, out, None, st])
+        st = img.f64(R(tm.N) * 2 * tm.N)
+        ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | P.CONV_STATS | P.FLAG_MEMBER, tm.conv_ints(), (), [a, w, out, None, st])
         outs.append((tm, out, st))
     ol.add(P.PAIR, 0, [0, 1])
     # BN apply on both conv outputs, paired
@@ -495,7 +658,7 @@ def test_wgrad_group_two_problems():
 def test_conv_eval_bn_epilogue_equals_conv_then_bn_apply(with_res, act):
     """CONV_TAPS flag 8 (eval BatchNorm folded into the epilogue) against the interpreter AND, bit for bit,
     against the two-launch form conv -> BN_APPLY(eval) on the GPU."""
-    tm = TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, 0, [(t - 1, t) for t in range(3)])
+    tm = TapMap(B * 13, 128, 64, 13, 25, 25, 2, 0, [(t - 1, t) for t in range(3)])
     M, N, K = tm.M, tm.N, tm.K
     img = Img(5)
     a, w = img.f32(B * 25 * K), img.f32(3 * N * K, 0.05)
@@ -504,9 +667,9 @@ def test_conv_eval_bn_epilogue_equals_conv_then_bn_apply(with_res, act):
     res = img.f32(M * N)
     out_f, raw, out_2, save = img.f32(M * N, zero=True), img.f32(M * N, zero=True), img.f32(M * N, zero=True), img.f32(2 * N, zero=True)
     ol = P.OpList()
-    ol.add(P.CONV_TAPS, P.CONV_BN_EVAL | (P.CONV_ACT if act else 0), tm.ints(), [1e-5, 0.01],
+    ol.add(P.CONV_TAPS, P.CONV_BN_EVAL | (P.CONV_ACT if act else 0), tm.conv_ints(), [1e-5, 0.01],
            [a, w, out_f, None, None, gamma, beta, rmean, rvar, res if with_res else None])
-    ol.add(P.CONV_TAPS, 0, tm.ints(), (), [a, w, raw, None, None])
+    ol.add(P.CONV_TAPS, 0, tm.conv_ints(), (), [a, w, raw, None, None])
     ol.add(P.BN_APPLY, 0, [M, N, 1 if with_res else 0, 0, 1 if act else 0], [0.01, 1e-5, 0.1],
            [raw, out_2, None, gamma, beta, rmean, rvar, save] + ([res] if with_res else []))
     gpu, cpu = run_both(img, ol.array())

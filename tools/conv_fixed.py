@@ -7,12 +7,12 @@ from hippie_amd.program import DeviceProgram, OpList, Ref, TapMap
 
 def bench(M, N, K, L, ntaps, reps=30):
     taps = [(t - 1, t) for t in range(3)][:ntaps] if ntaps > 1 else [(0, 0)]
-    tm = TapMap(M, N, K, L, L, L, 1, 0, 0, taps)
+    tm = TapMap(M, N, K, L, L, L, 1, 0, taps)
     ws = torch.randn(M * K + 3 * N * K + M * N, device="cuda") * 0.05
     ra, rw, ro = Ref(P.WS, 0), Ref(P.WS, 4 * M * K), Ref(P.WS, 4 * (M * K + 3 * N * K))
     ol = OpList()
     for _ in range(reps):
-        ol.add(P.CONV_TAPS, 0, tm.ints(), (), [ra, rw, ro, None, None])
+        ol.add(P.CONV_TAPS, 0, tm.conv_ints(), (), [ra, rw, ro, None, None])
     dummy = torch.zeros(16, device="cuda")
     prog = DeviceProgram(ol.array(), [ws.data_ptr()] + [dummy.data_ptr()] * 5, [ws.numel() * 4] + [64] * 5)
     prog.profile(0, reps)

@@ -11,7 +11,7 @@ from hippie_amd.program import DeviceProgram, OpList, Ref, TapMap
 
 
 def bench(M, N, K, L, w_kn=False, dbg=0, reps=30, stats=False):
-    tm = TapMap(M, N, K, L, L, L, 1, 0, 0, [(t - 1, t) for t in range(3)])
+    tm = TapMap(M, N, K, L, L, L, 1, 0, [(t - 1, t) for t in range(3)])
     a = torch.randn(M * K, device="cuda")
     w = torch.randn(3 * N * K, device="cuda") * 0.05
     out = torch.zeros(M * N, device="cuda")
@@ -21,7 +21,7 @@ def bench(M, N, K, L, w_kn=False, dbg=0, reps=30, stats=False):
     rs = Ref(P.WS, 4 * (M * K + 3 * N * K + M * N))
     ol = OpList()
     for _ in range(reps):
-        ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | (P.CONV_STATS if stats else 0), tm.ints(), (),
+        ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | (P.CONV_STATS if stats else 0), tm.conv_ints(), (),
                [ra, rw, ro, None, rs if stats else None])
     dummy = torch.zeros(16, device="cuda")
     prog = DeviceProgram(ol.array(), [ws.data_ptr()] + [dummy.data_ptr()] * 5, [ws.numel() * 4] + [64] * 5)
