@@ -518,7 +518,9 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
     xsh = gload4(p.coef + t.K + c0 + cq);
   }
   const float xslope = p.slope;
+  unsigned okmask = 0;     // bit 2*tau + j: rx[tau][j] holds a real row (the transform must not touch padding zeros)
   auto load_regs = [&](int mb) {
+    okmask = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int m = mb + lr + 16 * j;
@@ -535,12 +537,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
         const bool ok = mv && pos >= 0 && pos < t.P && (c0 + cq < t.K);
         rx[tau][j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
-          float4 v = gload4(gX + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
-          if (x_bn) {     // the activation the forward conv consumed, re-evaluated bit for bit
-            v.x = lrelu(fmaf(v.x, xsc.x, xsh.x), xslope); v.y = lrelu(fmaf(v.y, xsc.y, xsh.y), xslope);
-            v.z = lrelu(fmaf(v.z, xsc.z, xsh.z), xslope); v.w = lrelu(fmaf(v.w, xsc.w, xsh.w), xslope);
-          }
-          rx[tau][j] = v;
+          rx[tau][j] = gload4(gX + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
+          okmask |= 1u << (2 * tau + j);
         }
       }
     }
@@ -550,8 +548,18 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
     for (int j = 0; j < 2; ++j) {
       *reinterpret_cast<float4*>(smem + (lr + 16 * j) * 64 + cq) = rdy[j];
 #pragma unroll
-      for (int tau = 0; tau < NT; ++tau)
-        *reinterpret_cast<float4*>(smem + (1 + tau) * T + (lr + 16 * j) * 64 + cq) = rx[tau][j];
+      for (int tau = 0; tau < NT; ++tau) {
+        float4 v = rx[tau][j];
+        if (x_bn) {
+          // the activation the forward conv consumed, re-evaluated bit for bit — HERE, at LDS-store time: the loads
+          // were issued one slice earlier and have been in flight under the MFMA block (a transform inside
+          // load_regs would wait for them before the MFMAs)
+          const float keep = (okmask >> (2 * tau + j)) & 1u ? 1.f : 0.f;
+          v.x = lrelu(fmaf(v.x, xsc.x, xsh.x), xslope) * keep; v.y = lrelu(fmaf(v.y, xsc.y, xsh.y), xslope) * keep;
+          v.z = lrelu(fmaf(v.z, xsc.z, xsh.z), xslope) * keep; v.w = lrelu(fmaf(v.w, xsc.w, xsh.w), xslope) * keep;
+        }
+        *reinterpret_cast<float4*>(smem + (1 + tau) * T + (lr + 16 * j) * 64 + cq) = v;
+      }
     }
   };
 

@@ -223,7 +223,12 @@ def manifests():
     print("manifest:", len(man["unimodal_z10_o50"]), len(man["multimodal_z10_o50_100"]), man["n_params_unimodal"])
 
 
+C5_CASE = dict(tag="z64_L256_32_B8", z=64, L1=256, L2=32, B=8, beta=1.0, w1=1.0, w2=1.0, steps=1, lr=1e-3, salt=8)
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["c5"]:          # only the BASELINE config-5 shape (multimodal, z=64, wave 256 + time 32) at a tiny batch
+        multimodal_case(**C5_CASE)
+        sys.exit(0)
     manifests()
     # wave model: pretrain style (1-D labels -> source only), no clip (scripts/...:200-207)
     unimodal_case("wave_z10_L50_B16", z=10, L=50, B=16, with_class=False, beta=1.0, clip=None, steps=3, lr=1e-3)
@@ -239,3 +244,4 @@ if __name__ == "__main__":
     unimodal_case("wave_z10_L50_B32_traj", z=10, L=50, B=32, with_class=False, beta=1.0, clip=None, steps=6, lr=1e-6, salt=9)
     unimodal_case("time_z10_L100_B32_traj_clip", z=10, L=100, B=32, with_class=False, beta=1.0, clip=1.0, steps=6, lr=1e-6, salt=10)
     multimodal_case("z10_B12", z=10, L1=50, L2=100, B=12, beta=1.0, w1=1.0, w2=0.5, steps=2, lr=1e-3, salt=7)
+    multimodal_case(**C5_CASE)

@@ -126,18 +126,21 @@ def test_unimodal_oracle_equals_reference(tag, c):
             np.testing.assert_allclose(gr[k.split(".", 1)[1]].numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
-def test_multimodal_oracle_equals_reference():
-    g = load("multimodal_z10_B12.npz")
-    z, L1, L2, B, salt = 10, 50, 100, 12, 7
+@pytest.mark.parametrize("fname,z,L1,L2,B,salt,w2,steps", [
+    ("multimodal_z10_B12.npz", 10, 50, 100, 12, 7, 0.5, 2),
+    ("multimodal_z64_L256_32_B8.npz", 64, 256, 32, 8, 8, 1.0, 1),       # BASELINE config 5's shape at a tiny batch
+])
+def test_multimodal_oracle_equals_reference(fname, z, L1, L2, B, salt, w2, steps):
+    g = load(fname)
     m = O.OracleModel("multimodal", z, L1, output_size2=L2, salt=salt)
     x1, src, cls, eps = O.synth_inputs(B, L1, z, salt=salt, name="x1")
     x2, _, _, _ = O.synth_inputs(B, L2, z, salt=salt, name="x2")
     batch = (x1, x2, src, None)
-    for s in (1, 2):
-        outs, ls, norm = m.train_step(batch, eps, lr=1e-3, beta=1.0, clip=1.0, w1=1.0, w2=0.5)
+    for s in range(1, steps + 1):
+        outs, ls, norm = m.train_step(batch, eps, lr=1e-3, beta=1.0, clip=1.0, w1=1.0, w2=w2)
         if s == 1:
             np.testing.assert_allclose([float(v) for v in ls], g["scalars"], rtol=1e-6)
-    for name, r in zip(g["state_names"], g["state_stats_step2"]):
+    for name, r in zip(g["state_names"], g[f"state_stats_step{steps}"]):
         name = str(name)
         if zero_grad_key(name):
             assert abs(stats(m.state[name])[2] - r[2]) <= 2.2e-3, name

@@ -1,5 +1,5 @@
 # rocprofv3 PMC passes over the bench command (one counter set per run, no trace domains), GPU box only.
-#   bash tools/pmc_round.sh   -> gpurun_out/pmc_<COUNTER>/... + gpurun_out/r01_conv_pmc.json
+#   bash tools/pmc_round.sh [git head]  -> gpurun_out/pmc_<COUNTER>/... + gpurun_out/r02_conv_pmc.json
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -10,4 +10,4 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   echo "pass $tag done: $(ls $R/gpurun_out/pmc_$tag | head -3 | tr '\n' ' ')"
 done
 cd $R
-python3 tools/pmc_summary.py gpurun_out conv_taps gpurun_out/r01_conv_pmc.json
+python3 tools/pmc_summary.py gpurun_out conv_taps gpurun_out/r02_conv_pmc.json $1
