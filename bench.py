@@ -287,6 +287,48 @@ def traffic_from_pmc(args):
         return None, None
 
 
+class HbmLoader:
+    """DataLoader(batch_size, shuffle=True) over HBM-resident tensors: ([B,1,L], labels[B]) batches, last one ragged."""
+
+    def __init__(self, x, labels, batch, seed):
+        self.x, self.labels, self.batch = x, labels, batch
+        self.gen = torch.Generator(device="cpu").manual_seed(seed)
+
+    def __len__(self):
+        return -(-self.x.shape[0] // self.batch)
+
+    def __iter__(self):
+        perm = torch.randperm(self.x.shape[0], generator=self.gen).to(self.x.device)
+        for i in range(0, len(perm), self.batch):
+            j = perm[i: i + self.batch]
+            yield self.x.index_select(0, j).unsqueeze(1), self.labels.index_select(0, j)
+
+
+def trainer_rate(device, data, epochs=2):
+    """Throughput of the REFERENCE-API path (what the scripts call): hippieUnimodalCVAE + hippieUnimodalEmbeddingModelCVAE
+    driven by Trainer.fit over the synthetic pretrain pool at batch 512, the wave model (no clipping) and then the time
+    model (clip 1.0) one after the other exactly as scripts/train_model_with_multimodal.py:200-224 trains them — no
+    cross-model overlap, a ragged last batch per epoch, per-epoch shuffling by index.  samples/s = N * epochs / (t_wave + t_time)."""
+    from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
+    from hippie_amd.trainer import Trainer
+    N = data[0].shape[0]
+    times = []
+    for k, (L, clip) in enumerate(((data[0].shape[1], None), (data[1].shape[1], 1.0))):
+        net = hippieUnimodalCVAE(z_dim=Z_DIM, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5, device=device)
+        mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3, weight_decay=0.01)
+        loader = HbmLoader(data[k], data[2], BATCH, seed=7 + k)
+        Trainer(max_epochs=1, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0).fit(mod, loader)   # warm-up: lowers + captures
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        Trainer(max_epochs=epochs, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0).fit(mod, loader)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    return {"value": N * epochs / sum(times), "unit": "samples/s", "epochs": epochs, "units_per_epoch": N,
+            "wave_s": times[0], "time_s": times[1],
+            "path": "hippie_amd.model.hippieUnimodalEmbeddingModelCVAE.training_step / optimizer.step via hippie_amd.trainer.Trainer.fit "
+                    "(hipGraph replay, per-step losses kept on the device), wave then time model sequentially"}
+
+
 def cpu_baseline(steps=20, warm=3):
     """The torch-CPU oracle (kind 'port': a restatement of the reference's PyTorch path, pinned to it
     by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512; median of `steps` timed
@@ -352,6 +394,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trainer", action="store_true", help="skip the secondary reference-API (Trainer.fit) throughput measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--pair", action="store_true", help="one zipped wave+time program (paired launches) instead of two engines on two streams")
     ap.add_argument("--overlap", action="store_true", help="decoder-side wgrad + first gradient bucket on a side stream (measured slower on ROCm 7: DESIGN.md 5.3)")
@@ -490,6 +533,10 @@ def main():
                          # whole-step view: samples/s x 3 x forward FLOPs per unit, all kernels and gaps included
                          "whole_step_tflops_per_gpu": BATCH * args.steps / dt * 3.0 * sum(e.plan.flops_fwd for e in pair.eng) / BATCH / 1e12},
         }
+        if world == 1 and not args.no_trainer and not args.pair:
+            tr = trainer_rate(device, data)
+            out["trainer_samples_per_s"] = tr["value"]
+            out["trainer_path"] = tr
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())

@@ -18,6 +18,11 @@ from .program import DeviceProgram, HipEngineError
 
 
 class Engine:
+    # Provider of the reparameterisation noise when set_inputs() is not handed one: None = torch's device generator
+    # (`torch.randn_like(std)`, hippie/model.py:48); a callable(engine) -> [B, z] tensor lets a caller run a whole
+    # pipeline (Trainer.fit, scripts) on a prescribed noise sequence — the pipeline parity test does.
+    eps_source = None
+
     def __init__(self, cfg: planner.ModelCfg, batch: int, train: planner.TrainCfg = None, with_class=False,
                  device=None, share_params_from: "Engine" = None, _view=None):
         if not torch.cuda.is_available():
@@ -154,8 +159,27 @@ class Engine:
             if lo < 0 or hi >= rows:
                 raise IndexError(f"{name} label out of range: values span [{lo}, {hi}] but the {name} embedding has {rows} rows")
 
+    def flag_bad_labels(self, src, cls=None):
+        """check_labels without the host sync: out-of-range labels are recorded in a device-side flag (the kernels treat
+        such rows as zeros meanwhile) and raise_if_bad_labels() reports them later — once per epoch in Trainer.fit."""
+        if getattr(self, "_bad_labels", None) is None:
+            self._bad_labels = torch.zeros((), dtype=torch.bool, device=self.device)
+        for t, rows in ((src, self.cfg.num_sources), (cls, self.cfg.num_classes)):
+            if t is not None and t.numel():
+                self._bad_labels |= ((t < 0) | (t >= rows)).any()
+
+    def raise_if_bad_labels(self):
+        bad = getattr(self, "_bad_labels", None)
+        if bad is not None and bool(bad):
+            self._bad_labels = None
+            raise IndexError(f"a source / class label was out of range (embedding tables have {self.cfg.num_sources} / "
+                             f"{self.cfg.num_classes} rows)")
+
     def set_inputs(self, x, src, cls=None, eps=None, x2=None, validate=True):
-        if validate:
+        """validate: True = check the labels now (one host sync), "deferred" = flag_bad_labels, False = not at all."""
+        if validate == "deferred":
+            self.flag_bad_labels(src, cls if self.with_class else None)
+        elif validate:
             self.check_labels(src, cls if self.with_class else None)
         self.io("x").copy_(x.reshape(self.io("x").shape), non_blocking=True)
         if x2 is not None:
@@ -167,6 +191,8 @@ class Engine:
             self.io("cls").copy_(cls, non_blocking=True)
         elif self.with_class:
             raise ValueError("engine was lowered with class labels; pass cls")
+        if eps is None and Engine.eps_source is not None:
+            eps = Engine.eps_source(self)
         if eps is None:
             self.io("eps").normal_()          # torch.randn_like(std), hippie/model.py:48
         else:

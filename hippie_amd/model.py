@@ -35,8 +35,18 @@ class _Net:
         self._engines = {}            # (B, with_class) -> Engine
         self._root = None
         self._train_cfg = planner.TrainCfg()
-        self._pending_sd = None
+        # Parameters are drawn HERE, at construction, from torch's global CPU generator in the reference constructor's
+        # order: `torch.manual_seed(42); ...; wave = hippieUnimodalCVAE(...); time = hippieUnimodalCVAE(...)` consumes
+        # the generator exactly as the reference script does (scripts/train_model_with_multimodal.py:78,169-176).  They
+        # move to HBM when the first engine is lowered.
+        self._pending_sd = reference_init_state(cfg)
         self._generation = 0
+        # hipGraph replay of the lowered segments (one capture per batch shape / label mode): what Trainer.fit and the
+        # scripts run.  False = eager launches (debugging).
+        self.use_graph = True
+        # "sync": labels are range-checked on the host before every forward (IndexError at once, like nn.Embedding);
+        # "deferred": device-side flag, raised by check_deferred_errors() — Trainer.fit does that once per epoch
+        self.label_check = "sync"
 
     # -- engine cache -----------------------------------------------------------------
     def engine(self, batch, with_class) -> Engine:
@@ -109,33 +119,140 @@ class _Net:
         if self.training and eng.B < 2:
             # torch's BatchNorm1d in training mode: "Expected more than 1 value per channel when training"
             raise ValueError("Expected more than 1 value per channel when training (batch of 1 in train mode)")
-        eng.set_inputs(x, src, cls, eps, x2=x2)
-        return eng.forward(training=self.training)
+        eng.set_inputs(x, src, cls, eps, x2=x2, validate=True if self.label_check == "sync" else "deferred")
+        return eng.forward(training=self.training, use_graph=self.use_graph)
+
+    def check_deferred_errors(self):
+        for eng in self._engines.values():
+            eng.raise_if_bad_labels()
+
+
+def reference_param_order(cfg: planner.ModelCfg):
+    """Parameter keys with shapes in the order the reference's constructors CREATE (and therefore randomly initialise)
+    them: hippieUnimodalCVAE.__init__ (hippie/model.py:13-44), MultiModalCVAE.__init__ (:352-395), ResNet18Enc /
+    BasicBlockEnc (hippie/backbones.py:20-34,74-92), ResNet18Dec / BasicBlockDec / ResizeConv1d (:7-11,45-63,107-126).
+    It is also the reference's state_dict order.  kind: "conv" | "linear" (weight then bias, kaiming-uniform(a=sqrt 5)
+    and U(+-1/sqrt(fan_in))), "bn" (ones / zeros, no draw), "emb" (N(0,1))."""
+    z, H = cfg.z_dim, cfg.class_hidden_dim
+    out = []
+
+    def conv(key, co, ci, k, bias=False):
+        out.append((key + ".weight", (co, ci, k), "weight"))
+        if bias:
+            out.append((key + ".bias", (co,), "bias:" + key + ".weight"))
+
+    def linear(key, n, k):
+        out.append((key + ".weight", (n, k), "weight"))
+        out.append((key + ".bias", (n,), "bias:" + key + ".weight"))
+
+    def bn(key, c):
+        out.append((key + ".weight", (c,), "ones"))
+        out.append((key + ".bias", (c,), "zeros"))
+
+    def encoder(pre):
+        conv(pre + "conv1", 64, 1, 3)
+        bn(pre + "bn1", 64)
+        cin = 64
+        for li, planes in enumerate((64, 128, 256, 512), start=1):
+            for bi in (0, 1):
+                stride = 2 if (bi == 0 and li > 1) else 1
+                p = f"{pre}layer{li}.{bi}."
+                conv(p + "conv1", planes, cin, 3)
+                bn(p + "bn1", planes)
+                conv(p + "conv2", planes, planes, 3)
+                bn(p + "bn2", planes)
+                if stride != 1:
+                    conv(p + "shortcut.0", planes, cin, 1)
+                    bn(p + "shortcut.1", planes)
+                cin = planes
+        linear(pre + "linear", 2 * z, 512)
+
+    def decoder(pre, output_size):
+        linear(pre + "linear", 512, 2 * z)
+        cin = 512
+        for li, planes in ((4, 256), (3, 128), (2, 64), (1, 64)):
+            for bi, stride in enumerate((1, 1 if li == 1 else 2)):
+                p = f"{pre}layer{li}.{bi}."
+                cout = cin // stride
+                conv(p + "conv2", cin, cin, 3)
+                bn(p + "bn2", cin)
+                if stride == 1:
+                    conv(p + "conv1", cout, cin, 3)
+                    bn(p + "bn1", cout)
+                else:
+                    conv(p + "conv1.conv", cout, cin, 3, bias=True)
+                    bn(p + "bn1", cout)
+                    conv(p + "shortcut.0.conv", cout, cin, 3, bias=True)
+                    bn(p + "shortcut.1", cout)
+            cin = planes
+        conv(pre + "conv1.conv", 1, 64, 3, bias=True)
+        linear(pre + "linear_out", output_size, 64)
+
+    def dec_fc(name):
+        linear(name + ".0", 2 * z, z + 2 * H)
+        linear(name + ".2", 2 * z, 2 * z)
+        bn(name + ".3", 2 * z)
+
+    if cfg.kind == "unimodal":
+        encoder("encoder.")
+        linear("encoder_fc.0", 2 * z, 2 * z + 2 * H)
+        bn("encoder_fc.1", 2 * z)
+        linear("encoder_fc.3", z, 2 * z)
+        bn("encoder_fc.4", z)
+    else:
+        encoder("encoder_mod1.")
+        encoder("encoder_mod2.")
+        linear("fusion_encoder.0", 2 * z, 4 * z + 2 * H)
+        bn("fusion_encoder.1", 2 * z)
+        linear("fusion_encoder.3", z, 2 * z)
+    out.append(("source_embedding.weight", (cfg.num_sources, H), "emb"))
+    out.append(("class_embedding.weight", (cfg.num_classes, H), "emb"))
+    linear("z_mean", z, z)
+    linear("z_log_var", z, z)
+    if cfg.kind == "unimodal":
+        dec_fc("decoder_fc")
+        decoder("decoder.", cfg.output_size)
+    else:
+        dec_fc("decoder_fc_mod1")
+        dec_fc("decoder_fc_mod2")
+        decoder("decoder_mod1.", cfg.output_size)
+        decoder("decoder_mod2.", cfg.output_size2)
+    return out
+
+
+def reference_init_state(cfg: planner.ModelCfg, generator=None):
+    """What the reference's constructor leaves in its parameters, drawn from torch's CPU generator (the global one by
+    default) with the same torch.nn.init calls in the same order — `torch.manual_seed(42)` followed by the same
+    preceding draws therefore gives the reference's initial weights bit for bit (pinned by tests/golden/init_seed42.npz,
+    produced by the reference classes).  nn.Conv1d / nn.Linear.reset_parameters: kaiming_uniform_(weight, a=sqrt(5)),
+    bias ~ U(+-1/sqrt(fan_in)); nn.Embedding: N(0, 1); BatchNorm1d: weight 1, bias 0 (no draw)."""
+    import math
+    sd = OrderedDict()
+    for key, shape, kind in reference_param_order(cfg):
+        t = torch.empty(shape, dtype=torch.float32)
+        if kind == "weight":
+            torch.nn.init.kaiming_uniform_(t, a=math.sqrt(5), generator=generator)
+        elif kind.startswith("bias:"):
+            w = sd[kind[5:]]
+            fan_in = w[0].numel()                       # in_channels * kernel_size (Conv1d) / in_features (Linear)
+            bound = 1.0 / math.sqrt(fan_in) if fan_in > 0 else 0.0
+            torch.nn.init.uniform_(t, -bound, bound, generator=generator)
+        elif kind == "emb":
+            torch.nn.init.normal_(t, generator=generator)
+        elif kind == "ones":
+            t.fill_(1.0)
+        else:
+            t.zero_()
+        sd[key] = t
+    return sd
 
 
 def _default_init(eng: Engine, seed=None):
-    """torch's default initialisers (kaiming-uniform(a=sqrt 5) => U(+-1/sqrt(fan_in)) for weights and biases,
-    BatchNorm 1/0, Embedding N(0,1)), drawn from the torch CPU generator like the reference's constructors."""
-    g = None
-    if seed is not None:
-        g = torch.Generator().manual_seed(seed)
-    sd = {}
-    bn_prefixes = set(eng.plan.bn_keys)
-    for k, info in eng.plan.params.items():
-        shp = info.shape
-        pre = k.rsplit(".", 1)[0]
-        if k.endswith("embedding.weight"):
-            v = torch.randn(shp, generator=g)
-        elif pre in bn_prefixes:
-            v = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
-        else:
-            wshape = eng.plan.params[pre + ".weight"].shape
-            fan_in = 1
-            for d in wshape[1:]:
-                fan_in *= d
-            bound = 1.0 / fan_in ** 0.5
-            v = (torch.rand(shp, generator=g) * 2 - 1) * bound
-        sd[k] = v
+    """The reference constructor's initialisation (reference_init_state), from the global CPU generator unless a seed
+    is given."""
+    g = torch.Generator().manual_seed(seed) if seed is not None else None
+    sd = reference_init_state(eng.cfg, g)
+    assert set(sd) == set(eng.plan.params), set(sd) ^ set(eng.plan.params)
     eng.load_state_dict(sd, strict=False)
 
 
@@ -166,8 +283,9 @@ class hippieUnimodalCVAE(_Net):
         if data.shape[-1] != self.cfg.output_size:
             raise ValueError(f"expected input length {self.cfg.output_size}, got {tuple(data.shape)}")
         eng = self.engine(data.shape[0], class_labels is not None)
-        eng.set_inputs(data, source_labels, class_labels, eps=torch.zeros_like(eng.io("eps")))
-        return eng.encode()
+        eng.set_inputs(data, source_labels, class_labels, eps=torch.zeros_like(eng.io("eps")),
+                       validate=True if self.label_check == "sync" else "deferred")
+        return eng.encode(use_graph=self.use_graph)
 
 
 class MultiModalCVAE(_Net):
@@ -191,21 +309,22 @@ class MultiModalCVAE(_Net):
 class _Loss:
     """What training_step returns: a scalar handle with .item() / .backward() / float()."""
 
-    def __init__(self, eng: Engine, slot=0):
-        self.eng, self.slot = eng, slot
+    def __init__(self, eng: Engine, slot=0, use_graph=True):
+        self.eng, self.slot, self.use_graph = eng, slot, use_graph
         self._backward_done = False
+        self.value = eng.io("scalars")[slot].clone()      # device scalar of THIS step (the slot is overwritten by the next one)
 
     def item(self):
-        return float(self.eng.io("scalars")[self.slot])
+        return float(self.value)                          # host sync, like torch's loss.item()
 
     __float__ = item
 
     def detach(self):
-        return self.eng.io("scalars")[self.slot].clone()
+        return self.value
 
     def backward(self):
         if not self._backward_done:
-            self.eng.backward()
+            self.eng.backward(self.use_graph)
             self._backward_done = True
 
 
@@ -223,7 +342,7 @@ class _Optimizer:
         eng = self.last_engine
         if eng is None:
             raise RuntimeError("optimizer.step() before any training_step")
-        eng.optimizer_step()
+        eng.optimizer_step(self.module.model.use_graph)
 
     @property
     def param_groups(self):
@@ -260,6 +379,10 @@ class _TrainModule:
         self.lr, self.weight_decay = learning_rate, weight_decay
         self.mod1_weight, self.mod2_weight = w1, w2
         self.val_loss, self.train_loss = [], []
+        # The reference appends loss.item() in every step (hippie/model.py:114): one host sync per step.  With
+        # sync_every_step False the per-step values stay on the device and are fetched once, when the epoch-end hooks
+        # average them (same printed numbers, no per-step sync) — Trainer.fit selects that.
+        self.sync_every_step = True
         self.logged = {}
         self.current_epoch = 0
         self.trainer = None
@@ -310,14 +433,29 @@ class _TrainModule:
     def load_state_dict(self, sd, strict=True):
         return self.model.load_state_dict(sd, strict=strict, prefix="model.")
 
+    @staticmethod
+    def _mean(values):
+        if not values:
+            return None
+        if torch.is_tensor(values[0]):
+            return float(torch.stack(values).double().mean())
+        return sum(values) / len(values)
+
+    def _record(self, store, loss):
+        store.append(loss.item() if self.sync_every_step else loss.value)
+
     def on_validation_epoch_end(self):
-        if self.val_loss:
-            print(f"Average validation loss is {sum(self.val_loss) / len(self.val_loss):.2f}")
+        m = self._mean(self.val_loss)
+        if m is not None:
+            print(f"Average validation loss is {m:.2f}")
+        self.last_val_mean = m
         self.val_loss = []
 
     def on_train_epoch_end(self):
-        if self.train_loss:
-            print(f"Average training loss is {sum(self.train_loss) / len(self.train_loss):.2f}")
+        m = self._mean(self.train_loss)
+        if m is not None:
+            print(f"Average training loss is {m:.2f}")
+        self.last_train_mean = m
         self.train_loss = []
 
     @staticmethod
@@ -340,12 +478,12 @@ class hippieUnimodalEmbeddingModelCVAE(_TrainModule):
         self.model.train(prefix == "train")
         eng = self.model.engine(data.shape[0], cls is not None)
         self.model._run_forward(eng, data, src, cls, None)
-        sc = eng.io("scalars")
+        sc = eng.io("scalars")                    # views: hold the values of the most recent step
         self.log(prefix + "_loss", sc[0])
         self.log(prefix + "_mse_loss", sc[1])
         self.log(prefix + "_kl_loss", sc[3])
-        loss = _Loss(eng)
-        store.append(loss.item())                 # loss.item() in the reference: one host sync per step
+        loss = _Loss(eng, use_graph=self.model.use_graph)
+        self._record(store, loss)                 # loss.item() in the reference: one host sync per step
         self.optimizer.last_engine = eng
         return loss
 
@@ -388,8 +526,8 @@ class MultiModalCVAETrainModule(_TrainModule):
         self.log(prefix + "_mse_loss1", sc[1])
         self.log(prefix + "_mse_loss2", sc[2])
         self.log(prefix + "_kl_loss", sc[3])
-        loss = _Loss(eng)
-        store.append(loss.item())
+        loss = _Loss(eng, use_graph=self.model.use_graph)
+        self._record(store, loss)
         self.optimizer.last_engine = eng
         return loss
 

@@ -14,7 +14,12 @@ import torch
 
 class Trainer:
     def __init__(self, max_epochs=1, gradient_clip_val=None, default_root_dir="checkpoints", patience=30,
-                 monitor="val_loss", logger_path=None, num_sanity_val_steps=2, device=None, enable_checkpointing=True):
+                 monitor="val_loss", logger_path=None, num_sanity_val_steps=2, device=None, enable_checkpointing=True,
+                 sync_every_step=False):
+        """sync_every_step: True reproduces the reference's per-step `loss.item()` host sync (hippie/model.py:114) and
+        checks labels on the host every step; False (default) keeps the step asynchronous — hipGraph replays, per-step
+        losses kept on the device and averaged at the epoch end, label range errors raised at the epoch end."""
+        self.sync_every_step = sync_every_step
         self.max_epochs, self.gradient_clip_val = max_epochs, gradient_clip_val
         self.root, self.patience, self.monitor = default_root_dir, patience, monitor
         self.logger_path = logger_path
@@ -41,10 +46,11 @@ class Trainer:
             if limit is not None and i >= limit:
                 break
             loss = module.validation_step(self._to_device(batch, self._dev(module)), i)
-            losses.append(loss.item())
+            losses.append(loss.value)
         module.on_validation_epoch_end()
+        module.model.check_deferred_errors()
         module.train()
-        return sum(losses) / max(1, len(losses))
+        return float(torch.stack(losses).double().mean()) if losses else 0.0
 
     def _dev(self, module):
         if self.device is not None:
@@ -60,6 +66,8 @@ class Trainer:
     def fit(self, module, train_dataloaders, val_dataloaders=None):
         module.trainer = self
         module.set_gradient_clip(self.gradient_clip_val)
+        module.sync_every_step = self.sync_every_step
+        module.model.label_check = "sync" if self.sync_every_step else "deferred"
         dev = self._dev(module)
         if val_dataloaders is not None and self.num_sanity_val_steps:
             self.validate(module, val_dataloaders, self.num_sanity_val_steps)
@@ -79,6 +87,7 @@ class Trainer:
                 n += batch[0].shape[0]
             torch.cuda.synchronize(dev)
             dt = time.perf_counter() - t0
+            module.model.check_deferred_errors()
             module.on_train_epoch_end()
             rec = {"epoch": epoch, "train_samples_per_s": n / dt}
             rec.update({k: float(v) for k, v in module.logged.items() if k.startswith("train")})

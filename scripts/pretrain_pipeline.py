@@ -101,18 +101,19 @@ class _Concat:
         self.labels = torch.cat([p.labels for p in parts], dim=0)
 
     def loader(self, indices, batch_size, shuffle):
-        idx = torch.as_tensor(list(indices))
+        """DataLoader(Subset(ConcatDataset, indices), batch_size, shuffle) of the reference (:155-166), with torch's own
+        DataLoader producing the INDEX batches — so the global generator is consumed exactly as there (one base-seed
+        draw per iterator, one more by RandomSampler when shuffling) — and the rows gathered from the HBM tables."""
+        index_loader = torch.utils.data.DataLoader(list(indices), batch_size=batch_size, shuffle=shuffle)
 
         class _L:
             def __iter__(s):
-                order = idx[torch.randperm(len(idx))] if shuffle else idx      # consumes the global RNG like DataLoader(shuffle=True)
-                order = order.to(self.data.device)
-                for i in range(0, len(order), batch_size):
-                    j = order[i: i + batch_size]
+                for j in index_loader:
+                    j = j.to(self.data.device)
                     yield self.data.index_select(0, j).unsqueeze(1), self.labels.index_select(0, j)
 
             def __len__(s):
-                return -(-len(idx) // batch_size)
+                return len(index_loader)
         return _L()
 
 

@@ -259,3 +259,47 @@ def test_second_optimizer_step_does_not_double_count_the_gradient_norm():
     big = m1.abs() > 1e-3 * m1.abs().max()
     ratio = (m2[big] / m1[big])
     assert float((ratio - 1.9).abs().max()) < 1e-3, float((ratio - 1.9).abs().max())
+
+
+def test_trainer_async_path_equals_per_step_sync_path(tmp_path):
+    """Trainer.fit default (hipGraph replay, losses kept on the device, label checks deferred to the epoch end) against
+    sync_every_step=True (the reference's per-step loss.item(), host-side label check every step) with the module
+    running eagerly: same epoch losses, same parameters."""
+    z, L = 10, 50
+    om = O.OracleModel("unimodal", z, L, salt=4)
+    train = batches(70, 32, L, z, seed=1)          # 32 + 32 + 6: a ragged last batch
+    val = batches(40, 32, L, z, seed=2)
+    res = []
+    for sync in (True, False):
+        net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+        net.load_state_dict({k: v.detach() for k, v in om.state.items()})
+        net.use_graph = not sync
+        mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-5, weight_decay=0.01)
+        torch.manual_seed(123)                      # the reparameterisation noise comes from the device generator
+        tr = Trainer(max_epochs=2, gradient_clip_val=1.0, enable_checkpointing=False, sync_every_step=sync)
+        tr.fit(mod, train, val)
+        res.append((tr.history, {k: v.cpu() for k, v in net.state_dict().items()}, mod.last_train_mean, mod.last_val_mean))
+    (h0, sd0, t0, v0), (h1, sd1, t1, v1) = res
+    assert len(h0) == len(h1) == 2
+    for a, b in zip(h0, h1):
+        np.testing.assert_allclose(a["val_loss"], b["val_loss"], rtol=2e-5)
+        np.testing.assert_allclose(a["train_loss"], b["train_loss"], rtol=2e-5)
+    np.testing.assert_allclose([t0, v0], [t1, v1], rtol=2e-5)
+    import re
+    for k in sd0:
+        if sd0[k].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, k):
+            H.assert_adam_close(sd1[k].numpy(), sd0[k].numpy(), 1e-5, k, steps=6, frac=5e-2)
+
+
+def test_trainer_reports_bad_labels_at_epoch_end():
+    z, L = 10, 50
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-4)
+    train = batches(64, 32, L, z, seed=1)
+    x, lab = train[1]
+    lab = lab.clone()
+    lab[3] = 9                                       # source id 9 of 5
+    train[1] = (x, lab)
+    with pytest.raises(IndexError):
+        Trainer(max_epochs=1, enable_checkpointing=False).fit(mod, train)
+    assert all(torch.isfinite(v).all() for v in net.state_dict().values() if v.dtype.is_floating_point)   # the kernels stayed safe

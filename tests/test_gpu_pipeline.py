@@ -120,3 +120,147 @@ def test_inference_script_roundtrip(tmp_path):
         assert np.isfinite(v).all()
     w = pd.read_csv(out["waveform"])[[str(i) for i in range(z)]].to_numpy()
     np.testing.assert_allclose(w.mean(1), 0, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Numerical pin of the pipeline: the script counterpart against the CPU oracle walking through the SAME
+# steps — seed 42, reference-order initialisation, torch's DataLoader index streams, sanity validation, epochs of
+# training steps with validation + top-1 checkpoint reload, label-free fine-tune with a fresh AdamW at lr/10,
+# row-standardised `enc` embeddings — on a prescribed reparameterisation-noise sequence.
+class _Noise:
+    """closed-form noise for the k-th forward of a run (same values on both sides)"""
+
+    def __init__(self):
+        self.k = 0
+
+    def draw(self, B, z):
+        from oracle import cvae_oracle as O
+        e = sum(O.unit_noise(f"pipe.eps{i}", B * z, salt=self.k) for i in range(4)) * (3.0 / 4.0) ** 0.5
+        self.k += 1
+        return torch.from_numpy(e.reshape(B, z)).float()
+
+
+def _oracle_fit(om, noise, train_batches, val_batches, epochs, lr, clip):
+    """hippie_amd.trainer.Trainer.fit + hippieUnimodalEmbeddingModelCVAE on an OracleModel: returns the state of the best
+    validation epoch (what the pipeline reloads)."""
+    import copy
+
+    def val(limit=None):
+        losses = []
+        for i, (x, lab) in enumerate(val_batches()):
+            if limit is not None and i >= limit:
+                break
+            eps = noise.draw(x.shape[0], om_z(om))
+            with torch.no_grad():
+                outs = om.forward((x, lab, None), eps, training=False)
+                losses.append(float(om.losses((x, lab, None), outs)[0]))
+        return sum(losses) / max(1, len(losses))
+
+    val(2)                                     # sanity check: two validation batches
+    best, best_state = float("inf"), None
+    for _ in range(epochs):
+        for x, lab in train_batches():
+            eps = noise.draw(x.shape[0], om_z(om))
+            om.train_step((x, lab, None), eps, lr=lr, weight_decay=0.01, beta=1.0, clip=clip)
+        v = val()
+        if v < best:
+            best, best_state = v, {k: t.detach().clone() for k, t in om.state.items()}
+    return best_state
+
+
+def om_z(om):
+    return om.state["z_mean.bias"].shape[0]
+
+
+def test_pipeline_numbers_match_the_oracle_walking_the_same_steps(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pretrain_pipeline as pp
+    from torch.utils.data import DataLoader, random_split
+    from hippie_amd.engine import Engine
+    from hippie_amd.model import reference_init_state
+    from hippie_amd import planner
+    from oracle import cvae_oracle as O
+    from oracle import preproc
+    rng = np.random.default_rng(1)
+    data = tmp_path / "datasets"
+    data.mkdir()
+    spec = make_root(data, rng)
+    out = tmp_path / "out"
+    z, bs, lr, epochs = 5, 64, 1e-5, 2
+    argv = ["--dataset", "cellexplorer-celltype", "--data-root", str(data), "--output-dir", str(out), "--batch-size", str(bs),
+            "--pretrain-max-epochs", str(epochs), "--finetune-max-epochs", "2", "--z_dim", str(z), "--learning-rate", str(lr)]
+    # ---- the product pipeline on the prescribed noise
+    noise = _Noise()
+    Engine.eps_source = staticmethod(lambda eng: noise.draw(eng.B, eng.cfg.z_dim).to(eng.device))
+    try:
+        paths = pp.main(argv)
+    finally:
+        Engine.eps_source = None
+    n_forwards = noise.k
+    # ---- the oracle, same steps
+    torch.manual_seed(42)
+    pool = pp.pretrain_pool("cellexplorer-celltype")
+    waves, times, labels = [], [], []
+    for folder, sid in pool.items():
+        wf = pd.read_csv(data / folder / "waveforms.csv").to_numpy()
+        isi = pd.read_csv(data / folder / "isi_dist.csv").to_numpy()
+        w, t = preproc.preprocess(wf, isi)
+        waves.append(w), times.append(t), labels.append(np.full(len(w), sid))
+    tabs = {"wave": torch.from_numpy(np.concatenate(waves)), "time": torch.from_numpy(np.concatenate(times))}
+    lab = torch.from_numpy(np.concatenate(labels)).long()
+    n = len(lab)
+    tr_idx, te_idx = random_split(list(range(n)), [int(0.8 * n), n - int(0.8 * n)])
+    oms = {}
+    for kind, L in (("wave", 50), ("time", 100)):         # construction order = RNG order
+        om = O.OracleModel("unimodal", z, L)
+        om.load(reference_init_state(planner.ModelCfg("unimodal", z, L, 0, 5, 5, 5)))
+        for k in om.state:                                 # BatchNorm buffers of a fresh module
+            if k.endswith("running_mean"):
+                om.state[k].zero_()
+            elif k.endswith("running_var"):
+                om.state[k].fill_(1.0)
+            elif k.endswith("num_batches_tracked"):
+                om.state[k].zero_()
+        oms[kind] = om
+    noise2 = _Noise()
+
+    def batches_of(tab, idx, shuffle):
+        loader = DataLoader(list(idx), batch_size=bs, shuffle=shuffle)
+        return lambda: ((tab[j], lab_of[j]) for j in loader)
+
+    lab_of = lab
+    for kind, clip in (("wave", None), ("time", 1.0)):
+        best = _oracle_fit(oms[kind], noise2, batches_of(tabs[kind], tr_idx, True), batches_of(tabs[kind], te_idx, False), epochs, lr, clip)
+        oms[kind].load(best)
+        for k in ("num_batches_tracked",):
+            pass
+    # label-free fine-tune on the target dataset: fresh AdamW at lr/10, loaders without shuffling
+    wf = pd.read_csv(data / "cellexplorer-celltype" / "waveforms.csv").dropna(axis=1).to_numpy()
+    isi = pd.read_csv(data / "cellexplorer-celltype" / "isi_dist.csv").dropna(axis=1).to_numpy()
+    w, t = preproc.preprocess(wf, isi)
+    ft = {"wave": torch.from_numpy(w), "time": torch.from_numpy(t)}
+    m = len(w)
+    lab_of = torch.full((m,), 3, dtype=torch.long)
+    ft_tr, ft_te = random_split(list(range(m)), [int(0.1 * m), m - int(0.1 * m)])
+    for kind, clip in (("wave", None), ("time", 1.0)):
+        om = oms[kind]
+        om.exp_avg, om.exp_avg_sq, om.step_count = {}, {}, 0
+        _oracle_fit(om, noise2, batches_of(ft[kind], ft_tr, False), batches_of(ft[kind], ft_te, False), 2, lr / 10, clip)
+        # (the pipeline does NOT reload a checkpoint after fine-tuning: the embeddings come from the final weights)
+    assert noise2.k == n_forwards, "the oracle walked a different number of forwards than the pipeline"
+    embs = {}
+    for kind in ("wave", "time"):
+        rows = []
+        for x, lb in batches_of(ft[kind], ft_tr, False)():
+            with torch.no_grad():
+                enc = oms[kind].forward((x, lb, None), torch.zeros(x.shape[0], z), training=False)[0]
+            rows.append((enc - enc.mean(dim=1)[:, None]) / enc.std(dim=1)[:, None])
+        embs[kind] = torch.cat(rows).numpy()
+    want = {"waveform": embs["wave"], "isi": embs["time"], "joint": np.concatenate([embs["wave"], embs["time"]], axis=1)}
+    for name, ref in want.items():
+        df = pd.read_csv(paths[name])
+        got = np.stack([np.array(v.strip("[]").split(), dtype=float) for v in df["embeddings"]])
+        assert got.shape == ref.shape
+        err = np.abs(got - ref).max() / np.abs(ref).max()
+        print(f"[pipeline parity] {name}: max rel err {err:.2e}")
+        assert err <= 1e-4, (name, err)
