@@ -9,6 +9,7 @@
 #include "hp_common.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -497,8 +498,8 @@ __global__ void repeat_bwd_kernel(const float* g1, const float* g2, float* d, in
 
 // ---- concat / embedding ----------------------------------------------------------
 struct ConcatArgs { float* out; const float* src[4]; const int64_t* idx[4]; int kind[4], w[4], ld[4], rows[4]; int B, nseg, ldo; };
-__global__ void concat_kernel(ConcatArgs p) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void concat_body(const ConcatArgs& p, int bx) {
+  const int id = bx * 256 + threadIdx.x;
   if (id >= p.B * p.ldo) return;
   const int b = id / p.ldo;
   int col = id - b * p.ldo;
@@ -516,14 +517,17 @@ __global__ void concat_kernel(ConcatArgs p) {
   }
   p.out[id] = v;
 }
-__global__ void emb_bwd_kernel(const float* d, const int64_t* idx, float* dt, int B, int w, int ld, int col0, int rows) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= B * w) return;
-  const int b = id / w, k = id - b * w;
-  const int64_t row = idx[b];
-  if (row < 0 || row >= (int64_t)rows) return;      // never write outside the table's gradient
-  atomic_add_f32(dt + (size_t)row * w + k, d[(size_t)b * ld + col0 + k]);
+__global__ __launch_bounds__(256) void concat_kernel(ConcatArgs p) { concat_body(p, blockIdx.x); }
+struct EmbArgs { const float* d; const int64_t* idx; float* dt; int B, w, ld, col0, rows; };
+__device__ __forceinline__ void emb_bwd_body(const EmbArgs& p, int bx) {
+  const int id = bx * 256 + threadIdx.x;
+  if (id >= p.B * p.w) return;
+  const int b = id / p.w, k = id - b * p.w;
+  const int64_t row = p.idx[b];
+  if (row < 0 || row >= (int64_t)p.rows) return;      // never write outside the table's gradient
+  atomic_add_f32(p.dt + (size_t)row * p.w + k, p.d[(size_t)b * p.ld + p.col0 + k]);
 }
+__global__ __launch_bounds__(256) void emb_bwd_kernel(EmbArgs p) { emb_bwd_body(p, blockIdx.x); }
 
 // ---- Linear ----------------------------------------------------------------------
 struct LinArgs {
@@ -533,8 +537,8 @@ struct LinArgs {
   float slope;
 };
 // one thread per output (small K)
-__global__ void linear_fwd_thread_kernel(LinArgs p) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void linear_fwd_thread_body(const LinArgs& p, int bx) {
+  const int id = bx * 256 + threadIdx.x;
   if (id >= p.M * p.N) return;
   const int m = id / p.N, n = id - m * p.N;
   const float* x = p.X + (size_t)m * p.ldx;
@@ -550,6 +554,7 @@ __global__ void linear_fwd_thread_kernel(LinArgs p) {
   if (p.act) s = lrelu(s, p.slope);
   p.Y[(size_t)m * p.ldy + n] = s;
 }
+__global__ __launch_bounds__(256) void linear_fwd_thread_kernel(LinArgs p) { linear_fwd_thread_body(p, blockIdx.x); }
 // one wave per output (long K): coalesced reads of both operands
 __global__ __launch_bounds__(256) void linear_fwd_wave_kernel(LinArgs p) {
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -571,8 +576,8 @@ __global__ __launch_bounds__(256) void linear_fwd_wave_kernel(LinArgs p) {
     p.Y[(size_t)m * p.ldy + n] = s;
   }
 }
-__global__ void linear_bwd_x_kernel(LinArgs p) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void linear_bwd_x_body(const LinArgs& p, int bx) {
+  const int id = bx * 256 + threadIdx.x;
   if (id >= p.M * p.K) return;
   const int m = id / p.K, k = id - m * p.K;
   const float* dy = p.DY + (size_t)m * p.ldy;
@@ -582,6 +587,7 @@ __global__ void linear_bwd_x_kernel(LinArgs p) {
   float* dst = p.DX + (size_t)m * p.ldx + k;
   *dst = p.accumulate ? *dst + s : s;
 }
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(LinArgs p) { linear_bwd_x_body(p, blockIdx.x); }
 // one wave per output when the contraction (N) is long: coalesced DY reads, strided W reads hit L2
 __global__ __launch_bounds__(256) void linear_bwd_x_wave_kernel(LinArgs p) {
   const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -598,15 +604,16 @@ __global__ __launch_bounds__(256) void linear_bwd_x_wave_kernel(LinArgs p) {
   }
 }
 // block = (output row n, chunk of <=256 input columns, slice of M); fp32 atomics into zeroed DW/DB
-__global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinArgs p, int rows_per_z) {
+__device__ __forceinline__ void linear_bwd_w_body(const LinArgs& p, int rows_per_z, int bx, int by, int bz) {
   __shared__ double lds[2 * 256];
-  const int n = blockIdx.x;
+  __syncthreads();                      // (chained launches call this body repeatedly: the previous call's readers are done)
+  const int n = bx;
   const int kw = p.K < 256 ? p.K : 256;
   const int ml = 256 / kw;
   const int tid = threadIdx.x, mlane = tid / kw;
-  const int k = blockIdx.y * kw + (tid - mlane * kw);
+  const int k = by * kw + (tid - mlane * kw);
   const bool active = mlane < ml && k < p.K;
-  const int mbeg = blockIdx.z * rows_per_z, mend = min(p.M, mbeg + rows_per_z);
+  const int mbeg = bz * rows_per_z, mend = min(p.M, mbeg + rows_per_z);
   double v[2] = {0.0, 0.0};
   if (active && mbeg < mend) {
     for (int m0 = mbeg + mlane; m0 < mend; m0 += 8 * ml) {      // batches of 8 rows: loads first, then use
@@ -636,10 +643,14 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinArgs p, int rows_p
     if (p.DB != nullptr && k == 0) atomic_add_f32(p.DB + n, (float)sb);
   }
 }
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinArgs p, int rows_per_z) {
+  linear_bwd_w_body(p, rows_per_z, blockIdx.x, blockIdx.y, blockIdx.z);
+}
 
 // ---- reparameterisation / losses ---------------------------------------------------
 __device__ __forceinline__ void block_atomic_f64(double v, double* dst) {
   __shared__ double red[4];
+  __syncthreads();                      // re-entrant: a previous call's reader (thread 0) is done with red[]
   v = wave_sum(v);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (lane == 0) red[w] = v;
@@ -650,8 +661,11 @@ __device__ __forceinline__ void block_atomic_f64(double v, double* dst) {
     atomic_add_f64(dst, s);
   }
 }
-__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, const float* eps, float* z, double* loss, int B, int zd) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+struct ReparamArgs { const float* mulv; const float* eps; float* z; double* loss; const float* dz; float* dmulv; int B, zd, lddz; float beta; };
+__device__ __forceinline__ void reparam_kl_fwd_body(const ReparamArgs& p, int bx) {
+  const float* mulv = p.mulv; const float* eps = p.eps; float* z = p.z; double* loss = p.loss;
+  const int B = p.B, zd = p.zd;
+  const int id = bx * 256 + threadIdx.x;
   double kl = 0.0;
   if (id < B * zd) {
     const int b = id / zd, j = id - b * zd;
@@ -661,8 +675,12 @@ __global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(const float* mulv, 
   }
   block_atomic_f64(kl, loss + 0);
 }
-__global__ void reparam_kl_bwd_kernel(const float* mulv, const float* eps, const float* dz, float* dmulv, int B, int zd, int lddz, float beta) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void reparam_kl_fwd_kernel(ReparamArgs p) { reparam_kl_fwd_body(p, blockIdx.x); }
+__device__ __forceinline__ void reparam_kl_bwd_body(const ReparamArgs& p, int bx) {
+  const float* mulv = p.mulv; const float* eps = p.eps; const float* dz = p.dz; float* dmulv = p.dmulv;
+  const int B = p.B, zd = p.zd, lddz = p.lddz;
+  const float beta = p.beta;
+  const int id = bx * 256 + threadIdx.x;
   if (id >= B * zd) return;
   const int b = id / zd, j = id - b * zd;
   const float mu = mulv[(size_t)b * 2 * zd + j], lv = mulv[(size_t)b * 2 * zd + zd + j];
@@ -671,18 +689,25 @@ __global__ void reparam_kl_bwd_kernel(const float* mulv, const float* eps, const
   dmulv[(size_t)b * 2 * zd + j] = g + beta * mu * invB;
   dmulv[(size_t)b * 2 * zd + zd + j] = g * eps[id] * 0.5f * expf(0.5f * lv) + beta * 0.5f * (expf(lv) - 1.f) * invB;
 }
-__global__ __launch_bounds__(256) void mse_kernel(const float* x, const float* rec, float* drec, double* loss, int n, int slot, float w) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void reparam_kl_bwd_kernel(ReparamArgs p) { reparam_kl_bwd_body(p, blockIdx.x); }
+struct MseArgs { const float* x; const float* rec; float* drec; double* loss; int n, slot; float w; };
+__device__ __forceinline__ void mse_body(const MseArgs& p, int bx) {
+  const int id = bx * 256 + threadIdx.x;
   double sq = 0.0;
-  if (id < n) {
-    const float d = rec[id] - x[id];
+  if (id < p.n) {
+    const float d = p.rec[id] - p.x[id];
     sq = (double)d * (double)d;
-    drec[id] = w * 2.f * d / (float)n;
+    p.drec[id] = p.w * 2.f * d / (float)p.n;
   }
-  block_atomic_f64(sq, loss + slot);
+  block_atomic_f64(sq, p.loss + p.slot);
 }
-__global__ void loss_finalize_kernel(const double* loss, float* out, int B, int n1, int n2, float beta, float w1, float w2) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void mse_kernel(MseArgs p) { mse_body(p, blockIdx.x); }
+struct LossArgs { const double* loss; float* out; int B, n1, n2; float beta, w1, w2; };
+__device__ __forceinline__ void loss_finalize_body(const LossArgs& p) {
+  const double* loss = p.loss; float* out = p.out;
+  const int B = p.B, n1 = p.n1, n2 = p.n2;
+  const float beta = p.beta, w1 = p.w1, w2 = p.w2;
+  if (threadIdx.x != 0) return;
   const double kl = loss[0] / (double)B;
   const double m1 = loss[1] / (double)n1;
   const double m2 = n2 > 0 ? loss[2] / (double)n2 : 0.0;
@@ -691,6 +716,7 @@ __global__ void loss_finalize_kernel(const double* loss, float* out, int B, int 
   out[2] = (float)m2;
   out[3] = (float)kl;
 }
+__global__ void loss_finalize_kernel(LossArgs p) { if (blockIdx.x == 0) loss_finalize_body(p); }
 
 // ---- decoder tail (C_out = 1) -----------------------------------------------------
 __global__ void tail_fwd_kernel(const float* act, const float* w, const float* bias, float* out, int B, int Lh, int C) {
@@ -989,6 +1015,195 @@ BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
   return a;
 }
 
+
+// ---- chained launches ---------------------------------------------------------------------------------------------
+// The heads of the cVAE (hippie/model.py:21-41,51-62) are ~35 dependent launches per model-step of a few thousand
+// FMAs each: pure launch latency.  A CHAIN runs a run of such ops, in program order, inside ONE launch of ONE
+// 256-thread workgroup: each member's own kernel body is executed over its virtual grid, with a workgroup barrier
+// and an agent-scope fence between blocks and members (the members communicate through global memory and fp64
+// atomics, which live in L2: the fence drops the CU's L1 lines).  Same bodies => same arithmetic as the stand-alone
+// launches; only the order of the fp64 / fp32 atomic sums differs.
+struct SmallEntry {
+  int op, variant;          // HP_OP_* ; variant: BatchNorm family vector width (4 / 1)
+  int gx, gy, gz;           // virtual grid of 256-thread blocks
+  int rows_per_z;           // LINEAR_BWD_W
+  union {
+    BnApplyArgs bn_apply; BnBwdReduceArgs bn_red; BnBwdApplyArgs bn_bapply; ConcatArgs concat; LinArgs lin; EmbArgs emb;
+    ReparamArgs rp; MseArgs mse; LossArgs loss;
+    struct { int64_t* step; } stepinc;
+    struct { uint4* p16; size_t n16; uint8_t* tail; int ntail; } zero;
+  } a;
+};
+
+// args + grid of one chainable op; false if the op (or this shape of it) has no chainable body
+bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
+  using hp::ptr;
+  const int32_t* I = op.i;
+  e.op = op.op; e.variant = 0; e.gx = e.gy = e.gz = 1; e.rows_per_z = 0;
+  switch (op.op) {
+    case HP_OP_BN_APPLY: {
+      e.a.bn_apply = bn_apply_args(op, bases);
+      e.variant = e.a.bn_apply.C % 4 == 0 ? 4 : 1;
+      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_apply.M, e.a.bn_apply.C, rpl_of(4)) : colgrid_v<1>(e.a.bn_apply.M, e.a.bn_apply.C, rpl_of(1));
+      e.gx = g.x; e.gy = g.y;
+      return true;
+    }
+    case HP_OP_BN_BWD_REDUCE: {
+      e.a.bn_red = bn_bwd_reduce_args(op, bases);
+      e.variant = e.a.bn_red.C % 4 == 0 ? 4 : 1;
+      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_red.M, e.a.bn_red.C, rpl_of(4)) : colgrid_v<1>(e.a.bn_red.M, e.a.bn_red.C, rpl_of(1));
+      e.gx = g.x; e.gy = g.y;
+      return true;
+    }
+    case HP_OP_BN_BWD_APPLY: {
+      e.a.bn_bapply = bn_bwd_apply_args(op, bases);
+      e.variant = e.a.bn_bapply.C % 4 == 0 ? 4 : 1;
+      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_bapply.M, e.a.bn_bapply.C, rpl_of(4)) : colgrid_v<1>(e.a.bn_bapply.M, e.a.bn_bapply.C, rpl_of(1));
+      e.gx = g.x; e.gy = g.y;
+      return true;
+    }
+    case HP_OP_CONCAT: {
+      ConcatArgs a{};
+      a.out = ptr<float>(op, 0, bases); a.B = I[0]; a.nseg = I[1]; a.ldo = I[2];
+      for (int j = 0; j < 4; ++j) {
+        a.kind[j] = I[4 + 3 * j]; a.w[j] = I[5 + 3 * j]; a.ld[j] = I[6 + 3 * j]; a.rows[j] = I[16 + j];
+        a.src[j] = ptr<const float>(op, 1 + 2 * j, bases); a.idx[j] = ptr<const int64_t>(op, 2 + 2 * j, bases);
+      }
+      e.a.concat = a; e.gx = blocks_for((int64_t)a.B * a.ldo);
+      return true;
+    }
+    case HP_OP_EMB_BWD: {
+      EmbArgs a{ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2], I[3], I[4]};
+      e.a.emb = a; e.gx = blocks_for((int64_t)I[0] * I[1]);
+      return true;
+    }
+    case HP_OP_LINEAR_FWD: {
+      LinArgs a{};
+      a.X = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.Bv = ptr<const float>(op, 2, bases);
+      a.Y = ptr<float>(op, 3, bases); a.stats = I[6] ? ptr<double>(op, 4, bases) : nullptr;
+      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldx = I[3]; a.ldy = I[4]; a.act = I[5]; a.slope = op.f[0];
+      e.a.lin = a; e.gx = blocks_for((int64_t)a.M * a.N);
+      return a.K < 128;                       // long contractions use the wave-per-output kernel (not chainable)
+    }
+    case HP_OP_LINEAR_BWD_X: {
+      LinArgs a{};
+      a.DY = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.DX = ptr<float>(op, 2, bases);
+      a.ACT = ptr<const float>(op, 3, bases);
+      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4]; a.has_mask = I[5]; a.lda = I[6]; a.accumulate = I[7];
+      a.slope = op.f[0];
+      e.a.lin = a; e.gx = blocks_for((int64_t)a.M * a.K);
+      return !(a.N >= 128 && (int64_t)a.M * a.K <= (1 << 20));
+    }
+    case HP_OP_LINEAR_BWD_W: {
+      LinArgs a{};
+      a.DY = ptr<const float>(op, 0, bases); a.X = ptr<const float>(op, 1, bases); a.DW = ptr<float>(op, 2, bases);
+      a.DB = ptr<float>(op, 3, bases);
+      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
+      const int kw = a.K < 256 ? a.K : 256;
+      const int ky = hp::cdiv(a.K, kw);
+      int nz = hp::cdiv(1024, a.N * ky);                      // aim at >= 1024 workgroups, >= 16 rows each
+      nz = max(1, min(nz, hp::cdiv(a.M, 16)));
+      e.rows_per_z = hp::cdiv(a.M, nz);
+      e.a.lin = a; e.gx = a.N; e.gy = ky; e.gz = hp::cdiv(a.M, e.rows_per_z);
+      return true;
+    }
+    case HP_OP_REPARAM_KL_FWD: {
+      ReparamArgs a{};
+      a.mulv = ptr<const float>(op, 0, bases); a.eps = ptr<const float>(op, 1, bases); a.z = ptr<float>(op, 2, bases);
+      a.loss = ptr<double>(op, 3, bases); a.B = I[0]; a.zd = I[1];
+      e.a.rp = a; e.gx = blocks_for((int64_t)I[0] * I[1]);
+      return true;
+    }
+    case HP_OP_REPARAM_KL_BWD: {
+      ReparamArgs a{};
+      a.mulv = ptr<const float>(op, 0, bases); a.eps = ptr<const float>(op, 1, bases); a.dz = ptr<const float>(op, 2, bases);
+      a.dmulv = ptr<float>(op, 3, bases); a.B = I[0]; a.zd = I[1]; a.lddz = I[2]; a.beta = op.f[0];
+      e.a.rp = a; e.gx = blocks_for((int64_t)I[0] * I[1]);
+      return true;
+    }
+    case HP_OP_MSE_FWD_BWD: {
+      MseArgs a{ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<double>(op, 3, bases), I[0], I[1], op.f[0]};
+      e.a.mse = a; e.gx = blocks_for(I[0]);
+      return true;
+    }
+    case HP_OP_LOSS_FINALIZE: {
+      LossArgs a{ptr<const double>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2], op.f[0], op.f[1], op.f[2]};
+      e.a.loss = a;
+      return true;
+    }
+    case HP_OP_STEP_INC:
+      e.a.stepinc.step = ptr<int64_t>(op, 0, bases);
+      return true;
+    case HP_OP_ZERO: {
+      uint8_t* dst = ptr<uint8_t>(op, 0, bases);
+      const size_t nbytes = (size_t)(uint32_t)I[0] + ((size_t)(uint32_t)I[1] << 32);
+      e.a.zero.p16 = reinterpret_cast<uint4*>(dst); e.a.zero.n16 = nbytes >> 4;
+      e.a.zero.tail = dst + ((nbytes >> 4) << 4); e.a.zero.ntail = (int)(nbytes & 15);
+      e.gx = (int)std::min<size_t>(2048, std::max<size_t>(1, (e.a.zero.n16 + 255) / 256));
+      return ((uintptr_t)dst & 15) == 0 && nbytes > 0;
+    }
+    default:
+      return false;
+  }
+}
+
+__device__ __forceinline__ void zero_body(uint4* p16, size_t n16, uint8_t* tail, int ntail, int bx, int nblk) {
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n16; i += (size_t)nblk * 256) p16[i] = z;
+  if (bx == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+// one virtual block of one chained op
+__device__ __forceinline__ void small_block(const SmallEntry& e, int bx, int by, int bz, double* lds_d, float* lds_f) {
+  switch (e.op) {
+    case HP_OP_BN_APPLY:
+      if (e.variant == 4) bn_apply_body<4>(e.a.bn_apply, bx, by, reinterpret_cast<float(*)[256 * 4]>(lds_f));
+      else bn_apply_body<1>(e.a.bn_apply, bx, by, reinterpret_cast<float(*)[256]>(lds_f));
+      break;
+    case HP_OP_BN_BWD_REDUCE:
+      if (e.variant == 4) bn_bwd_reduce_body<4>(e.a.bn_red, bx, by, lds_d);
+      else bn_bwd_reduce_body<1>(e.a.bn_red, bx, by, lds_d);
+      break;
+    case HP_OP_BN_BWD_APPLY:
+      if (e.variant == 4) bn_bwd_apply_body<4>(e.a.bn_bapply, bx, by, reinterpret_cast<float(*)[256 * 4]>(lds_f));
+      else bn_bwd_apply_body<1>(e.a.bn_bapply, bx, by, reinterpret_cast<float(*)[256]>(lds_f));
+      break;
+    case HP_OP_CONCAT: concat_body(e.a.concat, bx); break;
+    case HP_OP_EMB_BWD: emb_bwd_body(e.a.emb, bx); break;
+    case HP_OP_LINEAR_FWD: linear_fwd_thread_body(e.a.lin, bx); break;
+    case HP_OP_LINEAR_BWD_X: linear_bwd_x_body(e.a.lin, bx); break;
+    case HP_OP_LINEAR_BWD_W: linear_bwd_w_body(e.a.lin, e.rows_per_z, bx, by, bz); break;
+    case HP_OP_REPARAM_KL_FWD: reparam_kl_fwd_body(e.a.rp, bx); break;
+    case HP_OP_REPARAM_KL_BWD: reparam_kl_bwd_body(e.a.rp, bx); break;
+    case HP_OP_MSE_FWD_BWD: mse_body(e.a.mse, bx); break;
+    case HP_OP_LOSS_FINALIZE: loss_finalize_body(e.a.loss); break;
+    case HP_OP_STEP_INC: if (threadIdx.x == 0) e.a.stepinc.step[0] += 1; break;
+    case HP_OP_ZERO: zero_body(e.a.zero.p16, e.a.zero.n16, e.a.zero.tail, e.a.zero.ntail, bx, e.gx); break;
+    default: break;
+  }
+}
+
+__global__ __launch_bounds__(256) void chain_kernel(const SmallEntry* __restrict__ entries, int n) {
+  // LDS of the BatchNorm bodies (the largest users): double[3*4*256] for the backward reduction, float[5][256*4] for the applies
+  __shared__ double lds_d[3 * 4 * 256];
+  float* lds_f = reinterpret_cast<float*>(lds_d);
+  for (int k = 0; k < n; ++k) {
+    const SmallEntry& e = entries[k];
+    const int gx = e.gx, gy = e.gy, gz = e.gz;
+    for (int bz = 0; bz < gz; ++bz)
+      for (int by = 0; by < gy; ++by)
+        for (int bx = 0; bx < gx; ++bx) {
+          small_block(e, bx, by, bz, lds_d, lds_f);
+          __syncthreads();                 // the bodies reuse their LDS
+        }
+    // the next member reads what this one wrote (global stores, fp32 / fp64 atomics): make it visible to the whole
+    // workgroup — barrier, then an agent-scope fence (release of our stores, invalidation of this CU's L1 lines)
+    __threadfence();
+    __syncthreads();
+    __threadfence();
+  }
+}
+
 }  // namespace
 
 // one launch for two independent BatchNorm-family ops of the same opcode and vector width
@@ -1089,11 +1304,12 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       hipLaunchKernelGGL(concat_kernel, dim3(blocks_for((int64_t)a.B * a.ldo)), dim3(256), 0, s, a);
       break;
     }
-    case HP_OP_EMB_BWD:
-      hipLaunchKernelGGL(emb_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1])), dim3(256), 0, s,
-                         ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases),
-                         I[0], I[1], I[2], I[3], I[4]);
+    case HP_OP_EMB_BWD: {
+      SmallEntry e;
+      small_entry(op, bases, e);
+      hipLaunchKernelGGL(emb_bwd_kernel, dim3(e.gx), dim3(256), 0, s, e.a.emb);
       break;
+    }
     case HP_OP_LINEAR_FWD: {
       LinArgs a{};
       a.X = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.Bv = ptr<const float>(op, 2, bases);
@@ -1129,20 +1345,24 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(256), 0, s, a, rows_per_z);
       break;
     }
-    case HP_OP_REPARAM_KL_FWD:
-      hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1])), dim3(256), 0, s,
-                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases),
-                         ptr<double>(op, 3, bases), I[0], I[1]);
+    case HP_OP_REPARAM_KL_FWD: {
+      SmallEntry e;
+      small_entry(op, bases, e);
+      hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(e.gx), dim3(256), 0, s, e.a.rp);
       break;
-    case HP_OP_REPARAM_KL_BWD:
-      hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1])), dim3(256), 0, s,
-                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<const float>(op, 2, bases),
-                         ptr<float>(op, 3, bases), I[0], I[1], I[2], op.f[0]);
+    }
+    case HP_OP_REPARAM_KL_BWD: {
+      SmallEntry e;
+      small_entry(op, bases, e);
+      hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(e.gx), dim3(256), 0, s, e.a.rp);
       break;
-    case HP_OP_MSE_FWD_BWD:
-      hipLaunchKernelGGL(mse_kernel, dim3(blocks_for(I[0])), dim3(256), 0, s, ptr<const float>(op, 0, bases),
-                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<double>(op, 3, bases), I[0], I[1], op.f[0]);
+    }
+    case HP_OP_MSE_FWD_BWD: {
+      SmallEntry e;
+      small_entry(op, bases, e);
+      hipLaunchKernelGGL(mse_kernel, dim3(e.gx), dim3(256), 0, s, e.a.mse);
       break;
+    }
     case HP_OP_TAIL_FWD:
       hipLaunchKernelGGL(tail_fwd_kernel, dim3(blocks_for((int64_t)I[0] * 2 * I[1], 4)), dim3(256), 0, s,
                          ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<const float>(op, 2, bases),
@@ -1159,10 +1379,12 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
                          ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], 0);
       break;
     }
-    case HP_OP_LOSS_FINALIZE:
-      hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, ptr<const double>(op, 0, bases),
-                         ptr<float>(op, 1, bases), I[0], I[1], I[2], op.f[0], op.f[1], op.f[2]);
+    case HP_OP_LOSS_FINALIZE: {
+      SmallEntry e;
+      small_entry(op, bases, e);
+      hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, s, e.a.loss);
       break;
+    }
     case HP_OP_GRADNORM:
       hipLaunchKernelGGL(gradnorm_kernel, dim3(min(256, max(1, blocks_for(I[0] >> 2)))), dim3(256), 0, s,
                          ptr<const float>(op, 0, bases), ptr<double>(op, 1, bases), I[0]);
@@ -1214,5 +1436,27 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     default:
       return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+
+// ---- HP chained launch: host side ---------------------------------------------------------------------------------
+bool hp::chainable(const HpOp& op) {
+  SmallEntry e;
+  void* const zero_bases[HP_NUM_SPACES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  return small_entry(op, zero_bases, e);
+}
+
+hipError_t hp::build_chain(const HpOp* members, int count, void* const* bases, void** d_entries) {
+  std::vector<SmallEntry> entries(count);
+  for (int j = 0; j < count; ++j)
+    if (!small_entry(members[j], bases, entries[j])) return hipErrorInvalidValue;
+  hipError_t e = hipMalloc(d_entries, entries.size() * sizeof(SmallEntry));
+  if (e != hipSuccess) return e;
+  return hipMemcpy(*d_entries, entries.data(), entries.size() * sizeof(SmallEntry), hipMemcpyHostToDevice);
+}
+
+hipError_t hp::launch_chain(const void* d_entries, int count, hipStream_t s) {
+  hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
   return hipGetLastError();
 }

@@ -13,8 +13,8 @@ struct HpProgram {
   std::vector<hipGraphExec_t> segs;
   std::vector<hipGraph_t> graphs;
   hipStream_t capture_stream = nullptr;
-  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; };
-  std::vector<Group> groups;          // indexed by op index (empty entries for non-group ops)
+  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; void* chain = nullptr; int chain_len = 0; };
+  std::vector<Group> groups;          // indexed by op index (empty entries for ops without device tables)
   bool groups_ready = false;
 };
 
@@ -36,6 +36,14 @@ int ensure_groups(HpProgram* p) {
   p->groups.assign(p->ops.size(), HpProgram::Group());
   for (size_t k = 0; k < p->ops.size(); ++k) {
     const HpOp& op = p->ops[k];
+    const int nchain = (op.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK;
+    if (nchain > 0) {
+      HpProgram::Group& g = p->groups[k];
+      g.chain_len = nchain + 1;
+      hipError_t e = hp::build_chain(&p->ops[k - nchain], nchain + 1, p->bases, &g.chain);
+      if (e != hipSuccess) return fail_hip("building chain table", e);
+      continue;
+    }
     if (op.op != HP_OP_WGRAD_GROUP) continue;
     HpProgram::Group& g = p->groups[k];
     g.ntaps = op.i[2];
@@ -56,7 +64,11 @@ hipError_t dispatch(const HpOp& op, void* const* bases, hipStream_t s) {
 
 hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
   const HpOp& op = p->ops[k];
-  if (op.flags & HP_FLAG_MEMBER) return hipSuccess;            // done by its group launch
+  if (op.flags & HP_FLAG_MEMBER) return hipSuccess;            // done by its group / pair / chain launch
+  if ((op.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK) {
+    const HpProgram::Group& g = p->groups[k];
+    return hp::launch_chain(g.chain, g.chain_len, s);
+  }
   if (op.op == HP_OP_WGRAD_GROUP) {
     const HpProgram::Group& g = p->groups[k];
     return hp::launch_wgrad_group(g.ntaps, g.probs, g.blocks, g.nblocks, s);
@@ -300,7 +312,7 @@ int hp_program_destroy(HpProgram* p) {
   if (!p) return 0;
   for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
   for (auto g : p->graphs) if (g) hipGraphDestroy(g);
-  for (auto& g : p->groups) { if (g.probs) hipFree(g.probs); if (g.blocks) hipFree(g.blocks); }
+  for (auto& g : p->groups) { if (g.probs) hipFree(g.probs); if (g.blocks) hipFree(g.blocks); if (g.chain) hipFree(g.chain); }
   if (p->capture_stream) hipStreamDestroy(p->capture_stream);
   delete p;
   return 0;
@@ -322,6 +334,17 @@ int hp_program_validate(const HpProgram* p) {
                             ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
                              (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
       if (!kind_ok) return fail("pair op " + std::to_string(k) + ": members are not two pairable ops of one kind");
+    }
+    const int nchain = (p->ops[k].flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK;
+    if (nchain > 0) {
+      if (nchain >= HP_CHAIN_MAX || (int)k - nchain < 0 || (p->ops[k].flags & HP_FLAG_MEMBER))
+        return fail("chain ending at op " + std::to_string(k) + ": bad length");
+      for (int j = (int)k - nchain; j <= (int)k; ++j) {
+        const HpOp& m = p->ops[j];
+        if ((j < (int)k && !(m.flags & HP_FLAG_MEMBER)) || !hp::chainable(m) ||
+            (j < (int)k && ((m.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK)))
+          return fail("chain ending at op " + std::to_string(k) + ": member " + std::to_string(j) + " is not a chainable member record");
+      }
     }
     if (p->ops[k].op == HP_OP_WGRAD_GROUP) {
       const HpOp& g = p->ops[k];

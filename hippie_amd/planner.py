@@ -54,6 +54,11 @@ class TrainCfg:
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
     fold_eval_bn: bool = True           # eval forward: BatchNorm (+residual, +leaky_relu) folded into the producing conv's epilogue
+    chain_small: bool = False           # runs of consecutive small ops (the heads' Linear / BatchNorm / concat / reparameterisation /
+                                        # loss ops) execute as ONE launch of one workgroup (HP_FLAG_CHAIN_SHIFT).  Correct (tests) and
+                                        # 174 -> 146 launches per model-step, but MEASURED SLOWER at batch 512 (46.9 k vs 104 k samples/s):
+                                        # one 256-thread workgroup serialises ~350 virtual blocks of dependent L2 round trips that the
+                                        # stand-alone launches spread over 40 CUs each.  Off by default; DESIGN.md section 8.
     fuse_bn: bool = True                # training: a block's inner BatchNorm + leaky_relu is evaluated in its consumers' operand
                                         # loaders (HP_CONV_IN_BN: the activation tensor is never written) and the BatchNorm-backward
                                         # reduction runs in the epilogue of the input-gradient conv that produces its operand
@@ -975,15 +980,16 @@ class Lowering:
             # ---------------- optimiser ----------------
             self.o.begin("opt")
             n = pl.n_active
+            t = self.train
+            if t.optimizer == "adamw":
+                self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="adam step += 1")       # (first: chains with the ZERO below)
             if self.train.clip > 0:
                 # the accumulator is zeroed HERE (not only by the forward's statistics memset): optimizer.step() may
                 # run more than once per forward (a closure, a second step()) and must not double-count the norm
                 self.o.add(P.ZERO, 0, i=[8, 0], buf=[norm2], note="zero the gradient-norm accumulator")
                 self.o.add(P.GRADNORM, 0, i=[n], buf=[Ref(P.GRAD, 0), norm2], note="clip_grad_norm: total norm")
-            t = self.train
             arenas = [Ref(P.PARAM, 0), Ref(P.GRAD, 0), Ref(P.ADAM_M, 0), Ref(P.ADAM_V, 0)]
             if t.optimizer == "adamw":
-                self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="adam step += 1")
                 self.o.add(P.ADAMW, 0, i=[n], f=[t.lr, t.beta1, t.beta2, t.adam_eps, t.weight_decay, t.clip, 1.0 - t.beta1, 1.0 - t.beta2],
                            buf=arenas + [self.step_ref, norm2], note="AdamW")
             elif t.optimizer == "schedulefree":
@@ -1007,6 +1013,10 @@ class Lowering:
         for key in ("train_zero", "eval_zero"):
             self.o.recs[segs[key]]["i"][0] = used
             self.o.recs[segs[key]]["i"][1] = 0
+        if self.train.chain_small and self.train.sync_bn_world <= 1:
+            f_eval = self.o.segments["fwd_eval"][0]
+            enc_eval_end = f_eval + self.o.segments["enc_eval"][1]
+            apply_chains(self.o, ("fwd_train", "bwd_a", "bwd_b", "opt", "fwd_eval"), breaks={enc_eval_end})
         slab = pl.ws(4 * max(pl.slab_need, 4))
         for r in self.o.recs:
             if int(r["op"]) == P.WGRAD_TAPS and not (int(r["flags"]) & 1):
@@ -1014,6 +1024,71 @@ class Lowering:
             elif int(r["op"]) == P.SLAB_REDUCE:
                 r["buf"][0] = slab.encode()
         return pl
+
+
+CHAIN_WORK_MAX = 700_000        # per-op work (FMA-equivalents) one 256-thread workgroup may take on inside a chained launch
+
+
+def chain_work(r):
+    """Cost estimate of one record if it is chainable (the C side has the authoritative list: hp::chainable), else None."""
+    op, I = int(r["op"]), r["i"]
+    if op in (P.LINEAR_FWD, P.LINEAR_BWD_X, P.LINEAR_BWD_W):
+        M, N, K = int(I[0]), int(I[1]), int(I[2])
+        if op == P.LINEAR_FWD and K >= 128:
+            return None
+        if op == P.LINEAR_BWD_X and N >= 128 and M * K <= (1 << 20):
+            return None
+        return M * N * K
+    if op in (P.BN_APPLY, P.BN_BWD_REDUCE, P.BN_BWD_APPLY):
+        return int(I[0]) * int(I[1]) * 8
+    if op == P.CONCAT:
+        return int(I[0]) * int(I[2]) * 2
+    if op == P.EMB_BWD:
+        return int(I[0]) * int(I[1]) * 2
+    if op in (P.REPARAM_KL_FWD, P.REPARAM_KL_BWD):
+        return int(I[0]) * int(I[1]) * 30
+    if op == P.MSE_FWD_BWD:
+        return int(I[0]) * 6
+    if op in (P.LOSS_FINALIZE, P.STEP_INC):
+        return 1
+    if op == P.ZERO:
+        nbytes = int(I[0]) + (int(I[1]) << 32)
+        return nbytes // 4 if nbytes % 16 == 0 or True else None
+    return None
+
+
+def apply_chains(oplist, segments, breaks=()):
+    """Mark maximal runs (length >= 2) of consecutive chainable records inside each named segment: all but the last
+    become members, the last carries the run length (HP_FLAG_CHAIN_SHIFT).  No record moves, so indices held by PAIR /
+    WGRAD_GROUP records and segment bounds stay valid.  A run never crosses an index in `breaks` (segment aliases that
+    end inside a segment)."""
+    recs = oplist.recs
+    for seg in segments:
+        if seg not in oplist.segments:
+            continue
+        first, count = oplist.segments[seg]
+        run = []
+
+        def flush():
+            if len(run) >= 2:
+                for k in run[:-1]:
+                    recs[k]["flags"] = int(recs[k]["flags"]) | P.FLAG_MEMBER
+                    oplist.notes[k] += " [chained]"
+                recs[run[-1]]["flags"] = int(recs[run[-1]]["flags"]) | ((len(run) - 1) << P.FLAG_CHAIN_SHIFT)
+                oplist.notes[run[-1]] += f" [chain of {len(run)}]"
+            run.clear()
+
+        for k in range(first, first + count):
+            r = recs[k]
+            w = chain_work(r)
+            ok = w is not None and w <= CHAIN_WORK_MAX and not (int(r["flags"]) & P.FLAG_MEMBER)
+            if k in breaks or len(run) >= P.CHAIN_MAX - 1:
+                flush()
+            if ok:
+                run.append(k)
+            else:
+                flush()
+        flush()
 
 
 def lower(cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, **kw) -> Plan:

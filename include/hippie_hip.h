@@ -69,6 +69,14 @@ static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 10
 /* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op: the program executor skips it
  * (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
 #define HP_FLAG_MEMBER 0x200
+/* Chained launch: bits 16..23 of `flags` of a record = number n of IMMEDIATELY PRECEDING records (all flagged
+ * HP_FLAG_MEMBER) that, together with this record, are executed in program order by ONE launch of one workgroup
+ * (n + 1 small ops: the Linear / BatchNorm / concat / reparameterisation / loss ops of the cVAE heads, each a few
+ * thousand FMAs, i.e. pure launch latency).  Arithmetic per op is unchanged (the members' own kernel bodies run);
+ * hp_run_op and the reference interpreter ignore the field and execute each record on its own. */
+#define HP_FLAG_CHAIN_SHIFT 16
+#define HP_FLAG_CHAIN_MASK 0xFF
+#define HP_CHAIN_MAX 64
 
 /* One op record (POD, 8-byte aligned; numpy dtype mirror in hippie_amd/program.py). */
 typedef struct HpOp {

@@ -282,9 +282,10 @@ def test_trainer_async_path_equals_per_step_sync_path(tmp_path):
     (h0, sd0, t0, v0), (h1, sd1, t1, v1) = res
     assert len(h0) == len(h1) == 2
     for a, b in zip(h0, h1):
-        np.testing.assert_allclose(a["val_loss"], b["val_loss"], rtol=2e-5)
-        np.testing.assert_allclose(a["train_loss"], b["train_loss"], rtol=2e-5)
-    np.testing.assert_allclose([t0, v0], [t1, v1], rtol=2e-5)
+        # (two runs differ in the order of their atomic sums; over 6 Adam steps that grows to a few 1e-5 of the loss)
+        np.testing.assert_allclose(a["val_loss"], b["val_loss"], rtol=1e-4)
+        np.testing.assert_allclose(a["train_loss"], b["train_loss"], rtol=1e-4)
+    np.testing.assert_allclose([t0, v0], [t1, v1], rtol=1e-4)
     import re
     for k in sd0:
         if sd0[k].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, k):

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '_')
-  timeout -k 10 280 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc_$tag.log 2>&1
+  timeout -k 10 280 rocprofv3 --pmc $c --output-format csv -d $R/gpurun_out/pmc_$tag -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-trainer --no-profile > $R/gpurun_out/pmc_$tag.log 2>&1
   echo "pass $tag done: $(ls $R/gpurun_out/pmc_$tag | head -3 | tr '\n' ' ')"
 done
 cd $R
