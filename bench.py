@@ -39,6 +39,7 @@ from hippie_amd.engine import Engine                   # noqa: E402
 
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_conv_pmc.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_TFLOPS = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0}     # bf16: ~2.5 PFLOP/s dense (v_mfma_f32_32x32x16_bf16)
 N_UNITS = 15631                   # cellexplorer-celltype pretrain pool, 80 % split
 BATCH = 512
 Z_DIM = 10
@@ -67,11 +68,11 @@ class Pair:
     (the GPU overlaps the two models' kernels).  --pair: ONE zipped program (hippie_amd.pair.PairEngine:
     every heavy op of the two models in one launch) on one stream."""
 
-    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False, lockstep=False, fuse_bn=True):
+    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False, lockstep=False, fuse_bn=True, mfma_dtype="f32"):
         self.device, self.world, self.paired, self.overlap, self.lockstep = device, world, paired, overlap, lockstep
         cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
-        tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, split_backward=overlap, fuse_bn=fuse_bn),
-               planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, split_backward=overlap, fuse_bn=fuse_bn)]
+        tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype),
+               planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype)]
         if paired:
             from hippie_amd.pair import PairEngine
             self.pe = PairEngine(cfgs[0], cfgs[1], BATCH, tcs[0], tcs[1], device=device)
@@ -401,6 +402,9 @@ def main():
     ap.add_argument("--overlap", action="store_true", help="decoder-side wgrad + first gradient bucket on a side stream (measured slower on ROCm 7: DESIGN.md 5.3)")
     ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 (default, the headline: the reference's arithmetic) | bf16: BASELINE config 2's reduced-precision mode "
+                         "(bf16 MFMA operands, fp32 accumulation / statistics / master weights): a separately labelled line, never the headline")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: one launch per BatchNorm pass instead of the fused loaders / epilogues")
     # non-default shapes (BASELINE configs[2]: --batch 4096 --z-dim 32 --wave-len 256 --time-len 32); the headline
     # metric is always quoted on the defaults
@@ -448,7 +452,7 @@ def main():
     dist_backend = dist.get_backend() if (world > 1 or force_dist) else None
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
     pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len), overlap=args.overlap, lockstep=args.lockstep,
-                fuse_bn=not args.no_fuse_bn)
+                fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype)
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -513,16 +517,17 @@ def main():
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": ("REDUCED-PRECISION MODE (bf16 MFMA operands, fp32 accumulate; NOT the headline; tolerance: tests/test_gpu_bf16.py) — " if args.dtype == "bf16" else "") +
+                                   ("BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
                                     "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "
                                     "fp32 arithmetic on f32 MFMA (the reference's arithmetic type; the config's bf16 wording is a separate, labelled mode)")
                        if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
                        f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
                        "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired, "lockstep": pair.lockstep,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "conv_taps_kernel + conv_taps_pair_kernel (same body: forward conv and input-gradient, f32 MFMA 32x32x2; "
                                    "BatchNorm input transform in the loader / BatchNorm-backward reduction in the epilogue where fused)",
                          "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
@@ -530,8 +535,8 @@ def main():
                          "algorithmic_gflop_per_step": conv_flop / 1e9,
                          # north_star's ">= 40 % MFMA utilisation on the encoder forward": encoder forward convs' FLOPs over (a) those
                          # launches' time, (b) the whole encoder-forward phase incl. its BatchNorm / stem / pool launches
-                         "encoder_forward": {"conv_tflops": sm["enc_fwd_tflops"], "conv_frac": sm["enc_fwd_tflops"] / PEAK_F32_MFMA_TFLOPS,
-                                             "phase_tflops": sm["enc_fwd_phase_tflops"], "phase_frac": sm["enc_fwd_phase_tflops"] / PEAK_F32_MFMA_TFLOPS},
+                         "encoder_forward": {"conv_tflops": sm["enc_fwd_tflops"], "conv_frac": sm["enc_fwd_tflops"] / PEAK_TFLOPS[args.dtype],
+                                             "phase_tflops": sm["enc_fwd_phase_tflops"], "phase_frac": sm["enc_fwd_phase_tflops"] / PEAK_TFLOPS[args.dtype]},
                          "wgrad_group_kernel": sm["wgrad"],
                          # achieved HBM GB/s (algorithmic bytes / HIP-event time) of the bandwidth- and latency-bound kernels
                          "hbm_gbps": sm["hbm"],
@@ -540,8 +545,8 @@ def main():
                          "whole_step_tflops_per_gpu": BATCH * args.steps / dt * 3.0 * sum(e.plan.flops_fwd for e in pair.eng) / BATCH / 1e12},
         }
         if world == 1 and not args.no_trainer and not args.pair:
-            tr = trainer_rate(device, data)
-            out["trainer_samples_per_s"] = tr["value"]
+            tr = trainer_rate(device, data) if args.dtype == "f32" else None
+            out["trainer_samples_per_s"] = tr["value"] if tr else None
             out["trainer_path"] = tr
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline()

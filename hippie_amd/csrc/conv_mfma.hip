@@ -14,6 +14,31 @@
 #include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// HP_CONV_BF16: operands rounded to bfloat16 on their way into LDS, products on v_mfma_f32_32x32x16_bf16, fp32 accumulation
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int kLdaH = 40;    // bf16 [row][32 k] image: 80-byte rows, conflict-free ds_read_b128 of 16 rows
+constexpr int kLdtH = 96;    // bf16 [32 rows][64 cols] image read with ds_read_b64_tr_b16: 192-byte rows (4 rows x 2 groups hit 64 distinct banks)
+
+__device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
+  bf16x4 r;
+  r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;      // round to nearest even (v_cvt_pk_bf16_f32)
+  return r;
+}
+// MFMA 32x32x16 operand whose 8 contraction values per lane are ROWS of a [rows][cols] bf16 image (the operand is the image's
+// transpose): two hardware transpose reads.  Lane l = 16g + 4q + p supplies the address of row (r0 + q), columns
+// c0 + 16*(g&1) + 4p .. +3 and receives, for its column c0 + (l & 31), rows r0 + 8*(l>>5) + 0..3 (second read: + 4..7).
+// EXEC must be all ones.
+__device__ __forceinline__ bf16x8 tr_operand(const __bf16* img, int ld, int r0, int c0, int lane) {
+  const int g = lane >> 4, q = (lane >> 2) & 3, pq = lane & 3;
+  const __bf16* a0 = img + (r0 + 8 * (g >> 1) + q) * ld + c0 + 16 * (g & 1) + 4 * pq;
+  const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0));
+  const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(a0 + 4 * ld));
+  union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
+  u.s.lo = t0; u.s.hi = t1;
+  return u.v;
+}
 
 struct TapMap {
   int M, N, K, Lout, Lin, P, a, sh, ntaps;
@@ -83,7 +108,7 @@ constexpr int kConvThreads = 512;
 // sit on the same SIMD pair-wise, so one wave's global loads / LDS traffic / address arithmetic overlap
 // the other's MFMAs — at batch 512 a layer has only ~256 tiles for 1024 SIMDs, so this is the only way to
 // get two waves per SIMD.  Their partial accumulators are summed once, through LDS, in the epilogue.
-template <bool W_KN, bool IN_BN>
+template <bool W_KN, bool IN_BN, bool BF16 = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
   constexpr int LDBK = 68;   // [k][n] image row stride
@@ -173,6 +198,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
         r.a.w = lrelu(fmaf(r.a.w, sc.w, sh.w), in_slope) * r.va;
       }
     }
+    if (BF16) {
+      __bf16* Ah = reinterpret_cast<__bf16*>(As);
+      __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
+      *reinterpret_cast<bf16x4*>(Ah + ar * kLdaH + aq) = to_bf16x4(r.a);
+      if (!W_KN) *reinterpret_cast<bf16x4*>(Bh + ar * kLdaH + aq) = to_bf16x4(r.b);
+      else       *reinterpret_cast<bf16x4*>(Bh + kr * kLdtH + nq) = to_bf16x4(r.b);
+      return;
+    }
     *reinterpret_cast<float4*>(As + ar * LDA + aq) = r.a;
     if (!W_KN) *reinterpret_cast<float4*>(Bs + ar * LDA + aq) = r.b;
     else       *reinterpret_cast<float4*>(Bs + kr * LDBK + nq) = r.b;
@@ -192,6 +225,26 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   // MFMA jj pairs element jj of both operands — a K permutation applied identically to A and B.
   // FETCH / STASH are compile-time: the steady-state loop has no conditions, so the compiler's vmcnt
   // bookkeeping stays exact (a merged "maybe pending" path costs a full drain).
+  // bf16 K-step: the wave's half (16 k) of the 32-wide slice is ONE v_mfma_f32_32x32x16_bf16
+#define HP_KSTEP_H(BUF, ST, LD, FETCH, STASH)                                                           \
+  {                                                                                                     \
+    const __bf16* Ah = reinterpret_cast<const __bf16*>(smem + (BUF) * TILE);                            \
+    const __bf16* Bh = reinterpret_cast<const __bf16*>(smem + 2 * TILE + (BUF) * TILE);                 \
+    const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ah + (wm * 32 + li) * kLdaH + kh * 16 + lh * 8); \
+    bf16x8 bf;                                                                                          \
+    if (!W_KN) bf = *reinterpret_cast<const bf16x8*>(Bh + (wn * 32 + li) * kLdaH + kh * 16 + lh * 8);   \
+    else       bf = tr_operand(Bh, kLdtH, kh * 16, wn * 32, lane);                                      \
+    if (FETCH) {                                                                                        \
+      LD.a = *reinterpret_cast<const float4*>(pa);                                                      \
+      LD.b = *reinterpret_cast<const float4*>(pb);                                                      \
+      if (IN_BN) { LD.kq = kc * 32 + aq; LD.va = ia ? 1.f : 0.f; }                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+      advance();                                                                                        \
+    }                                                                                                   \
+    if (STASH) { stash((BUF) ^ 1, ST); }                                                                \
+    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc2[0], 0, 0, 0);                        \
+    __syncthreads();                                                                                    \
+  }
 #define HP_KSTEP(BUF, ST, LD, FETCH, STASH)                                                             \
   {                                                                                                     \
     const float* As = smem + (BUF) * TILE + (wm * 32 + li) * LDA + lh * 4 + kh * 16;                    \
@@ -244,6 +297,23 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   Pref setB = setA;
   __syncthreads();
   int s = 0;
+  if (BF16) {
+    for (; s + 3 < nsteps; s += 2) {
+      HP_KSTEP_H(0, setA, setB, true, true)
+      HP_KSTEP_H(1, setB, setA, true, true)
+    }
+    const int remh = nsteps - s;
+    if (remh == 3) {
+      HP_KSTEP_H(0, setA, setB, true, true)
+      HP_KSTEP_H(1, setB, setA, false, true)
+      HP_KSTEP_H(0, setA, setB, false, false)
+    } else if (remh == 2) {
+      HP_KSTEP_H(0, setA, setB, false, true)
+      HP_KSTEP_H(1, setB, setA, false, false)
+    } else {
+      HP_KSTEP_H(0, setA, setB, false, false)
+    }
+  } else {
   for (; s + 3 < nsteps; s += 2) {           // steady state: both steps fetch and stash
     HP_KSTEP(0, setA, setB, true, true)
     HP_KSTEP(1, setB, setA, true, true)
@@ -259,7 +329,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   } else {
     HP_KSTEP(0, setA, setB, false, false)
   }
+  }
 #undef HP_KSTEP
+#undef HP_KSTEP_H
 
   // sum the two K-halves through LDS (the staging buffers are free after the last barrier)
   f32x16 acc;
@@ -388,20 +460,20 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   }
 }
 
-template <bool W_KN, bool IN_BN>
+template <bool W_KN, bool IN_BN, bool BF16 = false>
 __global__ __launch_bounds__(kConvThreads) void conv_taps_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[kConvLds + (IN_BN ? kConvCoef : 0)];
-  conv_body<W_KN, IN_BN>(p, blockIdx.x, smem);
+  conv_body<W_KN, IN_BN, BF16>(p, blockIdx.x, smem);
 }
 
 // HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, a block's conv1
 // and its shortcut, or the even / odd output phases of a stride-2 input-gradient) in ONE launch: twice the
 // workgroups per launch at batch 512, where a single layer only fills each CU with one workgroup.
-template <bool W_KN, bool IN_BN>
+template <bool W_KN, bool IN_BN, bool BF16 = false>
 __global__ __launch_bounds__(kConvThreads) void conv_taps_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
   __shared__ __attribute__((aligned(16))) float smem[kConvLds + (IN_BN ? kConvCoef : 0)];
-  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, IN_BN>(a, blockIdx.x, smem);
-  else conv_body<W_KN, IN_BN>(b, blockIdx.x - nblk_a, smem);
+  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, IN_BN, BF16>(a, blockIdx.x, smem);
+  else conv_body<W_KN, IN_BN, BF16>(b, blockIdx.x - nblk_a, smem);
 }
 
 static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
@@ -446,6 +518,12 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
   const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
   const bool kn = opa.flags & 1, inbn = (opa.flags | opb.flags) & HP_CONV_IN_BN;
   const dim3 g(na + nb), th(kConvThreads);
+  if ((opa.flags & HP_CONV_BF16) != (opb.flags & HP_CONV_BF16)) return hipErrorInvalidValue;
+  if (opa.flags & HP_CONV_BF16) {         // bf16 mode: always the IN_BN-capable instantiation (the flag is checked at run time)
+    if (kn) hipLaunchKernelGGL((conv_taps_pair_kernel<true, true, true>), g, th, 0, s, a, b, na);
+    else    hipLaunchKernelGGL((conv_taps_pair_kernel<false, true, true>), g, th, 0, s, a, b, na);
+    return hipGetLastError();
+  }
   if (kn && inbn)       hipLaunchKernelGGL((conv_taps_pair_kernel<true, true>), g, th, 0, s, a, b, na);
   else if (kn)          hipLaunchKernelGGL((conv_taps_pair_kernel<true, false>), g, th, 0, s, a, b, na);
   else if (inbn)        hipLaunchKernelGGL((conv_taps_pair_kernel<false, true>), g, th, 0, s, a, b, na);
@@ -457,6 +535,11 @@ hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t 
   const ConvArgs a = conv_args_from(op, bases);
   const dim3 g(hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64)), th(kConvThreads);
   const bool kn = op.flags & 1, inbn = op.flags & HP_CONV_IN_BN;
+  if (op.flags & HP_CONV_BF16) {
+    if (kn) hipLaunchKernelGGL((conv_taps_kernel<true, true, true>), g, th, 0, s, a);
+    else    hipLaunchKernelGGL((conv_taps_kernel<false, true, true>), g, th, 0, s, a);
+    return hipGetLastError();
+  }
   if (kn && inbn)       hipLaunchKernelGGL((conv_taps_kernel<true, true>), g, th, 0, s, a);
   else if (kn)          hipLaunchKernelGGL((conv_taps_kernel<true, false>), g, th, 0, s, a);
   else if (inbn)        hipLaunchKernelGGL((conv_taps_kernel<false, true>), g, th, 0, s, a);
@@ -486,7 +569,7 @@ __device__ __forceinline__ float4 gload4(const float* p) {
   return make_float4(v.x, v.y, v.z, v.w);
 }
 
-template <int NT>
+template <int NT, bool BF16 = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, const int split, float* smem) {
   constexpr int T = 32 * 64;   // one [32 rows][64 cols] image
   const TapMap& t = p.t;
@@ -546,7 +629,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
   auto store_lds = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      *reinterpret_cast<float4*>(smem + (lr + 16 * j) * 64 + cq) = rdy[j];
+      if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(smem) + (lr + 16 * j) * kLdtH + cq) = to_bf16x4(rdy[j]);
+      else *reinterpret_cast<float4*>(smem + (lr + 16 * j) * 64 + cq) = rdy[j];
 #pragma unroll
       for (int tau = 0; tau < NT; ++tau) {
         float4 v = rx[tau][j];
@@ -558,7 +642,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
           v.x = lrelu(fmaf(v.x, xsc.x, xsh.x), xslope) * keep; v.y = lrelu(fmaf(v.y, xsc.y, xsh.y), xslope) * keep;
           v.z = lrelu(fmaf(v.z, xsc.z, xsh.z), xslope) * keep; v.w = lrelu(fmaf(v.w, xsc.w, xsh.w), xslope) * keep;
         }
-        *reinterpret_cast<float4*>(smem + (1 + tau) * T + (lr + 16 * j) * 64 + cq) = v;
+        if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(smem + (1 + tau) * T) + (lr + 16 * j) * kLdtH + cq) = to_bf16x4(v);
+        else *reinterpret_cast<float4*>(smem + (1 + tau) * T + (lr + 16 * j) * 64 + cq) = v;
       }
     }
   };
@@ -576,6 +661,25 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
     for (int mb = mbeg; mb < mend; mb += 32) {
       const bool more = mb + 32 < mend;
       if (more) load_regs(mb + 32);
+      if (BF16) {
+        // both operands are TRANSPOSES of the row-major [32 rows m][64 columns] bf16 images: hardware transpose reads,
+        // two v_mfma_f32_32x32x16_bf16 per tap and slice
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          const bf16x8 af = tr_operand(reinterpret_cast<const __bf16*>(smem), kLdtH, st * 16, wn * 32, lane);
+#pragma unroll
+          for (int tau = 0; tau < NT; ++tau) {
+            const bf16x8 bf = tr_operand(reinterpret_cast<const __bf16*>(smem + (1 + tau) * T), kLdtH, st * 16, wc * 32, lane);
+            acc[tau] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[tau], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+        if (more) {
+          store_lds();
+          __syncthreads();
+        }
+        continue;
+      }
       const float* dys = smem + lh * 64 + wn * 32 + li;
       const float* xs = smem + T + lh * 64 + wc * 32 + li;
       // all operand reads of the slice go out before the MFMA block (distinct registers), so the
@@ -619,16 +723,16 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
   }
 }
 
-template <int NT>
+template <int NT, bool BF16 = false>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64];
-  wgrad_body<NT>(p, blockIdx.x, blockIdx.y, smem);
+  wgrad_body<NT, BF16>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // Grouped form: ONE launch runs every weight-gradient GEMM of a backward pass.  They are independent
 // leaves whose inputs persist, so their tiles fill the chip together (no per-layer tail, fewer K-splits
 // and atomics, one launch instead of ~38).  blocks[b] = (problem, tile, split, -).
-template <int NT>
+template <int NT, bool BF16 = false>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __restrict__ probs, const int4* __restrict__ blocks) {
   __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64];
   const int4 bi = blocks[blockIdx.x];
@@ -638,7 +742,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __res
   // by value: one scalar load of the problem record up front.  Through a reference into global memory the
   // compiler re-loads the fields (s_load + wait) inside every guarded load of the slice loop.
   const WgradArgs p = probs[pj];
-  wgrad_body<NT>(p, tile, split, smem);
+  wgrad_body<NT, BF16>(p, tile, split, smem);
 }
 
 static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {
@@ -682,11 +786,14 @@ hipError_t hp::build_wgrad_group(const HpOp* members, int count, void* const* ba
   return e;
 }
 
-hipError_t hp::launch_wgrad_group(int ntaps, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s) {
-  if (ntaps == 1)
-    hipLaunchKernelGGL(wgrad_group_kernel<1>, dim3(nblocks), dim3(256), 0, s, (const WgradArgs*)d_probs, (const int4*)d_blocks);
-  else if (ntaps == 3)
-    hipLaunchKernelGGL(wgrad_group_kernel<3>, dim3(nblocks), dim3(256), 0, s, (const WgradArgs*)d_probs, (const int4*)d_blocks);
+hipError_t hp::launch_wgrad_group(int ntaps, bool bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s) {
+  const dim3 g(nblocks), th(256);
+  const WgradArgs* pr = (const WgradArgs*)d_probs;
+  const int4* bl = (const int4*)d_blocks;
+  if (ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_group_kernel<1, false>), g, th, 0, s, pr, bl);
+  else if (ntaps == 1)          hipLaunchKernelGGL((wgrad_group_kernel<1, true>), g, th, 0, s, pr, bl);
+  else if (ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_group_kernel<3, false>), g, th, 0, s, pr, bl);
+  else if (ntaps == 3)          hipLaunchKernelGGL((wgrad_group_kernel<3, true>), g, th, 0, s, pr, bl);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -694,8 +801,11 @@ hipError_t hp::launch_wgrad_group(int ntaps, const void* d_probs, const void* d_
 hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t s) {
   WgradArgs a = wgrad_args_from(op, bases);
   dim3 grid(hp::cdiv(a.t.N, 64) * hp::cdiv(a.t.K, 64), a.nsplit);
-  if (a.t.ntaps == 1)      hipLaunchKernelGGL(wgrad_taps_kernel<1>, grid, dim3(256), 0, s, a);
-  else if (a.t.ntaps == 3) hipLaunchKernelGGL(wgrad_taps_kernel<3>, grid, dim3(256), 0, s, a);
+  const bool bf16 = op.flags & HP_CONV_BF16;
+  if (a.t.ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_taps_kernel<1, false>), grid, dim3(256), 0, s, a);
+  else if (a.t.ntaps == 1)          hipLaunchKernelGGL((wgrad_taps_kernel<1, true>), grid, dim3(256), 0, s, a);
+  else if (a.t.ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_taps_kernel<3, false>), grid, dim3(256), 0, s, a);
+  else if (a.t.ntaps == 3)          hipLaunchKernelGGL((wgrad_taps_kernel<3, true>), grid, dim3(256), 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -25,7 +25,7 @@ hipError_t launch_small(const HpOp& op, void* const* bases, hipStream_t s);
 hipError_t launch_conv_pair(const HpOp& a, const HpOp& b, void* const* bases, hipStream_t s);
 hipError_t launch_small_pair(const HpOp& a, const HpOp& b, void* const* bases, hipStream_t s);   // BN family
 hipError_t build_wgrad_group(const HpOp* members, int count, void* const* bases, void** d_probs, void** d_blocks, int* nblocks);
-hipError_t launch_wgrad_group(int ntaps, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s);
+hipError_t launch_wgrad_group(int ntaps, bool bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s);
 // chained launch of small ops (ops_small.hip): one workgroup runs the member records in program order
 bool chainable(const HpOp& op);
 hipError_t build_chain(const HpOp* members, int count, void* const* bases, void** d_entries);

@@ -13,7 +13,7 @@ struct HpProgram {
   std::vector<hipGraphExec_t> segs;
   std::vector<hipGraph_t> graphs;
   hipStream_t capture_stream = nullptr;
-  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; void* chain = nullptr; int chain_len = 0; };
+  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; bool bf16 = false; void* chain = nullptr; int chain_len = 0; };
   std::vector<Group> groups;          // indexed by op index (empty entries for ops without device tables)
   bool groups_ready = false;
 };
@@ -47,6 +47,7 @@ int ensure_groups(HpProgram* p) {
     if (op.op != HP_OP_WGRAD_GROUP) continue;
     HpProgram::Group& g = p->groups[k];
     g.ntaps = op.i[2];
+    g.bf16 = (p->ops[op.i[0]].flags & HP_CONV_BF16) != 0;
     hipError_t e = hp::build_wgrad_group(&p->ops[op.i[0]], op.i[1], p->bases, &g.probs, &g.blocks, &g.nblocks);
     if (e != hipSuccess) return fail_hip("building wgrad group tables", e);
   }
@@ -71,7 +72,7 @@ hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
   }
   if (op.op == HP_OP_WGRAD_GROUP) {
     const HpProgram::Group& g = p->groups[k];
-    return hp::launch_wgrad_group(g.ntaps, g.probs, g.blocks, g.nblocks, s);
+    return hp::launch_wgrad_group(g.ntaps, g.bf16, g.probs, g.blocks, g.nblocks, s);
   }
   if (op.op == HP_OP_PAIR) {
     const HpOp& a = p->ops[op.i[0]];
@@ -330,7 +331,7 @@ int hp_program_validate(const HpProgram* p) {
       const HpOp& a = p->ops[g.i[0]];
       const HpOp& b = p->ops[g.i[1]];
       const bool kind_ok = a.op == b.op && (a.flags & HP_FLAG_MEMBER) && (b.flags & HP_FLAG_MEMBER) &&
-                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1)) ||
+                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & HP_CONV_BF16) == (b.flags & HP_CONV_BF16)) ||
                             ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
                              (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
       if (!kind_ok) return fail("pair op " + std::to_string(k) + ": members are not two pairable ops of one kind");
@@ -350,7 +351,8 @@ int hp_program_validate(const HpProgram* p) {
       const HpOp& g = p->ops[k];
       for (int j = g.i[0]; j < g.i[0] + g.i[1]; ++j) {
         const HpOp& m = p->ops[j];
-        if (m.op != HP_OP_WGRAD_TAPS || !(m.flags & HP_FLAG_MEMBER) || !(m.flags & 1) || m.i[9] != g.i[2])
+        if (m.op != HP_OP_WGRAD_TAPS || !(m.flags & HP_FLAG_MEMBER) || !(m.flags & 1) || m.i[9] != g.i[2] ||
+            (m.flags & HP_CONV_BF16) != (p->ops[g.i[0]].flags & HP_CONV_BF16))
           return fail("wgrad group member " + std::to_string(j) + " is not an atomic WGRAD_TAPS member with matching taps");
       }
     }

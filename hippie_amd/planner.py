@@ -66,6 +66,10 @@ class TrainCfg:
     sync_bn_world: int = 0              # > 1: sync-BatchNorm over that many data-parallel ranks (HP_OP_STATS_SYNC markers)
     split_backward: bool = False        # emit the deferred wgrad GEMMs in two groups (decoder | encoder side) so that
                                         # Engine.backward(overlap=True) can run the first under the encoder-side chain
+    mfma_dtype: str = "f32"             # "f32": the reference's arithmetic (parity path, v_mfma_f32_32x32x2_f32).  "bf16": BASELINE config 2's
+                                        # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
+                                        # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
+                                        # weights and AdamW stay fp32.  Own tolerance (tests/test_gpu_bf16.py), own bench line
     optimizer: str = "adamw"            # "adamw" (model.py:93) | "schedulefree" (hippie/optimizers.py:18-209)
     warmup_steps: int = 0               # schedule-free only
     sf_r: float = 0.0
@@ -187,6 +191,9 @@ class Lowering:
         self.pending_wgrads = []
         self.conv_rec_of = {}                # encoded OUT ref -> index of the CONV_TAPS record that produced it
         self.count_flops = False          # forward FLOPs (2*MAC, conv + linear) are counted for the training forward only
+        if self.train.mfma_dtype not in ("f32", "bf16"):
+            raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', not {self.train.mfma_dtype!r}")
+        self.mm_flag = P.CONV_BF16 if self.train.mfma_dtype == "bf16" else 0
 
     # ---- parameter declaration (own order; class_embedding last so that AdamW can skip it) ----
     def declare_encoder(self, pre):
@@ -267,6 +274,7 @@ class Lowering:
         the loader (HP_CONV_IN_BN).  epi = a reduction spec (red_spec): HP_OP_BN_BWD_REDUCE fused into the epilogue,
         `out` must be the spec's g tensor."""
         flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias is not None else 0) | (P.CONV_STATS if stats is not None else 0)
+        flags |= self.mm_flag
         ii = tm.conv_ints() + [0, 0]
         ff = [0.0] * 6
         bufs = [a, w.ref, out, bias.ref if bias is not None else None, stats] + [None] * 19
@@ -313,7 +321,7 @@ class Lowering:
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note="", coef=None):
         """coef: x is the raw input of a BatchNorm whose activation was never stored (HP_CONV_IN_BN on the forward
         conv): the kernel re-evaluates leaky_relu(fma(x, scale, shift)) from (scale, shift) = coef."""
-        xf = P.CONV_IN_BN if coef is not None else 0
+        xf = (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
         if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
             # deferred: all wgrads of the backward pass run in one grouped launch at its end.  With the
@@ -791,7 +799,7 @@ class Lowering:
                 continue
             first = len(self.o.recs)
             for (tm, nsplit, rps, dy, x, w, note, coef) in mem:
-                self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0), i=tm.ints() + [nsplit, rps, w.numel],
+                self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag, i=tm.ints() + [nsplit, rps, w.numel],
                            f=[SLOPE_BACKBONE], buf=[dy, x, w.gref, coef], note=note)
             self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
         if only_if:

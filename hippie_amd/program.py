@@ -29,7 +29,7 @@ assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
-CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED = 1, 2, 4, 8, 16, 64, 128
+CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 1, 2, 4, 8, 16, 64, 128, 256
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the chain it belongs to
 FLAG_CHAIN_SHIFT, FLAG_CHAIN_MASK, CHAIN_MAX = 16, 0xFF, 64     # chained launch: see include/hippie_hip.h
 STAT_REPL_MAX = 16       # HP_STAT_REPL_MAX

@@ -106,6 +106,10 @@ typedef struct HpOp {
 #define HP_CONV_ACT      16    /* ... followed by leaky_relu */
 #define HP_CONV_IN_BN    64    /* training-mode BatchNorm + leaky_relu of the INPUT applied in the operand loader */
 #define HP_CONV_EPI_BNRED 128  /* BatchNorm-backward reduction fused into the epilogue (input-gradient convs) */
+#define HP_CONV_BF16     256   /* CONV_TAPS / WGRAD_TAPS: both GEMM operands are rounded to bfloat16 (nearest even) when staged into
+                                * LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors in HBM, BatchNorm
+                                * statistics, epilogues and the optimiser stay fp32.  The separately labelled reduced-precision mode
+                                * of BASELINE config 2; never part of the fp32 parity path. */
 enum {
   /* out[m][n] = sum_taps sum_k A_src[row(m,tap)][k] * W_src[tap_w][..] (+bias[n]);  f32 MFMA.
    * Replaces nn.Conv1d forward (backbones.py:24,26,33,50,55), ResizeConv1d =

@@ -14,7 +14,14 @@ import numpy as np
 NULL = -1
 STAT_REPL_MAX = 16
 MASK = (1 << 56) - 1
-CONV_IN_BN, CONV_EPI_BNRED = 64, 128
+CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 64, 128, 256
+
+
+def _bf16(x):
+    """round float32 to the nearest bfloat16 (ties to even), returned as float32 — what v_cvt_pk_bf16_f32 does"""
+    u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+    r = (u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)
+    return r.view(np.float32)
 
 
 def stat_repl(C):
@@ -141,8 +148,11 @@ def run(ops, A: Arenas, first=0, count=None):
                 Xs = X[src]
                 if coefs is not None:
                     Xs = _lrelu(_fma32(Xs, coefs[0][None, :], coefs[1][None, :]), f[2])
-                Ag = np.where(ok[:, None], Xs, 0).astype(np.float64)
+                Ag = np.where(ok[:, None], Xs, 0)
                 Ws = W[w * N * K: (w + 1) * N * K]
+                if flags & CONV_BF16:
+                    Ag, Ws = _bf16(Ag), _bf16(Ws)
+                Ag = Ag.astype(np.float64)
                 Wm = Ws.reshape(K, N) if flags & 1 else Ws.reshape(N, K).T
                 acc += Ag @ Wm.astype(np.float64)
             if coefs is not None:       # the input BatchNorm's side effects (workgroup 0 of the kernel)
@@ -192,6 +202,8 @@ def run(ops, A: Arenas, first=0, count=None):
             if flags & CONV_IN_BN:
                 cf = A.f32(b[3], 2 * K)
                 X = _lrelu(_fma32(X, cf[None, :K], cf[None, K:]), f[0])
+            if flags & CONV_BF16:
+                DY, X = _bf16(DY.astype(np.float32)).astype(np.float64), _bf16(X)
             atomic = flags & 1
             slab = A.f32(b[2], stride if atomic else nsplit * stride)
             if not atomic:

@@ -1,0 +1,129 @@
+"""GPU: the bfloat16 mode (TrainCfg.mfma_dtype="bf16", HP_CONV_BF16) — BASELINE config 2's reduced-precision variant.
+Not the parity path: conv and weight-gradient operands are rounded to bfloat16 (8 significant bits) in the loaders.
+Checked (1) op by op against the interpreter on identically rounded operands (tight: only the accumulation differs),
+incl. exact layout-identity tests of the bf16 MFMA operand paths, and (2) end to end against the float64 oracle at the
+tolerance the format allows, stated here (measured values are printed): outputs within 8e-2 of the tensor's max after 40
+bfloat16 conv layers (measured 3-4e-2), loss scalars 3e-2 relative, every gradient tensor's cosine with the float64 oracle
+(on the engine's own leaky-ReLU branches) >= 0.98."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from hippie_amd import planner, program as P
+from hippie_amd.engine import Engine
+from hippie_amd.program import TapMap
+from oracle import cvae_oracle as O
+from tests import helpers as H
+from tests.test_gpu_ops import Img, run_both, check, view, R, CONV_CASES, WGRAD_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(CONV_CASES))
+def test_conv_taps_bf16(name):
+    tm, w_kn, bias = CONV_CASES[name]()
+    img = Img(61)
+    nb = tm.M // tm.Lout
+    a = img.f32(nb * tm.Lin * tm.K)
+    nslab = max(t[1] for t in tm.taps) + 1
+    w = img.f32(nslab * tm.N * tm.K, scale=0.1)
+    two = any(len(t) > 2 and t[2] for t in tm.taps)
+    a2 = img.f32(nb * tm.Lin * tm.K) if two else None
+    w2 = img.f32(nslab * tm.N * tm.K, scale=0.1) if two else None
+    out = img.f32(tm.out_rows * tm.N, scale=3.0)
+    bv = img.f32(tm.N) if bias else None
+    fl = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_BF16
+    ol = P.OpList()
+    ol.add(P.CONV_TAPS, fl, tm.conv_ints(), (), [a, w, out, bv, None, None, None, None, None, None, a2, w2])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, out, tm.out_rows * tm.N, rel=2e-5, what=name + " bf16 out")
+
+
+def test_bf16_mfma_operand_layouts_are_exact():
+    """A = I with an asymmetric, bf16-exact weight matrix: the [N][K] path (ds_read_b128 fragments) and the [K][N] path
+    (hardware transpose reads) must reproduce W bit for bit — catches swapped / transposed operand or C/D layouts."""
+    K = N = 64
+    tm = TapMap(64, N, K, 64, 64, 64, 1, 0, [(0, 0)])
+    # bfloat16 holds 8 significant bits, so a matrix with 4096 distinct exact entries does not exist: two matrices, one
+    # that depends on the row only and one on the column only (values 0..63 are exact), pin both index maps
+    mats = [np.repeat(np.arange(N, dtype=np.float32)[:, None], K, 1), np.repeat(np.arange(K, dtype=np.float32)[None, :], N, 0)]
+    for wmat in mats:
+        for w_kn in (False, True):
+            img = Img(2)
+            a = img._put(np.eye(64, dtype=np.float32).reshape(-1))
+            w = img._put((wmat.T.copy() if w_kn else wmat).reshape(-1))
+            out = img.f32(64 * N, zero=True)
+            ol = P.OpList()
+            ol.add(P.CONV_TAPS, (P.CONV_W_KN if w_kn else 0) | P.CONV_BF16, tm.conv_ints(), (), [a, w, out, None, None])
+            gpu, _ = run_both(img, ol.array())
+            np.testing.assert_array_equal(view(gpu, out, np.float32, 64 * N).reshape(64, N), wmat.T)    # out[m][n] = W[n][m]
+        # weight gradient: DY = I: dW[n][k] = X[n][k]
+        img = Img(4)
+        dy = img._put(np.eye(64, dtype=np.float32).reshape(-1))
+        x = img._put(wmat.reshape(-1))
+        slab = img.f32(64 * 64, zero=True)
+        ol = P.OpList()
+        ol.add(P.WGRAD_TAPS, P.CONV_BF16, tm.ints() + [1, 64, 64 * 64], (), [dy, x, slab])
+        gpu, _ = run_both(img, ol.array())
+        np.testing.assert_array_equal(view(gpu, slab, np.float32, 64 * 64).reshape(64, 64), wmat)
+
+
+@pytest.mark.parametrize("name", list(WGRAD_CASES))
+@pytest.mark.parametrize("nsplit", [1, 3])
+def test_wgrad_taps_bf16(name, nsplit):
+    tm = WGRAD_CASES[name]()
+    img = Img(63)
+    nb = tm.M // tm.Lout
+    dy = img.f32(tm.M * tm.N)
+    x = img.f32(nb * tm.Lin * tm.K)
+    numel = len(tm.taps) * tm.N * tm.K
+    rps = -(-(-(-tm.M // nsplit)) // 32) * 32
+    ns = -(-tm.M // rps)
+    slab = img.f32(ns * numel, zero=True)
+    grad = img.f32(numel, zero=True)
+    ol = P.OpList()
+    ol.add(P.WGRAD_TAPS, P.CONV_BF16, tm.ints() + [ns, rps, numel], (), [dy, x, slab])
+    ol.add(P.SLAB_REDUCE, 0, [numel, ns, numel], (), [slab, grad])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, grad, numel, rel=3e-5, what=f"wgrad bf16 {name}")
+
+
+@pytest.mark.parametrize("L,clip", [(50, 0.0), (100, 1.0)])
+def test_bf16_step_against_the_float64_oracle(L, clip):
+    z, B = 10, 64
+    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-3, clip=clip, mfma_dtype="bf16"))
+    om = O.OracleModel("unimodal", z, L, salt=2, dtype=torch.float64)
+    eng.load_state_dict({k: v.detach().float() for k, v in om.state.items()})
+    x, src, cls, eps = O.synth_inputs(B, L, z, salt=2)
+    eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+    outs = eng.forward(True)
+    eng.backward()
+    torch.cuda.synchronize()
+    masks = H.engine_masks(eng)
+    o64 = om.forward((x.double(), src, None), eps.double(), True, masks=masks)
+    ls = om.losses((x.double(), src, None), o64)
+    ls[0].backward()
+    for a, b, nm in zip(outs, o64, ("enc", "mu", "logvar", "rec")):
+        e = H.assert_close(a.cpu().numpy().reshape(b.shape), b.detach().numpy(), 8e-2, "bf16 " + nm)
+        print(f"[bf16 L={L}] {nm}: max err / max |ref| = {e:.3e}")
+    sc = eng.scalars()
+    want = np.array([float(v.detach()) for v in ls])
+    print(f"[bf16 L={L}] loss scalars rel err {np.abs(np.array([sc[0], sc[1], sc[3]]) / want - 1)}")
+    np.testing.assert_allclose([sc[0], sc[1], sc[3]], want, rtol=3e-2)
+    grads = eng.grad_dict()
+    worst = 1.0
+    for k, g in om.grads().items():
+        if g is None or re.search(H.ZERO_GRAD_RE, k):
+            continue
+        a, b = grads[k].double().cpu().reshape(-1), g.reshape(-1)
+        cos = float((a @ b) / (a.norm() * b.norm()).clamp_min(1e-300))
+        worst = min(worst, cos)
+        assert cos >= 0.98, (k, cos)
+    print(f"[bf16 L={L}] worst gradient cosine vs masked f64 oracle: {worst:.5f}")
+    eng.optimizer_step()
+    for _ in range(5):
+        eng.train_step(use_graph=True)
+    torch.cuda.synchronize()
+    assert eng.adam_step == 6 and torch.isfinite(eng.params).all() and np.isfinite(eng.scalars()[0])
