@@ -288,7 +288,9 @@ def test_trainer_async_path_equals_per_step_sync_path(tmp_path):
     np.testing.assert_allclose([t0, v0], [t1, v1], rtol=1e-4)
     import re
     for k in sd0:
-        if sd0[k].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, k):
+        if "running_" in k:
+            H.assert_close(sd1[k].numpy(), sd0[k].numpy(), 1e-3, k)          # follow the +-lr parameter noise
+        elif sd0[k].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, k):
             H.assert_adam_close(sd1[k].numpy(), sd0[k].numpy(), 1e-5, k, steps=6, frac=5e-2)
 
 

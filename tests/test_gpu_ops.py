@@ -725,7 +725,7 @@ def test_chained_launch_equals_standalone_ops():
         ol.end()
         outs = dict(c0=(c0, Bn * ld), u1=(u1, Bn * 2 * z), a1=(a1, Bn * 2 * z), save=(save, 4 * z), rm=(rm, 2 * z), rv=(rv, 2 * z),
                     mulv=(mulv, Bn * 2 * z), zz=(zz, Bn * z), drec=(drec, Bn * 50), scal=(scal, 4), g=(g, Bn * 2 * z), dr=(dr, Bn * 2 * z),
-                    dw=(dw, 2 * z * ld), db=(db, 2 * z), dx=(dx, Bn * ld), dsemb=(dsemb, 5 * H), dgam=(dgam, 2 * z))
+                    dw=(dw, 2 * z * ld), dx=(dx, Bn * ld), dsemb=(dsemb, 5 * H), dgam=(dgam, 2 * z))
         return ol, outs
 
     img = Img(51)
