@@ -125,6 +125,25 @@ __device__ __forceinline__ void bn_side_effects(const BnCoef& k, int M, int C, i
   rvar[c] = (float)((1.0 - (double)momentum) * (double)k.rv + (double)momentum * unb);
 }
 
+// BatchNorm backward, input gradient: dr = sc * (g - c1 - xhat * c2) with xhat = (x - mean) * invstd, c1 = sum(g)/M,
+// c2 = sum(g*xhat)/M, sc = gamma * invstd — as three per-channel coefficients formed in fp64 and two fused multiply-adds
+// per element:  dr = fma(g, A, fma(x, B, C)),  A = sc,  B = -sc*c2*invstd,  C = sc*(c2*invstd*mean - c1).
+// One derivation (bn_dr_coef) and one expression (bn_dr) shared by HP_OP_BN_BWD_APPLY and the HP_CONV_IN_DR operand
+// loader: the same bits wherever dr is evaluated.
+struct BnDrCoef { float A, B, C; };
+__device__ __forceinline__ BnDrCoef bn_dr_coef(float mean, float invstd, float gamma, double sg, double sgx, int Mstat) {
+  const double sc = (double)gamma * (double)invstd;
+  const double c1 = sg / (double)Mstat, c2 = sgx / (double)Mstat;
+  BnDrCoef k;
+  k.A = (float)sc;
+  k.B = (float)(-sc * c2 * (double)invstd);
+  k.C = (float)(sc * (c2 * (double)invstd * (double)mean - c1));
+  return k;
+}
+__device__ __forceinline__ float bn_dr(float g, float x, float A, float B, float C) {
+  return __fmaf_rn(g, A, __fmaf_rn(x, B, C));
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -350,27 +350,20 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
     const float mean = p.save[c], invstd = p.save[p.C + c], gam = p.gamma[c];
     double sg, sgx;
     stat_sum2(p.bs, p.C, c, sg, sgx);
-    s_coef[0][ci] = mean; s_coef[1][ci] = invstd;
-    s_coef[2][ci] = (float)(sg / (double)p.Mstat); s_coef[3][ci] = (float)(sgx / (double)p.Mstat);
-    s_coef[4][ci] = gam * invstd;
+    const BnDrCoef k = bn_dr_coef(mean, invstd, gam, sg, sgx, p.Mstat);
+    s_coef[0][ci] = k.A; s_coef[1][ci] = k.B; s_coef[2][ci] = k.C;
     if (bx == 0) { p.dgamma[c] = (float)(sgx * (double)p.gscale); p.dbeta[c] = (float)(sg * (double)p.gscale); }
   }
   __syncthreads();
   if (!m.active) return;
   const int ci0 = (threadIdx.x - m.rlane * m.cw) * V;
-  float mean[V], invstd[V], c1[V], c2[V], sc[V];
+  float cA[V], cB[V], cC[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) {
-    mean[j] = s_coef[0][ci0 + j]; invstd[j] = s_coef[1][ci0 + j];
-    c1[j] = s_coef[2][ci0 + j]; c2[j] = s_coef[3][ci0 + j]; sc[j] = s_coef[4][ci0 + j];
-  }
+  for (int j = 0; j < V; ++j) { cA[j] = s_coef[0][ci0 + j]; cB[j] = s_coef[1][ci0 + j]; cC[j] = s_coef[2][ci0 + j]; }
   auto apply = [&](T x, T g, size_t idx) {
     T o;
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      const float xh = (at<V>(x, j) - mean[j]) * invstd[j];
-      at<V>(o, j) = sc[j] * (at<V>(g, j) - c1[j] - xh * c2[j]);
-    }
+    for (int j = 0; j < V; ++j) at<V>(o, j) = bn_dr(at<V>(g, j), at<V>(x, j), cA[j], cB[j], cC[j]);
     *reinterpret_cast<T*>(p.dr + idx) = o;
   };
   if (V == 4) {

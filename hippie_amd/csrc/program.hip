@@ -103,8 +103,19 @@ int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
         if (I[22 + j]) { src1 = true; w1 = I[16 + j] + 1 > w1 ? I[16 + j] + 1 : w1; }
         else { src0 = true; w0 = I[16 + j] + 1 > w0 ? I[16 + j] + 1 : w0; }
       }
-      if (src0) { need[0] = rows_in() * K * f4; need[1] = w0 * N * K * f4; }
-      if (src1) { need[10] = rows_in() * K * f4; need[11] = w1 * N * K * f4; }
+      const bool in_dr = op.flags & HP_CONV_IN_DR;
+      if (src0) { if (!in_dr) need[0] = rows_in() * K * f4; need[1] = w0 * N * K * f4; }
+      if (src1) { if (!in_dr) need[10] = rows_in() * K * f4; need[11] = w1 * N * K * f4; }
+      if (in_dr) {
+        for (int s_ = 0; s_ < 2; ++s_) {
+          if (!(s_ == 0 ? src0 : src1)) continue;
+          const int b0 = 24 + 8 * s_;
+          need[b0] = need[b0 + 1] = rows_in() * K * f4;            // G, RAW
+          need[b0 + 2] = 2 * K * f4; need[b0 + 3] = stat(K);       // SAVE, BS
+          need[b0 + 4] = need[b0 + 5] = need[b0 + 6] = K * f4;     // GAMMA, DGAMMA, DBETA
+          if (op.buf[b0 + 7] != HP_NULL) need[b0 + 7] = rows_in() * K * f4;
+        }
+      }
       need[2] = out_rows * N * f4;
       if (op.flags & HP_CONV_IN_BN) { need[5] = need[6] = need[7] = need[8] = K * f4; need[12] = stat(K); need[13] = need[14] = 2 * K * f4; }
       if (op.flags & HP_CONV_EPI_BNRED) {
@@ -251,6 +262,7 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
       if (op.i[28] > 0) ok = ok && op.i[29] >= 1 && op.i[30] >= 0 && (int64_t)op.i[29] * (op.i[3] - 1) + op.i[30] < op.i[28];
       if (op.flags & HP_CONV_IN_BN) ok = ok && K <= 512 && op.i[31] > 0 && !(op.flags & HP_CONV_BN_EVAL);     // coefficient table in LDS
       if (op.flags & HP_CONV_EPI_BNRED) ok = ok && !(op.flags & (HP_CONV_BIAS | HP_CONV_STATS | HP_CONV_BN_EVAL));
+      if (op.flags & HP_CONV_IN_DR) ok = ok && K <= 512 && op.i[33] > 0 && !(op.flags & (HP_CONV_IN_BN | HP_CONV_BN_EVAL));
       for (int j = 0; j < nt && j < HP_MAX_TAPS; ++j) ok = ok && (op.i[22 + j] == 0 || op.i[22 + j] == 1);
     }
     if (op.op == HP_OP_WGRAD_TAPS)
@@ -331,7 +343,8 @@ int hp_program_validate(const HpProgram* p) {
       const HpOp& a = p->ops[g.i[0]];
       const HpOp& b = p->ops[g.i[1]];
       const bool kind_ok = a.op == b.op && (a.flags & HP_FLAG_MEMBER) && (b.flags & HP_FLAG_MEMBER) &&
-                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & HP_CONV_BF16) == (b.flags & HP_CONV_BF16)) ||
+                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & HP_CONV_BF16) == (b.flags & HP_CONV_BF16) &&
+                             (a.flags & HP_CONV_IN_DR) == (b.flags & HP_CONV_IN_DR)) ||
                             ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
                              (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
       if (!kind_ok) return fail("pair op " + std::to_string(k) + ": members are not two pairable ops of one kind");

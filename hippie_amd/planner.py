@@ -59,6 +59,11 @@ class TrainCfg:
                                         # 174 -> 146 launches per model-step, but MEASURED SLOWER at batch 512 (46.9 k vs 104 k samples/s):
                                         # one 256-thread workgroup serialises ~350 virtual blocks of dependent L2 round trips that the
                                         # stand-alone launches spread over 40 CUs each.  Off by default; DESIGN.md section 8.
+    fuse_bn_apply: bool = False         # (with fuse_bn) BatchNorm-backward APPLY evaluated in the input-gradient conv's operand loader
+                                        # (HP_CONV_IN_DR), which writes dr back for the grouped weight-gradient launch: 174 -> 142
+                                        # launches per model-step, bit-identical results, but MEASURED SLOWER at batch 512 (100.9 k vs
+                                        # 104.7 k samples/s): the loader's second operand stream + 12 VALU ops per float4 + 14 spilled
+                                        # VGPRs cost each input-gradient conv 5-12 us, more than the 5-8 us launch it replaces.  Off.
     fuse_bn: bool = True                # training: a block's inner BatchNorm + leaky_relu is evaluated in its consumers' operand
                                         # loaders (HP_CONV_IN_BN: the activation tensor is never written) and the BatchNorm-backward
                                         # reduction runs in the epilogue of the input-gradient conv that produces its operand
@@ -269,7 +274,7 @@ class Lowering:
 
     # ---- op emitters --------------------------------------------------------------
     def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note="", a2=None, w2: PInfo = None,
-             in_bn=None, epi=None):
+             in_bn=None, epi=None, wb_taps=()):
         """One HP_OP_CONV_TAPS record.  in_bn = dict(bn, stats, M): the A operand is leaky_relu(bn(a)) evaluated in
         the loader (HP_CONV_IN_BN).  epi = a reduction spec (red_spec): HP_OP_BN_BWD_REDUCE fused into the epilogue,
         `out` must be the spec's g tensor."""
@@ -277,9 +282,28 @@ class Lowering:
         flags |= self.mm_flag
         ii = tm.conv_ints() + [0, 0]
         ff = [0.0] * 6
-        bufs = [a, w.ref, out, bias.ref if bias is not None else None, stats] + [None] * 19
+        bufs = [a, w.ref, out, bias.ref if bias is not None else None, stats] + [None] * 35
+        ii += [0] * (40 - len(ii))
         if a2 is not None:
             bufs[10], bufs[11] = a2, w2.ref
+        lazy = [x for x in (a, a2) if isinstance(x, dict)]
+        if lazy:
+            # the operand(s) are BatchNorm-backward input gradients evaluated in the loader (HP_CONV_IN_DR): no stored tensor
+            assert all(isinstance(x, dict) for x in (a, a2) if x is not None) and in_bn is None
+            flags |= P.CONV_IN_DR
+            bufs[0] = None
+            if a2 is not None:
+                bufs[10] = None
+            for s_, d in enumerate(lazy):
+                b0 = 24 + 8 * s_
+                bufs[b0: b0 + 8] = [d["g"], d["raw"], d["save"], d["bs"], d["gamma"], d["dgamma"], d["dbeta"], d["dr"]]
+                ii[33 + s_] = d["M"]
+            ii[35] = self.train.sync_bn_world
+            mask = 0
+            for j in wb_taps:
+                mask |= 1 << j
+            ii[36] = mask
+            note += " <- bn-bwd-apply in the loader"
         if in_bn is not None:
             bn = in_bn["bn"]
             flags |= P.CONV_IN_BN
@@ -321,6 +345,8 @@ class Lowering:
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note="", coef=None):
         """coef: x is the raw input of a BatchNorm whose activation was never stored (HP_CONV_IN_BN on the forward
         conv): the kernel re-evaluates leaky_relu(fma(x, scale, shift)) from (scale, shift) = coef."""
+        if isinstance(dy, dict):
+            dy = dy["dr"]               # written back by the input-gradient conv that evaluates it (HP_CONV_IN_DR)
         xf = (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
         if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
@@ -448,9 +474,25 @@ class Lowering:
                    f=[sp["slope"]], buf=bufs, note=bn["prefix"] + " bwd-reduce")
         self.reduce_sync(sp)
 
-    def apply_op(self, sp):
-        """-> (dr, dr_b): gradients of the BatchNorm inputs (conv outputs)."""
+    @property
+    def fuse_dr(self):
+        """BatchNorm-backward apply evaluated in the input-gradient conv's loader (HP_CONV_IN_DR): needs the deferred
+        grouped weight-gradient launch (it reads the dr tensors the convs write back)."""
+        t = self.train
+        return t.fuse_bn and t.fuse_bn_apply and t.grouped_wgrad and not t.deterministic_wgrad
+
+    def lazy_dr(self, sp, second=False):
+        """descriptor of dr = bn_bwd_apply(sp) for conv(a=...): evaluated by the consuming conv, which also writes it to `dr`"""
+        bn = sp["bn_b"] if second else sp["bn"]
+        return dict(g=sp["g"], raw=sp["raw_b"] if second else sp["raw"], save=bn["save"], bs=sp["bs_b"] if second else sp["bs"],
+                    gamma=bn["gamma"].ref, dgamma=bn["gamma"].gref, dbeta=bn["beta"].gref, dr=self.pl.f32(sp["M"] * sp["C"]), M=sp["M"])
+
+    def apply_op(self, sp, lazy=False):
+        """-> (dr, dr_b): gradients of the BatchNorm inputs (conv outputs).  lazy (and fuse_dr): descriptors instead of
+        tensors — no launch; the consuming input-gradient conv evaluates them (its `dr` member is what wgrad() gets)."""
         M, C, bn, bn_b, W = sp["M"], sp["C"], sp["bn"], sp["bn_b"], self.train.sync_bn_world
+        if lazy and self.fuse_dr:
+            return self.lazy_dr(sp), (self.lazy_dr(sp, True) if bn_b is not None else None)
         dr = self.pl.f32(M * C)
         self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[sp["g"], sp["raw"], bn["save"], sp["bs"], bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
                    note=bn["prefix"] + " bwd-apply")
@@ -469,14 +511,15 @@ class Lowering:
         dr, dr_b = self.apply_op(sp)
         return sp["g"], dr, dr_b
 
-    def dgrad_reduce(self, tm, dr, w, sp, note):
-        """Input-gradient conv whose output feeds the BatchNorm-backward reduction `sp` (fused when fuse_bn)."""
+    def dgrad_reduce(self, tm, dr, w, sp, note, wb_taps=(1,)):
+        """Input-gradient conv whose output feeds the BatchNorm-backward reduction `sp` (fused when fuse_bn).
+        wb_taps: for a lazy dr operand, the taps that write it back (stride-1 k=3: the centre tap touches every row once)."""
         if self.train.fuse_bn:
-            self.conv(tm, dr, w, sp["g"], w_kn=True, epi=sp, note=note)
+            self.conv(tm, dr, w, sp["g"], w_kn=True, epi=sp, note=note, wb_taps=wb_taps)
             self.reduce_sync(sp)
         else:
             tmp = self.pl.f32(tm.out_rows * tm.N)
-            self.conv(tm, dr, w, tmp, w_kn=True, note=note)
+            self.conv(tm, dr, w, tmp, w_kn=True, note=note, wb_taps=wb_taps)
             self.reduce_op(sp, tmp)
 
     def linear_fwd(self, M, lin, x, ldx, y, ldy, act=False, stats=None, note=""):
@@ -605,13 +648,13 @@ class Lowering:
             Lo, Li = blk["Lout"], blk["Lin"]
             Mo = B * Lo
             p = blk["prefix"]
-            dr2, drs = self.apply_op(sp)
+            dr2, drs = self.apply_op(sp, lazy=True)
             stored = blk["a1"] is not None
             self.wgrad(blk["tm2"], dr2, blk["a1"] if stored else blk["r1"], blk["conv2"], note=p + "conv2 wgrad",
                        coef=None if stored else blk["bn1"]["coef"])
             sp1 = self.red_spec(Mo, blk["bn1"], blk["a1"], blk["r1"])
             self.dgrad_reduce(self.map_dgrad(Lo, Lo, cout, cout), dr2, blk["conv2"], sp1, p + "conv2 dgrad")
-            dr1, _ = self.apply_op(sp1)
+            dr1, _ = self.apply_op(sp1, lazy=True)
             self.wgrad(blk["tm1"], dr1, blk["x"], blk["conv1"], note=p + "conv1 wgrad")
             if s == 1:
                 # d/dx = conv1 path + identity shortcut (this block's masked gradient)
@@ -626,7 +669,9 @@ class Lowering:
                 dst = spp["g"] if fuse else pl.f32(B * Li * cin)
                 tms = self.map_dgrad_s2_phases(Li, Lo, cin, cout)
                 for q, tm in enumerate(tms):
+                    # (lazy operands: the even-row op's two taps touch every row of dr1 and of drs once -> they write them back)
                     self.conv(tm, dr1, blk["conv1"], dst, w_kn=True, a2=drs, w2=blk["sc"], epi=spp if fuse else None,
+                              wb_taps=(0, 1) if tm.out_o == 0 else (),
                               note=p + "conv1 + shortcut dgrad, " + ("even" if tm.out_o == 0 else "odd") + " rows")
                 if len(tms) == 2:
                     self.pair_last_two("pair " + p + "conv1 + shortcut dgrad (even | odd rows)")
@@ -723,7 +768,7 @@ class Lowering:
             Li, Lo = blk["Lin"], blk["Lout"]
             Mi = B * Li
             p = blk["prefix"]
-            dr1, drs = self.apply_op(sp)
+            dr1, drs = self.apply_op(sp, lazy=True)
             stored = blk["a2"] is not None
             x1, c1 = (blk["a2"], None) if stored else (blk["r2"], blk["bn2"]["coef"])
             sp2 = self.red_spec(Mi, blk["bn2"], blk["a2"], blk["r2"])
@@ -736,16 +781,18 @@ class Lowering:
                 self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=p + "shortcut (resize) wgrad")
                 fuse = self.train.fuse_bn
                 da2 = sp2["g"] if fuse else pl.f32(Mi * cin)
+                # (lazy operands: taps 1 (offset 0) and 0 (offset 1) of the 6-tap map touch the even / odd rows once)
                 self.conv(self.map_dgrad_up(Li, cin, cout), dr1, blk["conv1"], da2, w_kn=True, epi=sp2 if fuse else None,
-                          note=p + "conv1 (resize) dgrad")
+                          wb_taps=(1, 0), note=p + "conv1 (resize) dgrad")
                 side = pl.f32(Mi * cin)
-                self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, note=p + "shortcut (resize) dgrad")
+                self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, wb_taps=(1, 0),
+                          note=p + "shortcut (resize) dgrad")
                 self.pair_last_two("pair " + p + "resize dgrads")
                 if fuse:
                     self.reduce_sync(sp2)
                 else:
                     self.reduce_op(sp2, da2)
-            dr2, _ = self.apply_op(sp2)
+            dr2, _ = self.apply_op(sp2, lazy=True)
             self.wgrad(blk["tm2"], dr2, blk["x"], blk["conv2"], note=p + "conv2 wgrad")
             tm = self.map_dgrad(Li, Li, cin, cin)
             if bi > 0:
@@ -756,7 +803,7 @@ class Lowering:
                 sp = spp
             else:
                 G1 = pl.f32(Mi * cin)
-                self.conv(tm, dr2, blk["conv2"], G1, w_kn=True, note=p + "conv2 dgrad")
+                self.conv(tm, dr2, blk["conv2"], G1, w_kn=True, note=p + "conv2 dgrad", wb_taps=(1,))
                 G2 = side
         dy = pl.f32(B * 512)
         self.o.add(P.REPEAT_BWD, 0, i=[B, 4, 512, 1], buf=[G1, G2, dy], note=d["prefix"] + "interpolate x4 bwd")

@@ -16,11 +16,11 @@ WS, PARAM, GRAD, BUF, ADAM_M, ADAM_V = range(6)
 NUM_SPACES = 6
 NULL = -1
 MAX_TAPS = 6
-NI, NF, NB = 40, 8, 24
+NI, NF, NB = 40, 8, 40
 
 OP_DTYPE = np.dtype([("op", "<i4"), ("flags", "<i4"), ("i", "<i4", (NI,)), ("f", "<f4", (NF,)),
                      ("buf", "<i8", (NB,))], align=True)
-assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
+assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 520
 
 (CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
  POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
@@ -29,7 +29,7 @@ assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
-CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 1, 2, 4, 8, 16, 64, 128, 256
+CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16, CONV_IN_DR = 1, 2, 4, 8, 16, 64, 128, 256, 1024
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the chain it belongs to
 FLAG_CHAIN_SHIFT, FLAG_CHAIN_MASK, CHAIN_MAX = 16, 0xFF, 64     # chained launch: see include/hippie_hip.h
 STAT_REPL_MAX = 16       # HP_STAT_REPL_MAX

@@ -64,7 +64,7 @@ static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 10
 }
 #define HP_OP_NI 40
 #define HP_OP_NF 8
-#define HP_OP_NB 24
+#define HP_OP_NB 40
 
 /* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op: the program executor skips it
  * (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
@@ -106,6 +106,7 @@ typedef struct HpOp {
 #define HP_CONV_ACT      16    /* ... followed by leaky_relu */
 #define HP_CONV_IN_BN    64    /* training-mode BatchNorm + leaky_relu of the INPUT applied in the operand loader */
 #define HP_CONV_EPI_BNRED 128  /* BatchNorm-backward reduction fused into the epilogue (input-gradient convs) */
+#define HP_CONV_IN_DR    1024  /* the A operand is a BatchNorm-backward input gradient evaluated in the operand loader (below) */
 #define HP_CONV_BF16     256   /* CONV_TAPS / WGRAD_TAPS: both GEMM operands are rounded to bfloat16 (nearest even) when staged into
                                 * LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors in HBM, BatchNorm
                                 * statistics, epilogues and the optimiser stay fp32.  The separately labelled reduced-precision mode
@@ -135,10 +136,19 @@ enum {
    *   (and the same sums for a second BatchNorm fed by the same g: E_RAW2, E_SAVE2, E_BS2)  —  HP_OP_BN_BWD_REDUCE
    *   on this conv's output, fused.  f[5]=slope of that leaky_relu.
    *
+   * HP_CONV_IN_DR (input-gradient convs): the A operand of source s (s = tap_src) is
+   *   dr_s = sc * (G_s - c1 - xhat * c2),  xhat = (RAW_s - mean) * invstd,  c1 = sum(g)/Ms, c2 = sum(g*xhat)/Ms, sc = gamma*invstd
+   *   — HP_OP_BN_BWD_APPLY (the second half of ATen native_batch_norm_backward) evaluated on the way into LDS, bit for bit
+   *   (bn_dr in hp_common.h); the sums come from BS_s (i[33+s] rows, x i[35] ranks under sync-BatchNorm), mean/invstd from
+   *   SAVE_s.  Workgroup 0 writes DGAMMA_s = sum g*xhat, DBETA_s = sum g (x 1/i[35]).  The taps in the bit mask i[36] store
+   *   the rows they evaluate to DR_s (column-tile 0 only): the planner picks taps that together touch every row once, so DR_s
+   *   is the complete tensor the weight-gradient GEMM reads later.  A / A2 are unused.
+   *
    * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[R][2][N]), 5 GAMMA 6 BETA 7 RMEAN 8 RVAR (of the epilogue BN with
    *      BN_EVAL, of the input BN with IN_BN), 9 RES(or NULL), 10 A2, 11 W2,
    *      12 IN_STATS(double[R][2][K]) 13 IN_SAVE(float[2][K]) 14 IN_COEF(float[2][K]),
-   *      15 E_G2 16 E_ACT 17 E_RAW 18 E_SAVE 19 E_COEF 20 E_BS 21 E_RAW2 22 E_SAVE2 23 E_BS2 */
+   *      15 E_G2 16 E_ACT 17 E_RAW 18 E_SAVE 19 E_COEF 20 E_BS 21 E_RAW2 22 E_SAVE2 23 E_BS2,
+   *      24+8s .. 31+8s (s = 0, 1): G_s RAW_s SAVE_s BS_s GAMMA_s DGAMMA_s DBETA_s DR_s */
   HP_OP_CONV_TAPS = 1,
   /* slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]; f32 MFMA.
    * Replaces the weight-gradient half of ATen convolution_backward.

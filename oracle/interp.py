@@ -14,7 +14,7 @@ import numpy as np
 NULL = -1
 STAT_REPL_MAX = 16
 MASK = (1 << 56) - 1
-CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 64, 128, 256
+CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16, CONV_IN_DR = 64, 128, 256, 1024
 
 
 def _bf16(x):
@@ -113,6 +113,20 @@ def _bn_coef(A, training, M, C, stats, gamma, beta, rmean, rvar, eps):
     return mean, var, invstd, sc.astype(np.float32), sh.astype(np.float32)
 
 
+def _bn_dr(A, g, raw, save, bs_ref, gamma, dgamma, dbeta, C, Mstat, world):
+    """HP_OP_BN_BWD_APPLY: dr = fma(g, A, fma(raw, B, C)) with the per-channel (A, B, C) of hp_common.h::bn_dr_coef; writes
+    dgamma / dbeta.  Returns dr (float32)."""
+    sv = A.f32(save, 2 * C).astype(np.float64)
+    mean, invstd = sv[:C], sv[C:]
+    bs = A.f64(bs_ref, stat_repl(C) * 2 * C).reshape(stat_repl(C), 2 * C).sum(0)
+    sc = A.f32(gamma, C).astype(np.float64) * invstd
+    c1, c2 = bs[:C] / Mstat, bs[C:] / Mstat
+    cA, cB, cC = sc.astype(np.float32), (-sc * c2 * invstd).astype(np.float32), (sc * (c2 * invstd * mean - c1)).astype(np.float32)
+    A.f32(dgamma, C)[:] = (bs[C:] / world).astype(np.float32)
+    A.f32(dbeta, C)[:] = (bs[:C] / world).astype(np.float32)
+    return _fma32(g, cA[None, :], _fma32(raw, cB[None, :], cC[None, :]))
+
+
 def _bn_side(A, M, C, mean, var, invstd, save, rmean, rvar, mom, coef=NULL, sc=None, sh=None):
     sv = A.f32(save, 2 * C)
     sv[:C] = mean.astype(np.float32)
@@ -141,8 +155,19 @@ def run(ops, A: Arenas, first=0, count=None):
                 Ms = int(i[31]) * max(1, int(i[32]))
                 mean, var, invstd, sc_in, sh_in = _bn_coef(A, True, Ms, K, b[12], b[5], b[6], b[7], b[8], f[3])
                 coefs = (sc_in, sh_in)
+            dr_src = {}
+            if flags & CONV_IN_DR:      # HP_OP_BN_BWD_APPLY of (G_s, RAW_s) evaluated in the loader; written back to DR_s
+                world = max(1, int(i[35]))
+                for s_ in sorted({t_[2] for t_ in taps}):
+                    b0 = 24 + 8 * s_
+                    g_ = A.f32(b[b0], nin * K).reshape(nin, K)
+                    raw_ = A.f32(b[b0 + 1], nin * K).reshape(nin, K)
+                    dr_src[s_] = _bn_dr(A, g_, raw_, b[b0 + 2], b[b0 + 3], b[b0 + 4], b[b0 + 5], b[b0 + 6], K, int(i[33 + s_]) * world, world)
+                    if int(b[b0 + 7]) != NULL:
+                        # (the kernel's write-back taps cover every row exactly once; rows no tap covers do not exist in the planner's maps)
+                        A.f32(b[b0 + 7], nin * K)[:] = dr_src[s_].reshape(-1)
             for off, w, srcsel in taps:
-                X = A.f32(b[10] if srcsel else b[0], nin * K).reshape(nin, K)
+                X = dr_src[srcsel] if flags & CONV_IN_DR else A.f32(b[10] if srcsel else b[0], nin * K).reshape(nin, K)
                 W = A.f32(b[11] if srcsel else b[1], (w + 1) * N * K)
                 src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, off)
                 Xs = X[src]
@@ -266,18 +291,10 @@ def run(ops, A: Arenas, first=0, count=None):
                 bs[C:] += (g.astype(np.float64) * xh.astype(np.float64)).sum(0)
         elif op == 6:    # BN_BWD_APPLY
             M, C = int(i[0]), int(i[1])
+            W = max(1, int(i[2]))
             g = A.f32(b[0], M * C).reshape(M, C)
             raw = A.f32(b[1], M * C).reshape(M, C)
-            sv = A.f32(b[2], 2 * C)
-            bs = A.f64(b[3], stat_repl(C) * 2 * C).reshape(stat_repl(C), 2 * C).sum(0)
-            gamma = A.f32(b[4], C)
-            xh = (raw - sv[None, :C]) * sv[None, C:]
-            W = max(1, int(i[2]))
-            c1 = (bs[:C] / (M * W)).astype(np.float32)
-            c2 = (bs[C:] / (M * W)).astype(np.float32)
-            A.f32(b[5], M * C)[:] = ((gamma * sv[C:])[None, :] * (g - c1[None, :] - xh * c2[None, :])).astype(np.float32).reshape(-1)
-            A.f32(b[6], C)[:] = (bs[C:] / W).astype(np.float32)
-            A.f32(b[7], C)[:] = (bs[:C] / W).astype(np.float32)
+            A.f32(b[5], M * C)[:] = _bn_dr(A, g, raw, b[2], b[3], b[4], b[6], b[7], C, M * W, W).reshape(-1)
         elif op in (7, 8):    # STEM_FWD / STEM_WGRAD
             B, Lin, Lout, C = [int(v) for v in i[:4]]
             xr = b[0] if op == 7 else b[1]

@@ -754,3 +754,65 @@ def test_chained_launch_equals_standalone_ops():
         tol = 0 if name in ("c0", "u1") else 2e-6
         assert np.abs(a - b).max() <= tol * max(np.abs(a).max(), 1e-30), name
         assert np.abs(b - c_).max() <= tol * max(np.abs(b).max(), 1e-30), name
+
+
+@pytest.mark.parametrize("variant", ["s1", "up", "phases"])
+def test_conv_in_dr_equals_bn_bwd_apply_then_conv(variant):
+    """HP_CONV_IN_DR: the input-gradient conv evaluates dr = bn_bwd_apply(g, raw) in its operand loader, writes it back
+    for the weight-gradient GEMM and (workgroup 0) the BatchNorm's dgamma / dbeta — bit-identical to HP_OP_BN_BWD_APPLY
+    followed by the plain conv (one coefficient derivation, one expression: hp_common.h bn_dr_coef / bn_dr)."""
+    Bn, K, N = 4, 128, 64
+    img = Img(71)
+    if variant == "s1":
+        L = 13
+        tms = [TapMap(Bn * L, N, K, L, L, L, 1, 0, [(1 - t, t) for t in range(3)])]
+        wb = [(1,)]
+        rows = Bn * L
+    elif variant == "up":       # transpose of nearest-x2 + conv: 6 taps over a source of 2*Lx rows
+        Lx = 7
+        tms = [TapMap(Bn * Lx, N, K, Lx, 2 * Lx, 2 * Lx, 2, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)])]
+        wb = [(1, 0)]
+        rows = Bn * 2 * Lx
+    else:                        # stride-2 phases: two sources, interleaved output rows
+        Lx, Ly = 13, 7
+        tms = [TapMap(Bn * 7, N, K, 7, Ly, Ly, 1, 0, [(0, 1, 0), (0, 0, 1)], out_Lfull=Lx, out_a=2, out_o=0),
+               TapMap(Bn * 6, N, K, 6, Ly, Ly, 1, 0, [(1, 0, 0), (0, 2, 0)], out_Lfull=Lx, out_a=2, out_o=1)]
+        wb = [(0, 1), ()]
+        rows = Bn * Ly
+    two = variant == "phases"
+    w, w2 = img.f32(3 * N * K, scale=0.1), img.f32(N * K, scale=0.1)
+    srcs = []
+    for s_ in range(2 if two else 1):
+        g, raw = img.f32(rows * K), img.f32(rows * K)
+        save = img._put(np.concatenate([img.rng.standard_normal(K) * 0.1, np.abs(img.rng.standard_normal(K)) + 0.5]).astype(np.float32))
+        gamma = img.f32(K)
+        bs = img.f64(R(K) * 2 * K)
+        _chunk_array(img, bs)[: 2 * K] = img.rng.standard_normal(2 * K) * rows * 0.1
+        srcs.append(dict(g=g, raw=raw, save=save, gamma=gamma, bs=bs,
+                         dr_a=img.f32(rows * K, zero=True), dr_b=img.f32(rows * K, zero=True),
+                         dga=img.f32(K, zero=True), dba=img.f32(K, zero=True), dgb=img.f32(K, zero=True), dbb=img.f32(K, zero=True)))
+    out_rows = tms[0].out_rows
+    out_a, out_b = img.f32(out_rows * N, zero=True), img.f32(out_rows * N, zero=True)
+    ol = P.OpList()
+    for sd in srcs:
+        ol.add(P.BN_BWD_APPLY, 0, [rows, K, 0], (), [sd["g"], sd["raw"], sd["save"], sd["bs"], sd["gamma"], sd["dr_a"], sd["dga"], sd["dba"]])
+    for tm in tms:
+        ol.add(P.CONV_TAPS, P.CONV_W_KN, tm.conv_ints(), (), [srcs[0]["dr_a"], w, out_a] + [None] * 7 + ([srcs[1]["dr_a"], w2] if two else []))
+    for tm, wbt in zip(tms, wb):
+        ii = tm.conv_ints() + [0] * (40 - len(tm.conv_ints()))
+        ii[33] = rows
+        ii[34] = rows if two else 0
+        ii[36] = sum(1 << j for j in wbt)
+        bufs = [None, w, out_b] + [None] * 7 + [None, w2 if two else None] + [None] * 12
+        for sd in srcs:
+            bufs += [sd["g"], sd["raw"], sd["save"], sd["bs"], sd["gamma"], sd["dgb"], sd["dbb"], sd["dr_b"]]
+        ol.add(P.CONV_TAPS, P.CONV_W_KN | P.CONV_IN_DR, ii, (), bufs)
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, out_b, out_rows * N, what="in-dr conv vs interpreter")
+    g_ = lambda ref, n: view(gpu, ref, np.float32, n)
+    np.testing.assert_array_equal(g_(out_a, out_rows * N), g_(out_b, out_rows * N))
+    for sd in srcs:
+        check(gpu, cpu, sd["dr_b"], rows * K, what="dr write-back vs interpreter")
+        np.testing.assert_array_equal(g_(sd["dr_a"], rows * K), g_(sd["dr_b"], rows * K))
+        np.testing.assert_array_equal(g_(sd["dga"], K), g_(sd["dgb"], K))
+        np.testing.assert_array_equal(g_(sd["dba"], K), g_(sd["dbb"], K))
