@@ -184,7 +184,7 @@ def op_bytes(r):
     return None
 
 
-def profile_ops(pair, data, idx, reps=3):
+def profile_ops(pair, data, idx, reps=5):
     """Per-launch HIP-event timing (hp_program_profile: events on the stream the kernels are launched on) of every op
     of one pair-step, in an untimed eager pass over the same programs.  Returns one dict per LAUNCH:
     {model, seg, kind, note, us, flop (conv / wgrad: 2*M*N*K*taps over the launch's member records), bytes, members}."""
@@ -207,10 +207,8 @@ def profile_ops(pair, data, idx, reps=3):
     for model, ops, segments, notes, prof in progs:
         for seg in ("fwd_train", "bwd", "opt"):
             first, count = segments[seg]
-            acc = np.zeros(count)
-            for _ in range(reps):
-                acc += prof(seg)
-            acc /= reps
+            prof(seg)                                   # untimed: first eager launches load code objects / build tables
+            acc = np.median(np.stack([prof(seg) for _ in range(reps)]), axis=0).astype(np.float64)      # median: robust against a stray slow launch
             for j in range(count):
                 r = ops[first + j]
                 opc = int(r["op"])
@@ -227,7 +225,7 @@ def profile_ops(pair, data, idx, reps=3):
                 if mop in (P.CONV_TAPS, P.WGRAD_TAPS):
                     flop = sum(2.0 * int(m["i"][0]) * int(m["i"][1]) * int(m["i"][2]) * int(m["i"][9]) for m in members)
                 nbytes = [op_bytes(m) for m in members]
-                rows.append(dict(model=model, seg=seg, kind=kind, base=P.OP_NAMES[mop], note=notes[first + j], us=acc[j] * 1e3, flop=flop,
+                rows.append(dict(model=model, seg=seg, kind=kind, base=P.OP_NAMES[mop], note=notes[first + j], us=float(acc[j]) * 1e3, flop=flop,
                                  bytes=sum(nbytes) if all(v is not None for v in nbytes) else None, members=members))
     return rows
 

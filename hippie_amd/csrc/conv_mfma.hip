@@ -64,6 +64,23 @@ static TapMap tapmap_from(const HpOp& op) {
 // 16 bytes of zeros in device memory: padded / out-of-range rows load from here, so no select is needed
 __device__ __attribute__((aligned(16))) const float hp_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
+// 16-byte load through the GLOBAL address space.  Pointers that arrive inside a by-value argument struct (or a record in
+// memory) are generic to the compiler: it emits flat_load, which (a) also counts against the LDS counter — every
+// `s_waitcnt lgkmcnt(0)` in front of an LDS fragment read then waits for the global prefetches as well — and (b) returns
+// out of order with LDS traffic, so the compiler can only ever wait with vmcnt(0): a two-slice prefetch degenerates to a
+// synchronous load per K-step.  Everything these kernels load lives in device memory, so the cast is always valid.
+typedef float hp_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 gload4(const float* p) {
+  const hp_v4f v = *(const hp_v4f __attribute__((address_space(1)))*)(p);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void gstore4(float* p, const float4 v) {
+  hp_v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+  *(hp_v4f __attribute__((address_space(1)))*)(p) = t;
+}
+__device__ __forceinline__ float gload1(const float* p) { return *(const float __attribute__((address_space(1)))*)(p); }
+__device__ __forceinline__ void gstore1(float* p, float v) { *(float __attribute__((address_space(1)))*)(p) = v; }
+
 // blockIdx -> tile id such that each XCD (blocks are dealt round-robin over the 8 XCDs)
 // owns one contiguous run of tile ids: the N-tiles that share an A row-panel then hit the
 // same L2.  Bijective for any nblk.  Speed only; correctness never depends on it.
@@ -112,11 +129,148 @@ constexpr int kConvCoefDr = 2 * 3 * 512;   // + the (A, B, C) of bn_dr for up to
 constexpr int conv_extra_lds(int mode) { return mode == 1 ? kConvCoef : (mode == 2 ? kConvCoefDr : 0); }
 constexpr int kConvThreads = 512;
 
+// Shared epilogue of the conv bodies: sums the two K-halves of every quadrant through LDS, then bias / BatchNorm
+// statistics, the eval-mode BatchNorm fold, or the fused BatchNorm-backward reduction.
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[2], float* smem, const int bid, const int m0, const int n0) {
+  const TapMap& t = p.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int quad = wave & 3, kh = wave >> 2;
+  const int wm = quad >> 1, wn = quad & 1, li = lane & 31, lh = lane >> 5;
+  // sum the two K-halves through LDS (the staging buffers are free after the last barrier)
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = acc2[0][r] + acc2[1][r];
+  float* red = smem + quad * (16 * 64);
+  if (kh == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (kh == 1) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
+
+  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  const int n = n0 + wn * 32 + li;
+  const bool nok = n < t.N;
+  // element offset of the output of this lane's GEMM row r (-1 = outside the problem).  out_Lfull > 0: the op
+  // writes a strided subset of the rows of a taller tensor.  (int: every tensor of a program is < 2^31 elements,
+  // checked by hp_program_validate.)
+  auto out_off = [&](int r) -> int {
+    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (!nok || m >= t.M) return -1;
+    int o = m;
+    if (t.out_Lfull > 0) {
+      const int b = m / t.Lout;
+      o = b * t.out_Lfull + t.out_a * (m - b * t.Lout) + t.out_o;
+    }
+    return o * t.N + n;
+  };
+  if (p.epi) {
+    // HP_CONV_EPI_BNRED: HP_OP_BN_BWD_REDUCE on the accumulators (same expressions as bn_bwd_reduce_body)
+    float mean = 0.f, invstd = 0.f, mean2 = 0.f, invstd2 = 0.f, csc = 0.f, csh = 0.f;
+    const bool has_act = p.e_act != nullptr, has_g2 = p.e_g2 != nullptr, has_2 = p.e_raw2 != nullptr;
+    if (nok) {
+      mean = p.e_save[n]; invstd = p.e_save[t.N + n];
+      if (has_2) { mean2 = p.e_save2[n]; invstd2 = p.e_save2[t.N + n]; }
+      if (!has_act) { csc = p.e_coef[n]; csh = p.e_coef[t.N + n]; }
+    }
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {          // two batches of 8 rows: all loads of a batch in flight before the first use
+      int off[8];
+      float xr[8], av[8], g2[8], x2[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        off[q] = out_off(h * 8 + q);
+        const int o = off[q] >= 0 ? off[q] : 0;        // clamped, unconditional
+        xr[q] = gload1(p.e_raw + o);
+        av[q] = has_act ? gload1(p.e_act + o) : 0.f;
+        g2[q] = has_g2 ? gload1(p.e_g2 + o) : 0.f;
+        x2[q] = has_2 ? gload1(p.e_raw2 + o) : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (off[q] < 0) continue;
+        float gv = acc[h * 8 + q];
+        if (has_g2) gv += g2[q];
+        const float pre = has_act ? av[q] : fmaf(xr[q], csc, csh);
+        gv *= lrelu_grad(pre, p.e_slope);
+        gstore1(p.out + off[q], gv);
+        s1 += (double)gv;
+        s2 += (double)gv * (double)((xr[q] - mean) * invstd);
+        if (has_2) s3 += (double)gv * (double)((x2[q] - mean2) * invstd2);
+      }
+    }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    s3 += __shfl_xor(s3, 32, 64);
+    if (lh == 0 && nok) {
+      double* b1 = stat_replica(p.e_bs, t.N, bid);
+      atomic_add_f64(b1 + n, s1);
+      atomic_add_f64(b1 + t.N + n, s2);
+      if (has_2) {
+        double* b2 = stat_replica(p.e_bs2, t.N, bid);
+        atomic_add_f64(b2 + n, s1);
+        atomic_add_f64(b2 + t.N + n, s3);
+      }
+    }
+    return;
+  }
+  const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
+  if (p.bn_eval) {
+    // forward-only path: BatchNorm1d in eval mode (+ residual, + leaky_relu) applied to the accumulators; the
+    // coefficients are formed exactly as bn_coef() does for HP_OP_BN_APPLY, so the result is bit-identical
+    float sc = 0.f, sh = 0.f;
+    if (nok) {
+      const double invstd = 1.0 / sqrt((double)p.rvar[n] + (double)p.eps);
+      const double scd = (double)p.gamma[n] * invstd;
+      sc = (float)scd;
+      sh = (float)((double)p.beta[n] - (double)p.rmean[n] * scd);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int o = out_off(r);
+      if (o >= 0) {
+        float v = fmaf(acc[r] + bv, sc, sh);
+        if (p.res != nullptr) v += gload1(p.res + o);
+        if (p.act) v = lrelu(v, p.slope);
+        gstore1(p.out + o, v);
+      }
+    }
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = out_off(r);
+    if (o >= 0) {
+      const float v = acc[r] + bv;
+      gstore1(p.out + o, v);
+      s1 += (double)v;
+      s2 += (double)v * (double)v;
+    }
+  }
+  if (p.stats != nullptr) {
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
+    if (lh == 0 && nok) {
+      double* st = stat_replica(p.stats, t.N, bid);
+      atomic_add_f64(st + n, s1);
+      atomic_add_f64(st + t.N + n, s2);
+    }
+  }
+}
+
 // One 64x64 output tile per 512-thread workgroup: 8 waves = 4 tile quadrants (32x32 MFMA tiles) x 2 K-halves.
 // The two waves that share a quadrant each take half of every 32-wide K slice (two 8-wide groups) and
 // sit on the same SIMD pair-wise, so one wave's global loads / LDS traffic / address arithmetic overlap
 // the other's MFMAs — at batch 512 a layer has only ~256 tiles for 1024 SIMDs, so this is the only way to
 // get two waves per SIMD.  Their partial accumulators are summed once, through LDS, in the epilogue.
+// (Measured and removed, round 2: a 64-wide K-step — half the barriers and LDS round trips per MFMA, 126-128 VGPRs, 70 KB
+// of LDS — is no faster at K = 512 (38.1 us either way) and slower at K = 64 (17-18.6 vs 13.4 us: twice the prologue):
+// the per-slice barrier is not what limits the loop.)
 // MODE: 0 = the A operand is a stored tensor; 1 = HP_CONV_IN_BN; 2 = HP_CONV_IN_DR
 template <bool W_KN, int MODE, bool BF16 = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
@@ -197,11 +351,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   };
   auto fetch = [&](PrefDr& d) -> Pref {
     Pref r;
-    r.a = *reinterpret_cast<const float4*>(pa);
-    r.b = *reinterpret_cast<const float4*>(pb);
+    r.a = gload4(pa);
+    r.b = gload4(pb);
     if (IN_BN) { r.kq = kc * 32 + aq; r.va = ia ? 1.f : 0.f; }
     if (IN_DR) {
-      d.a2 = *reinterpret_cast<const float4*>(pa + draw);
+      d.a2 = gload4(pa + draw);
       d.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;      // where the evaluated dr segment is stored back (nullptr = not)
       r.kq = dtab + kc * 32 + aq; r.va = ia ? 1.f : 0.f;
     }
@@ -223,7 +377,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       r.a.y = bn_dr(r.a.y, d.a2.y, cA.y, cB.y, cC.y) * r.va;
       r.a.z = bn_dr(r.a.z, d.a2.z, cA.z, cB.z, cC.z) * r.va;
       r.a.w = bn_dr(r.a.w, d.a2.w, cA.w, cB.w, cC.w) * r.va;
-      if (d.wb != nullptr) *reinterpret_cast<float4*>(d.wb) = r.a;
+      if (d.wb != nullptr) gstore4(d.wb, r.a);
     }
     if (IN_BN) {
       if (in_bn) {
@@ -273,11 +427,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     if (!W_KN) bf = *reinterpret_cast<const bf16x8*>(Bh + (wn * 32 + li) * kLdaH + kh * 16 + lh * 8);   \
     else       bf = tr_operand(Bh, kLdtH, kh * 16, wn * 32, lane);                                      \
     if (FETCH) {                                                                                        \
-      LD.a = *reinterpret_cast<const float4*>(pa);                                                      \
-      LD.b = *reinterpret_cast<const float4*>(pb);                                                      \
+      LD.a = gload4(pa);                                                                                \
+      LD.b = gload4(pb);                                                                                \
       if (IN_BN) { LD.kq = kc * 32 + aq; LD.va = ia ? 1.f : 0.f; }                                      \
       if (IN_DR) {                                                                                      \
-        D##LD.a2 = *reinterpret_cast<const float4*>(pa + draw);                                         \
+        D##LD.a2 = gload4(pa + draw);                                                                   \
         D##LD.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;                                        \
         LD.kq = dtab + kc * 32 + aq; LD.va = ia ? 1.f : 0.f;                                            \
       }                                                                                                 \
@@ -303,11 +457,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       }                                                                                                 \
     }                                                                                                   \
     if (FETCH) {                                                                                        \
-      LD.a = *reinterpret_cast<const float4*>(pa);                                                      \
-      LD.b = *reinterpret_cast<const float4*>(pb);                                                      \
+      LD.a = gload4(pa);                                                                                \
+      LD.b = gload4(pb);                                                                                \
       if (IN_BN) { LD.kq = kc * 32 + aq; LD.va = ia ? 1.f : 0.f; }                                      \
       if (IN_DR) {                                                                                      \
-        D##LD.a2 = *reinterpret_cast<const float4*>(pa + draw);                                         \
+        D##LD.a2 = gload4(pa + draw);                                                                   \
         D##LD.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;                                        \
         LD.kq = dtab + kc * 32 + aq; LD.va = ia ? 1.f : 0.f;                                            \
       }                                                                                                 \
@@ -401,131 +555,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
 #undef HP_KSTEP
 #undef HP_KSTEP_H
 
-  // sum the two K-halves through LDS (the staging buffers are free after the last barrier)
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = acc2[0][r] + acc2[1][r];
-  float* red = smem + quad * (16 * 64);
-  if (kh == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
-  }
-  __syncthreads();
-  if (kh == 1) return;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
-
-  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  const int n = n0 + wn * 32 + li;
-  const bool nok = n < t.N;
-  // element offset of the output of this lane's GEMM row r (-1 = outside the problem).  out_Lfull > 0: the op
-  // writes a strided subset of the rows of a taller tensor.  (int: every tensor of a program is < 2^31 elements,
-  // checked by hp_program_validate.)
-  auto out_off = [&](int r) -> int {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (!nok || m >= t.M) return -1;
-    int o = m;
-    if (t.out_Lfull > 0) {
-      const int b = m / t.Lout;
-      o = b * t.out_Lfull + t.out_a * (m - b * t.Lout) + t.out_o;
-    }
-    return o * t.N + n;
-  };
-  if (p.epi) {
-    // HP_CONV_EPI_BNRED: HP_OP_BN_BWD_REDUCE on the accumulators (same expressions as bn_bwd_reduce_body)
-    float mean = 0.f, invstd = 0.f, mean2 = 0.f, invstd2 = 0.f, csc = 0.f, csh = 0.f;
-    const bool has_act = p.e_act != nullptr, has_g2 = p.e_g2 != nullptr, has_2 = p.e_raw2 != nullptr;
-    if (nok) {
-      mean = p.e_save[n]; invstd = p.e_save[t.N + n];
-      if (has_2) { mean2 = p.e_save2[n]; invstd2 = p.e_save2[t.N + n]; }
-      if (!has_act) { csc = p.e_coef[n]; csh = p.e_coef[t.N + n]; }
-    }
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {          // two batches of 8 rows: all loads of a batch in flight before the first use
-      int off[8];
-      float xr[8], av[8], g2[8], x2[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        off[q] = out_off(h * 8 + q);
-        const int o = off[q] >= 0 ? off[q] : 0;        // clamped, unconditional
-        xr[q] = p.e_raw[o];
-        av[q] = has_act ? p.e_act[o] : 0.f;
-        g2[q] = has_g2 ? p.e_g2[o] : 0.f;
-        x2[q] = has_2 ? p.e_raw2[o] : 0.f;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (off[q] < 0) continue;
-        float gv = acc[h * 8 + q];
-        if (has_g2) gv += g2[q];
-        const float pre = has_act ? av[q] : fmaf(xr[q], csc, csh);
-        gv *= lrelu_grad(pre, p.e_slope);
-        p.out[off[q]] = gv;
-        s1 += (double)gv;
-        s2 += (double)gv * (double)((xr[q] - mean) * invstd);
-        if (has_2) s3 += (double)gv * (double)((x2[q] - mean2) * invstd2);
-      }
-    }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    s3 += __shfl_xor(s3, 32, 64);
-    if (lh == 0 && nok) {
-      double* b1 = stat_replica(p.e_bs, t.N, bid);
-      atomic_add_f64(b1 + n, s1);
-      atomic_add_f64(b1 + t.N + n, s2);
-      if (has_2) {
-        double* b2 = stat_replica(p.e_bs2, t.N, bid);
-        atomic_add_f64(b2 + n, s1);
-        atomic_add_f64(b2 + t.N + n, s3);
-      }
-    }
-    return;
-  }
-  const float bv = (p.bias != nullptr && nok) ? p.bias[n] : 0.f;
-  if (p.bn_eval) {
-    // forward-only path: BatchNorm1d in eval mode (+ residual, + leaky_relu) applied to the accumulators; the
-    // coefficients are formed exactly as bn_coef() does for HP_OP_BN_APPLY, so the result is bit-identical
-    float sc = 0.f, sh = 0.f;
-    if (nok) {
-      const double invstd = 1.0 / sqrt((double)p.rvar[n] + (double)p.eps);
-      const double scd = (double)p.gamma[n] * invstd;
-      sc = (float)scd;
-      sh = (float)((double)p.beta[n] - (double)p.rmean[n] * scd);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = out_off(r);
-      if (o >= 0) {
-        float v = fmaf(acc[r] + bv, sc, sh);
-        if (p.res != nullptr) v += p.res[o];
-        if (p.act) v = lrelu(v, p.slope);
-        p.out[o] = v;
-      }
-    }
-    return;
-  }
-  double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int o = out_off(r);
-    if (o >= 0) {
-      const float v = acc[r] + bv;
-      p.out[o] = v;
-      s1 += (double)v;
-      s2 += (double)v * (double)v;
-    }
-  }
-  if (p.stats != nullptr) {
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (lh == 0 && nok) {
-      double* st = stat_replica(p.stats, t.N, bid);
-      atomic_add_f64(st + n, s1);
-      atomic_add_f64(st + t.N + n, s2);
-    }
-  }
+  conv_epilogue(p, acc2, smem, bid, m0, n0);
 }
 
 // (amdgpu_waves_per_eu(4): two 512-thread workgroups per CU, i.e. at most 128 VGPRs, for every instantiation)
@@ -644,13 +674,6 @@ struct WgradArgs {
   int atomic;   // 1: accumulate into `slab` (= the zeroed gradient tensor) with fp32 atomics, no slabs
 };
 
-// 16-byte load through the global address space: pointers read from a record in memory are generic to the
-// compiler, and a flat_load also counts against the LDS counter
-typedef float hp_v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 gload4(const float* p) {
-  const hp_v4f v = *(const hp_v4f __attribute__((address_space(1)))*)(p);
-  return make_float4(v.x, v.y, v.z, v.w);
-}
 
 template <int NT, bool BF16 = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, const int split, float* smem) {
