@@ -35,6 +35,7 @@ class _Net:
         self._engines = {}            # (B, with_class) -> Engine
         self._root = None
         self._train_cfg = planner.TrainCfg()
+        self.deterministic = False           # see configure_training
         # Parameters are drawn HERE, at construction, from torch's global CPU generator in the reference constructor's
         # order: `torch.manual_seed(42); ...; wave = hippieUnimodalCVAE(...); time = hippieUnimodalCVAE(...)` consumes
         # the generator exactly as the reference script does (scripts/train_model_with_multimodal.py:78,169-176).  They
@@ -71,6 +72,10 @@ class _Net:
         ZEROED with reset_optimizer=True: a new train module over an existing network owns a fresh
         torch.optim.AdamW in the reference (hippie/model.py:93; the label-free fine-tune stage re-wraps the
         pretrained network, scripts/train_model_with_multimodal.py:263-268)."""
+        # Lightning's Trainer(deterministic=True) / torch.use_deterministic_algorithms(True): the weight gradients are summed
+        # in a fixed order (per-split slabs + ordered reduce) instead of with fp32 atomics — runs become bit-reproducible
+        if (self.deterministic or torch.are_deterministic_algorithms_enabled()) and not train_cfg.deterministic_wgrad:
+            train_cfg = replace(train_cfg, deterministic_wgrad=True)
         self._train_cfg = train_cfg
         keep = self._root
         self._engines = {}

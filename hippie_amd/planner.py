@@ -16,6 +16,8 @@ from __future__ import annotations
 from collections import OrderedDict
 from dataclasses import dataclass
 
+import os
+
 import numpy as np
 
 from . import program as P
@@ -75,6 +77,9 @@ class TrainCfg:
                                         # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
                                         # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
                                         # weights and AdamW stay fp32.  Own tolerance (tests/test_gpu_bf16.py), own bench line
+    reuse_workspace: bool = True        # liveness-based packing of the workspace arena (pack_workspace): tensors that only the backward
+                                        # pass touches share memory once dead, and so do the eval forward's; training-forward tensors
+                                        # (all needed by the backward pass) and named I/O slots keep their own memory
     optimizer: str = "adamw"            # "adamw" (model.py:93) | "schedulefree" (hippie/optimizers.py:18-209)
     warmup_steps: int = 0               # schedule-free only
     sf_r: float = 0.0
@@ -126,6 +131,8 @@ class Plan:
         self._poff = 0
         self._boff = 0
         self._ws = 0
+        self.allocs = []                     # workspace allocations [offset, nbytes, pinned] in allocation order (pack_workspace)
+        self.ws_unpacked = None              # workspace size before pack_workspace (None = not packed)
         self.stats_bytes = 0
         self.act_sites = []                  # leaky-ReLU sites of the training forward (tests read the branches taken back)
         self.slab_need = 0                   # floats
@@ -154,6 +161,8 @@ class Plan:
         self._ws = _round_up(self._ws, ALIGN)
         r = Ref(P.WS, self._ws)
         self._ws += int(nbytes)
+        if nbytes > 0:
+            self.allocs.append([r.offset, int(nbytes), name is not None])
         if name is not None:
             self.io[name] = (r, tuple(shape), dtype)
         return r
@@ -1078,7 +1087,128 @@ class Lowering:
                 r["buf"][2] = slab.encode()
             elif int(r["op"]) == P.SLAB_REDUCE:
                 r["buf"][0] = slab.encode()
+        if self.train.reuse_workspace and not os.environ.get("HIPPIE_NO_WS_REUSE"):     # (the variable: A/B runs of unmodified callers)
+            pack_workspace(pl, serial_backward=not self.train.split_backward)
         return pl
+
+
+def pack_workspace(pl, serial_backward=True):
+    """Liveness-based reuse of the workspace arena (arena colouring over op intervals).
+
+    Two classes of allocations are packed, each into a region of its own: those that only records of the backward pass
+    touch, and those that only records of the eval forward touch.  Inside a class an allocation is live from the first
+    to the last record that names it — counted at the position where the record EXECUTES: members of a WGRAD_GROUP /
+    PAIR / chained launch run at their group record, so the operands of the grouped weight-gradient GEMMs stay live to
+    the end of the backward pass — and two allocations share memory only when one is dead strictly before the other is
+    born.  Everything else (training-forward tensors, which the backward pass reads; named I/O slots; the statistics
+    region; the slabs) keeps memory of its own, so training and eval passes may be interleaved in any order.
+    `serial_backward=False` (the decoder-side weight gradients may run on a second stream under the encoder-side chain)
+    leaves the backward class alone.  Rewrites the records, plan.io and plan.act_sites."""
+    import bisect
+    recs = pl.ops.recs
+    segs = pl.ops.segments
+    allocs = sorted(a for a in pl.allocs if a[1] > 0)
+    starts = [a[0] for a in allocs]
+    mask = (1 << 56) - 1
+
+    def alloc_of(off):
+        j = bisect.bisect_right(starts, off) - 1
+        assert j >= 0 and off < allocs[j][0] + allocs[j][1], f"workspace ref {off} outside every allocation"
+        return j
+
+    # where each record executes
+    at = list(range(len(recs)))
+    for g, r in enumerate(recs):
+        op = int(r["op"])
+        if op == P.WGRAD_GROUP:
+            for k in range(int(r["i"][0]), int(r["i"][0]) + int(r["i"][1])):
+                at[k] = g
+        elif op == P.PAIR:
+            at[int(r["i"][0])] = at[int(r["i"][1])] = g
+        n_chain = (int(r["flags"]) >> P.FLAG_CHAIN_SHIFT) & 0xFF
+        for k in range(g - n_chain, g):
+            at[k] = g
+
+    def seg_of(k):
+        for name in ("fwd_train", "bwd", "opt", "fwd_eval"):
+            if name in segs and segs[name][0] <= k < segs[name][0] + segs[name][1]:
+                return name
+        return "other"
+
+    users = [set() for _ in allocs]
+    span = [[None, None] for _ in allocs]
+    for k, r in enumerate(recs):
+        sname = seg_of(k)
+        for b in r["buf"]:
+            b = int(b)
+            if b == P.NULL or (b >> 56) != P.WS:
+                continue
+            j = alloc_of(b & mask)
+            users[j].add(sname)
+            span[j][0] = at[k] if span[j][0] is None else min(span[j][0], at[k])
+            span[j][1] = at[k] if span[j][1] is None else max(span[j][1], at[k])
+    pinned = [a[2] for a in allocs]
+    for ref, _, _ in pl.io.values():        # named slots are read by the host after the pass
+        if ref.space == P.WS:
+            pinned[alloc_of(ref.offset)] = True
+    for site in pl.act_sites:
+        for key in ("raw", "out", "coef"):
+            ref = site.get(key)
+            if isinstance(ref, Ref) and ref.space == P.WS:
+                pinned[alloc_of(ref.offset)] = True
+    classes = {"bwd": [], "fwd_eval": []}
+    for j in range(len(allocs)):
+        if pinned[j] or len(users[j]) != 1:
+            continue
+        (u,) = users[j]
+        if u == "fwd_eval" or (u == "bwd" and serial_backward):
+            classes[u].append(j)
+
+    new_off = {}
+    top = 0
+    packed = {j for js in classes.values() for j in js}
+    for j, a in enumerate(allocs):          # everything else: one after the other, allocation order
+        if j in packed:
+            continue
+        top = _round_up(top, ALIGN)
+        new_off[j] = top
+        top += a[1]
+    for js in classes.values():
+        base = _round_up(top, ALIGN)
+        live = []                           # (last record, offset, size) of allocations placed so far that may still be live
+        hi = 0
+        for j in sorted(js, key=lambda j: (span[j][0], -allocs[j][1])):
+            live = [x for x in live if x[0] >= span[j][0]]
+            size = _round_up(allocs[j][1], ALIGN)
+            off = 0
+            for _, o, sz in sorted(live, key=lambda x: x[1]):     # first fit over the address-ordered live set
+                if off + size <= o:
+                    break
+                off = max(off, o + sz)
+            new_off[j] = base + off
+            live.append((span[j][1], off, size))
+            hi = max(hi, off + size)
+        top = base + hi
+
+    def remap(off):
+        j = alloc_of(off)
+        return new_off[j] + (off - allocs[j][0])
+
+    for r in recs:
+        for q in range(P.NB):
+            b = int(r["buf"][q])
+            if b != P.NULL and (b >> 56) == P.WS:
+                r["buf"][q] = (P.WS << 56) | remap(b & mask)
+    pl.io = {k: ((Ref(P.WS, remap(ref.offset)) if ref.space == P.WS else ref), shp, dt) for k, (ref, shp, dt) in pl.io.items()}
+    for site in pl.act_sites:
+        for key in ("raw", "out", "coef"):
+            ref = site.get(key)
+            if isinstance(ref, Ref) and ref.space == P.WS:
+                site[key] = Ref(P.WS, remap(ref.offset))
+    pl.stats_base = remap(pl.stats_base)
+    pl.ws_unpacked = pl.ws_bytes
+    pl.allocs = [[new_off[j], a[1], a[2]] for j, a in enumerate(allocs)]
+    pl._ws = top
 
 
 CHAIN_WORK_MAX = 700_000        # per-op work (FMA-equivalents) one 256-thread workgroup may take on inside a chained launch

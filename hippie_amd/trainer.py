@@ -15,11 +15,12 @@ import torch
 class Trainer:
     def __init__(self, max_epochs=1, gradient_clip_val=None, default_root_dir="checkpoints", patience=30,
                  monitor="val_loss", logger_path=None, num_sanity_val_steps=2, device=None, enable_checkpointing=True,
-                 sync_every_step=False):
+                 sync_every_step=False, deterministic=False):
         """sync_every_step: True reproduces the reference's per-step `loss.item()` host sync (hippie/model.py:114) and
         checks labels on the host every step; False (default) keeps the step asynchronous — hipGraph replays, per-step
         losses kept on the device and averaged at the epoch end, label range errors raised at the epoch end."""
         self.sync_every_step = sync_every_step
+        self.deterministic = deterministic      # Lightning's flag: bit-reproducible runs (ordered weight-gradient sums, no fp32 atomics)
         self.max_epochs, self.gradient_clip_val = max_epochs, gradient_clip_val
         self.root, self.patience, self.monitor = default_root_dir, patience, monitor
         self.logger_path = logger_path
@@ -65,6 +66,9 @@ class Trainer:
 
     def fit(self, module, train_dataloaders, val_dataloaders=None):
         module.trainer = self
+        if self.deterministic and not module.model.deterministic:
+            module.model.deterministic = True
+            module._apply_cfg()
         module.set_gradient_clip(self.gradient_clip_val)
         module.sync_every_step = self.sync_every_step
         module.model.label_check = "sync" if self.sync_every_step else "deferred"

@@ -261,10 +261,15 @@ def test_second_optimizer_step_does_not_double_count_the_gradient_norm():
     assert float((ratio - 1.9).abs().max()) < 1e-3, float((ratio - 1.9).abs().max())
 
 
-def test_trainer_async_path_equals_per_step_sync_path(tmp_path):
+@pytest.mark.parametrize("deterministic", [True, False])
+def test_trainer_async_path_equals_per_step_sync_path(tmp_path, deterministic):
     """Trainer.fit default (hipGraph replay, losses kept on the device, label checks deferred to the epoch end) against
     sync_every_step=True (the reference's per-step loss.item(), host-side label check every step) with the module
-    running eagerly: same epoch losses, same parameters."""
+    running eagerly.  deterministic=True (Lightning's flag: ordered weight-gradient sums instead of fp32 atomics): the
+    two paths launch the same kernels in the same order, so epoch losses and every parameter are EQUAL, bit for bit.
+    deterministic=False: the order of the fp32 atomic sums differs from run to run; Adam turns a rounding-level
+    gradient into a +-lr update and the ragged 6-sample batch (BatchNorm over 6 rows) amplifies that to a few 1e-3 of
+    its loss (tools/debug/trainer_noise.py: same spread between two identical runs) — only a loose bound holds."""
     z, L = 10, 50
     om = O.OracleModel("unimodal", z, L, salt=4)
     train = batches(70, 32, L, z, seed=1)          # 32 + 32 + 6: a ragged last batch
@@ -276,16 +281,24 @@ def test_trainer_async_path_equals_per_step_sync_path(tmp_path):
         net.use_graph = not sync
         mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-5, weight_decay=0.01)
         torch.manual_seed(123)                      # the reparameterisation noise comes from the device generator
-        tr = Trainer(max_epochs=2, gradient_clip_val=1.0, enable_checkpointing=False, sync_every_step=sync)
+        tr = Trainer(max_epochs=2, gradient_clip_val=1.0, enable_checkpointing=False, sync_every_step=sync, deterministic=deterministic)
         tr.fit(mod, train, val)
+        assert net._train_cfg.deterministic_wgrad == deterministic
         res.append((tr.history, {k: v.cpu() for k, v in net.state_dict().items()}, mod.last_train_mean, mod.last_val_mean))
     (h0, sd0, t0, v0), (h1, sd1, t1, v1) = res
     assert len(h0) == len(h1) == 2
+    if deterministic:
+        for a, b in zip(h0, h1):
+            # (the per-step values are identical; the sync path averages Python floats, the async path a float64 tensor)
+            np.testing.assert_allclose([a["val_loss"], a["train_loss"]], [b["val_loss"], b["train_loss"]], rtol=1e-12)
+        np.testing.assert_allclose([t0, v0], [t1, v1], rtol=1e-12)
+        for k in sd0:
+            assert torch.equal(sd0[k], sd1[k]), k
+        return
     for a, b in zip(h0, h1):
-        # (two runs differ in the order of their atomic sums; over 6 Adam steps that grows to a few 1e-5 of the loss)
-        np.testing.assert_allclose(a["val_loss"], b["val_loss"], rtol=1e-4)
-        np.testing.assert_allclose(a["train_loss"], b["train_loss"], rtol=1e-4)
-    np.testing.assert_allclose([t0, v0], [t1, v1], rtol=1e-4)
+        np.testing.assert_allclose(a["val_loss"], b["val_loss"], rtol=2e-2)
+        np.testing.assert_allclose(a["train_loss"], b["train_loss"], rtol=2e-2)
+    np.testing.assert_allclose([t0, v0], [t1, v1], rtol=2e-2)
     import re
     for k in sd0:
         if "running_" in k:
