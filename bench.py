@@ -70,6 +70,7 @@ class Pair:
 
     def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False, lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True):
         self.device, self.world, self.paired, self.overlap, self.lockstep = device, world, paired, overlap, lockstep
+        self.only = None          # --only-model: step one of the two models (how much of the pair step is overlap?)
         cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
         tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws),
                planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws)]
@@ -141,6 +142,8 @@ class Pair:
         if self.lockstep:
             self.fork()
         for k, (e, s) in enumerate(zip(self.eng, self.streams)):
+            if self.only is not None and k != self.only:
+                continue
             with torch.cuda.stream(s):
                 e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
                 e.io("src").copy_(data[2].index_select(0, idx), non_blocking=True)
@@ -399,6 +402,7 @@ def main():
     ap.add_argument("--no-reuse-ws", action="store_true", help="every workspace tensor in memory of its own (A/B against the liveness-packed arena)")
     ap.add_argument("--pair", action="store_true", help="one zipped wave+time program (paired launches) instead of two engines on two streams")
     ap.add_argument("--overlap", action="store_true", help="decoder-side wgrad + first gradient bucket on a side stream (measured slower on ROCm 7: DESIGN.md 5.3)")
+    ap.add_argument("--only-model", type=int, choices=(0, 1), default=None, help="diagnostic: step only the wave (0) or the time (1) model; the line is then NOT the headline metric")
     ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -452,6 +456,7 @@ def main():
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
     pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len), overlap=args.overlap, lockstep=args.lockstep,
                 fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws)
+    pair.only = args.only_model
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -523,7 +528,7 @@ def main():
                                     "fp32 arithmetic on f32 MFMA (the reference's arithmetic type; the config's bf16 wording is a separate, labelled mode)")
                        if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
                        f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired, "lockstep": pair.lockstep,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired, "lockstep": pair.lockstep,
                        "final_loss_wave": loss[0], "final_loss_time": loss[1]},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_source": traffic_src,

@@ -131,41 +131,93 @@ constexpr int kConvThreads = 512;
 
 // Shared epilogue of the conv bodies: sums the two K-halves of every quadrant through LDS, then bias / BatchNorm
 // statistics, the eval-mode BatchNorm fold, or the fused BatchNorm-backward reduction.
+#ifndef HP_ABL
+#define HP_ABL 0      // tools/micro/conv_ablate.sh: 1 = return before the epilogue, 2 = every operand load reads the zero page, 4 = no output store,
+#endif                // 8 = 100 MHz timestamps of the first / last workgroup's phases into the (otherwise unused) E_BS buffer
+#if HP_ABL & 8
+#define HP_TS(k)                                                                                  \
+  if (threadIdx.x == 0 && p.e_bs != nullptr) {                                                    \
+    unsigned long long* q_ = reinterpret_cast<unsigned long long*>(p.e_bs);                       \
+    if (bid == 0) { q_[k] = wall_clock64(); q_[16 + (k)] = clock64(); }                           \
+    else if (bid == (int)gridDim.x - 1) q_[8 + (k)] = wall_clock64();                             \
+  }
+#else
+#define HP_TS(k)
+#endif
+// Column sums of the four waves that share 32 output columns (two row halves x two K-half owners) are folded in LDS
+// and leave the workgroup as ONE fp64 atomic per column and statistic (a quarter of the atomics of per-wave adds).
+// `v[k]` = this lane's partial of statistic k (rows of both lane halves already folded), meaningful on lanes < 32.
+template <int NS>
+__device__ __forceinline__ void fold_column_stats(double (&v)[NS], double* sred, const int wave, const int lane) {
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sred[(wave * NS + k) * 32 + lane] = v[k];
+  }
+  __syncthreads();
+  // waves 0 and 1 (row half 0, K-half owner 0; column halves 0 and 1) add the partials of waves w, w+2, w+4, w+6
+  if (wave < 2 && lane < 32) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      v[k] = ((sred[(wave * NS + k) * 32 + lane] + sred[((wave + 4) * NS + k) * 32 + lane]) +
+              (sred[((wave + 2) * NS + k) * 32 + lane] + sred[((wave + 6) * NS + k) * 32 + lane]));
+  }
+}
+
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[2], float* smem, const int bid, const int m0, const int n0) {
   const TapMap& t = p.t;
+  if ((HP_ABL & 1) && t.M >= 0) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = wave & 3, kh = wave >> 2;
   const int wm = quad >> 1, wn = quad & 1, li = lane & 31, lh = lane >> 5;
-  // sum the two K-halves through LDS (the staging buffers are free after the last barrier)
+  // The two K-half waves of a quadrant each FINISH eight of its sixteen accumulator rows: wave kh keeps accumulators
+  // 8*kh .. 8*kh+7, hands the other eight to its partner through LDS (the staging buffers are free after the last
+  // barrier) and adds what the partner left — the epilogue's ~20 dependent instructions per row then run on two waves
+  // per SIMD instead of one (a lone wave per SIMD issues them back to back with nothing to hide their latency:
+  // measured 3.0 us of a launch, tools/micro/conv_phases.py).  a + b == b + a: the sums are the ones a single owner forms.
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = acc2[0][r] + acc2[1][r];
-  float* red = smem + quad * (16 * 64);
-  if (kh == 1) {
+  float* mine = smem + (quad * 2 + kh) * (8 * 64);
+  float* theirs = smem + (quad * 2 + (kh ^ 1)) * (8 * 64);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[r];
-  }
+  for (int j = 0; j < 8; ++j) theirs[j * 64 + lane] = kh ? acc[j] : acc[8 + j];
   __syncthreads();
-  if (kh == 1) return;
+  float own[8];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] += red[r * 64 + lane];
+  for (int j = 0; j < 8; ++j) own[j] = (kh ? acc[8 + j] : acc[j]) + mine[j * 64 + lane];
+  double* sred = reinterpret_cast<double*>(smem + 8 * 8 * 64);      // behind the exchange area (fold_column_stats)
+  HP_TS(3)
 
-  // epilogue: C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) with r = 8*kh + j
   const int n = n0 + wn * 32 + li;
   const bool nok = n < t.N;
-  // element offset of the output of this lane's GEMM row r (-1 = outside the problem).  out_Lfull > 0: the op
-  // writes a strided subset of the rows of a taller tensor.  (int: every tensor of a program is < 2^31 elements,
-  // checked by hp_program_validate.)
-  auto out_off = [&](int r) -> int {
-    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-    if (!nok || m >= t.M) return -1;
-    int o = m;
-    if (t.out_Lfull > 0) {
-      const int b = m / t.Lout;
-      o = b * t.out_Lfull + t.out_a * (m - b * t.Lout) + t.out_o;
+  const int mrow = m0 + wm * 32 + 16 * kh + 4 * lh;              // + (j&3) + 8*(j>>2)
+  // element offset of the output of this lane's row j (-1 = outside the problem).  out_Lfull > 0: the op writes a
+  // strided subset of the rows of a taller tensor.  (int: every tensor of a program is < 2^31 elements, checked by
+  // hp_program_validate.)  A workgroup whose tile lies inside the problem (all but the last row / column of tiles)
+  // takes the unguarded form: no per-row exec-mask juggling.
+  const bool full = m0 + 64 <= t.M && n0 + 64 <= t.N && t.out_Lfull == 0;
+  int off[8];
+  if (full) {
+    const int base = mrow * t.N + n;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) off[j] = base + ((j & 3) + 8 * (j >> 2)) * t.N;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int m = mrow + (j & 3) + 8 * (j >> 2);
+      int o = -1;
+      if (nok && m < t.M) {
+        o = m;
+        if (t.out_Lfull > 0) {
+          const int b = m / t.Lout;
+          o = b * t.out_Lfull + t.out_a * (m - b * t.Lout) + t.out_o;
+        }
+        o = o * t.N + n;
+      }
+      off[j] = o;
     }
-    return o * t.N + n;
-  };
+  }
   if (p.epi) {
     // HP_CONV_EPI_BNRED: HP_OP_BN_BWD_REDUCE on the accumulators (same expressions as bn_bwd_reduce_body)
     float mean = 0.f, invstd = 0.f, mean2 = 0.f, invstd2 = 0.f, csc = 0.f, csh = 0.f;
@@ -175,45 +227,40 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
       if (has_2) { mean2 = p.e_save2[n]; invstd2 = p.e_save2[t.N + n]; }
       if (!has_act) { csc = p.e_coef[n]; csh = p.e_coef[t.N + n]; }
     }
-    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double s[3] = {0.0, 0.0, 0.0};
+    float xr[8], av[8], g2[8], x2[8];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {          // two batches of 8 rows: all loads of a batch in flight before the first use
-      int off[8];
-      float xr[8], av[8], g2[8], x2[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        off[q] = out_off(h * 8 + q);
-        const int o = off[q] >= 0 ? off[q] : 0;        // clamped, unconditional
-        xr[q] = gload1(p.e_raw + o);
-        av[q] = has_act ? gload1(p.e_act + o) : 0.f;
-        g2[q] = has_g2 ? gload1(p.e_g2 + o) : 0.f;
-        x2[q] = has_2 ? gload1(p.e_raw2 + o) : 0.f;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        if (off[q] < 0) continue;
-        float gv = acc[h * 8 + q];
-        if (has_g2) gv += g2[q];
-        const float pre = has_act ? av[q] : fmaf(xr[q], csc, csh);
-        gv *= lrelu_grad(pre, p.e_slope);
-        gstore1(p.out + off[q], gv);
-        s1 += (double)gv;
-        s2 += (double)gv * (double)((xr[q] - mean) * invstd);
-        if (has_2) s3 += (double)gv * (double)((x2[q] - mean2) * invstd2);
-      }
+    for (int j = 0; j < 8; ++j) {          // all loads in flight before the first use
+      const int o = off[j] >= 0 ? off[j] : 0;          // clamped, unconditional
+      xr[j] = gload1(p.e_raw + o);
+      av[j] = has_act ? gload1(p.e_act + o) : 0.f;
+      g2[j] = has_g2 ? gload1(p.e_g2 + o) : 0.f;
+      x2[j] = has_2 ? gload1(p.e_raw2 + o) : 0.f;
     }
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    s3 += __shfl_xor(s3, 32, 64);
-    if (lh == 0 && nok) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!full && off[j] < 0) continue;
+      float gv = own[j];
+      if (has_g2) gv += g2[j];
+      const float pre = has_act ? av[j] : fmaf(xr[j], csc, csh);
+      gv *= lrelu_grad(pre, p.e_slope);
+      gstore1(p.out + off[j], gv);
+      s[0] += (double)gv;
+      s[1] += (double)gv * (double)((xr[j] - mean) * invstd);
+      if (has_2) s[2] += (double)gv * (double)((x2[j] - mean2) * invstd2);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] += __shfl_xor(s[k], 32, 64);
+    fold_column_stats<3>(s, sred, wave, lane);
+    if (wave < 2 && lane < 32 && nok) {
       double* b1 = stat_replica(p.e_bs, t.N, bid);
-      atomic_add_f64(b1 + n, s1);
-      atomic_add_f64(b1 + t.N + n, s2);
+      atomic_add_f64(b1 + n, s[0]);
+      atomic_add_f64(b1 + t.N + n, s[1]);
       if (has_2) {
         double* b2 = stat_replica(p.e_bs2, t.N, bid);
-        atomic_add_f64(b2 + n, s1);
-        atomic_add_f64(b2 + t.N + n, s3);
+        atomic_add_f64(b2 + n, s[0]);
+        atomic_add_f64(b2 + t.N + n, s[2]);
       }
     }
     return;
@@ -229,36 +276,37 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
       sc = (float)scd;
       sh = (float)((double)p.beta[n] - (double)p.rmean[n] * scd);
     }
+    float rs[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int o = out_off(r);
-      if (o >= 0) {
-        float v = fmaf(acc[r] + bv, sc, sh);
-        if (p.res != nullptr) v += gload1(p.res + o);
-        if (p.act) v = lrelu(v, p.slope);
-        gstore1(p.out + o, v);
-      }
+    for (int j = 0; j < 8; ++j) rs[j] = p.res != nullptr ? gload1(p.res + (off[j] >= 0 ? off[j] : 0)) : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!full && off[j] < 0) continue;
+      float v = fmaf(own[j] + bv, sc, sh);
+      if (p.res != nullptr) v += rs[j];
+      if (p.act) v = lrelu(v, p.slope);
+      gstore1(p.out + off[j], v);
     }
     return;
   }
-  double s1 = 0.0, s2 = 0.0;
+  double s[2] = {0.0, 0.0};
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int o = out_off(r);
-    if (o >= 0) {
-      const float v = acc[r] + bv;
-      gstore1(p.out + o, v);
-      s1 += (double)v;
-      s2 += (double)v * (double)v;
-    }
+  for (int j = 0; j < 8; ++j) {
+    if (!full && off[j] < 0) continue;
+    const float v = own[j] + bv;
+    if (!((HP_ABL & 4) && t.M >= 0)) gstore1(p.out + off[j], v);
+    s[0] += (double)v;
+    s[1] += (double)v * (double)v;
   }
+  HP_TS(4)
   if (p.stats != nullptr) {
-    s1 += __shfl_xor(s1, 32, 64);
-    s2 += __shfl_xor(s2, 32, 64);
-    if (lh == 0 && nok) {
+    s[0] += __shfl_xor(s[0], 32, 64);
+    s[1] += __shfl_xor(s[1], 32, 64);
+    fold_column_stats<2>(s, sred, wave, lane);
+    if (wave < 2 && lane < 32 && nok) {
       double* st = stat_replica(p.stats, t.N, bid);
-      atomic_add_f64(st + n, s1);
-      atomic_add_f64(st + t.N + n, s2);
+      atomic_add_f64(st + n, s[0]);
+      atomic_add_f64(st + t.N + n, s[1]);
     }
   }
 }
@@ -280,6 +328,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   constexpr int TILE = 64 * LDA;   // 2304 floats; the [32][68] image (2176) fits too
 
   const TapMap& t = p.t;
+  HP_TS(0)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int quad = wave & 3, kh = wave >> 2;
   const int wm = quad >> 1, wn = quad & 1, li = lane & 31, lh = lane >> 5;
@@ -291,7 +340,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   const int ar = tid >> 3, aq = (tid & 7) << 2;
   const int kr = tid >> 4, nq = (tid & 15) << 2;   // [k][n] weight image slot
   const int m_row = m0 + ar;
-  const bool rvalid = m_row < t.M;
+  const bool rvalid = m_row < t.M && !((HP_ABL & 2) && t.M >= 0);
   const int b_row = m_row / t.Lout;
   const int rbase = b_row * t.Lin;
   const int rl = t.a * (m_row - b_row * t.Lout);
@@ -332,11 +381,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     }
     bool ob;
     if (!W_KN) {
-      ob = n0 + ar < t.N;
+      ob = n0 + ar < t.N && !((HP_ABL & 2) && t.M >= 0);
       pb = ob ? wp + (size_t)(n0 + ar) * t.K + aq : hp_zero16;
       ib = ob ? 32 : 0;
     } else {
-      ob = n0 + nq < t.N;
+      ob = n0 + nq < t.N && !((HP_ABL & 2) && t.M >= 0);
       pb = ob ? wp + (size_t)kr * t.N + n0 + nq : hp_zero16;
       ib = ob ? 32 * t.N : 0;
     }
@@ -518,6 +567,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   Pref setB = setA;
   DsetB = DsetA;
   __syncthreads();
+  HP_TS(1)
   int s = 0;
   if (BF16) {
     for (; s + 3 < nsteps; s += 2) {
@@ -555,6 +605,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
 #undef HP_KSTEP
 #undef HP_KSTEP_H
 
+  HP_TS(2)
   conv_epilogue(p, acc2, smem, bid, m0, n0);
 }
 

@@ -131,7 +131,7 @@ class OpList:
 # ---- shared library ---------------------------------------------------------------
 _LIB = None
 ABI_VERSION = 3          # include/hippie_hip.h: HP_ABI_VERSION
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")
+LIB_PATH = os.environ.get("HIPPIE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")   # (the variable: kernel-variant experiments)
 
 EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",
            "hp_program_validate", "hp_program_run", "hp_program_capture", "hp_program_replay", "hp_program_profile",

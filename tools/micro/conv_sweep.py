@@ -50,7 +50,34 @@ def time_op(tm, flags, ntapslab, reps=REP):
     return best
 
 
+def time_null(reps=REP):
+    """the floor: a chain of dependent launches that do (almost) nothing — HP_OP_ZERO of 16 bytes"""
+    ol = P.OpList()
+    for _ in range(reps):
+        ol.add(P.ZERO, 0, [16, 0], (), [Ref(P.WS, 0)])
+    dev = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    prog = P.DeviceProgram(ol.array(), [dev.data_ptr()] + [0] * 5, [dev.numel(), 4, 4, 4, 4, 4])
+    seg = prog.capture(0, reps)
+    s = torch.cuda.current_stream().cuda_stream
+    prog.replay(seg, s)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(5):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        prog.replay(seg, s)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) * 1e3 / reps)
+    prog.close()
+    return best
+
+
 def main():
+    print(f"chain of dependent 16-byte ZERO launches in a graph: {time_null():.2f} us per launch", flush=True)
+    for nt, K in ((1, 32), (1, 64)):
+        tm = TapMap(512 * 4, 512, K, 4, 4, 4, 1, 0, [(0, 0)] * nt)
+        print(f"conv M=2048 N=512 K={K} taps={nt} ({nt * K // 32} K-steps): {time_op(tm, 0, 1):.2f} us", flush=True)
     shapes = {
         "L4  M=2048  N=512 K=512": (512, 4, 512, 512),
         "L3  M=3584  N=256 K=256": (512, 7, 256, 256),
