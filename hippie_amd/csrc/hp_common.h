@@ -105,7 +105,11 @@ __device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* st
     mean = (double)k.rm;
     var = (double)k.rv;
   }
+#ifdef HP_BN_FAST_RSQ      // timing experiment only (tools/micro/bn_sweep.py): how much of BN_APPLY is the fp64 sqrt + divide?
+  const double invstd = (double)rsqrtf((float)(var + (double)eps));
+#else
   const double invstd = 1.0 / sqrt(var + (double)eps);
+#endif
   const double sc = (double)g * invstd;
   k.mean = (float)mean; k.invstd = (float)invstd; k.var = var;
   k.scale = (float)sc; k.shift = (float)((double)b - mean * sc);

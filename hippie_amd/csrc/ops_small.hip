@@ -91,7 +91,11 @@ inline dim3 colgrid_v(int M, int C, int rpl) {
   const int cw = cg < 256 ? cg : 256;
   return dim3(hp::cdiv(M, (256 / cw) * rpl), hp::cdiv(cg, cw));
 }
-constexpr int rpl_of(int V) { return V == 4 ? 4 : kRowsPerLane; }
+#ifndef HP_BN_ROWS
+#define HP_BN_ROWS 4       // rows per thread of the float4 BatchNorm passes (tools/micro/bn_sweep.py builds 1 / 2 / 4 / 8)
+#endif
+constexpr int kBnRows = HP_BN_ROWS;
+constexpr int rpl_of(int V) { return V == 4 ? kBnRows : kRowsPerLane; }
 
 // fold NV partials per thread over the row lanes (thread index layout of colmap_v)
 template <int NV>
@@ -120,29 +124,33 @@ struct BnApplyArgs {
   float slope, eps, momentum;
 };
 
-template <int V>
-__device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
+#ifdef HP_BN_TS       // timing experiment (tools/micro/bn_phases.py): 100 MHz timestamps of block 0 / the last block into SAVE2
+#define BN_TS(k) if (threadIdx.x == 0 && p.save2 != nullptr && by == 0) { unsigned long long* q_ = (unsigned long long*)p.save2; \
+    if (bx == 0) q_[k] = wall_clock64(); else if (bx == (int)gridDim.x - 1) q_[8 + (k)] = wall_clock64(); }
+#else
+#define BN_TS(k)
+#endif
+// RES (= BnApplyArgs::res_mode) is a template parameter: with the residual forms as run-time branches the compiler
+// re-read the coefficients from LDS for every row and waited for each row's STORE before touching the next row
+// (vmcnt(0) per row: 1.4 us of serialised store latency per launch, tools/micro/bn_phases.py).
+template <int V, int RES>
+__device__ __forceinline__ void bn_apply_impl(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
+  BN_TS(0)
   const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
-  // The kernel is latency-bound (one round trip for the statistics, one for the rows): issue the row loads
-  // first so both round trips overlap.  (V = 4: exactly rpl_of(4) = 4 rows per thread.)
-  constexpr int NR = V == 4 ? 4 : 1;
+  // The kernel is latency-bound (one round trip for the statistics, one for the rows): issue the row loads first so
+  // both round trips overlap.  UNCONDITIONAL loads (row / column clamped into the tensor; only the stores are
+  // guarded): every row of the thread is in flight at once.  (V = 4: exactly rpl_of(4) rows per thread.)
+  constexpr int NR = V == 4 ? kBnRows : 1;
   T xs[NR], rs[NR];
   if (V == 4) {
+    const int cc = m.active ? m.c : 0;
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
-      const int r = m.row + k * m.rstep;
-      if (m.active && r < m.rend) {
-        const size_t idx = (size_t)r * p.C + m.c;
-        xs[k] = *reinterpret_cast<const T*>(p.raw + idx);
-      }
-    }
-    if (p.res_mode != 0) {
-#pragma unroll
-      for (int k = 0; k < NR; ++k) {
-        const int r = m.row + k * m.rstep;
-        if (m.active && r < m.rend) rs[k] = *reinterpret_cast<const T*>(p.res + (size_t)r * p.C + m.c);
-      }
+      const int r = min(m.row + k * m.rstep, p.M - 1);
+      const size_t idx = (size_t)r * p.C + cc;
+      xs[k] = *reinterpret_cast<const T*>(p.raw + idx);
+      if (RES != 0) rs[k] = *reinterpret_cast<const T*>(p.res + idx);
     }
   }
   // each channel's (replicated) statistics are summed ONCE per block, not once per thread
@@ -152,51 +160,64 @@ __device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx
     const BnCoef k = bn_coef(p.training, p.Mstat, p.stats, p.C, c, p.gamma, p.beta, p.rmean, p.rvar, p.eps);
     s_coef[0][ci] = k.scale; s_coef[1][ci] = k.shift;
     BnCoef k2 = k;
-    if (p.res_mode == 2) {
+    if (RES == 2) {
       k2 = bn_coef(p.training, p.Mstat, p.stats2, p.C, c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
       s_coef[2][ci] = k2.scale; s_coef[3][ci] = k2.shift;
     }
     if (p.training && bx == 0) {
       bn_side_effects(k, p.Mstat, p.C, c, p.save, p.rmean, p.rvar, p.momentum);
-      if (p.res_mode == 2) bn_side_effects(k2, p.Mstat, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
+      if (RES == 2) bn_side_effects(k2, p.Mstat, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
     }
   }
+  BN_TS(1)
   __syncthreads();
+  BN_TS(2)
   if (!m.active) return;
   const int ci0 = (threadIdx.x - m.rlane * m.cw) * V;
   float sc[V], sh[V], sc2[V], sh2[V];
 #pragma unroll
   for (int j = 0; j < V; ++j) {
     sc[j] = s_coef[0][ci0 + j]; sh[j] = s_coef[1][ci0 + j];
-    sc2[j] = p.res_mode == 2 ? s_coef[2][ci0 + j] : 0.f; sh2[j] = p.res_mode == 2 ? s_coef[3][ci0 + j] : 0.f;
+    sc2[j] = RES == 2 ? s_coef[2][ci0 + j] : 0.f; sh2[j] = RES == 2 ? s_coef[3][ci0 + j] : 0.f;
   }
-  auto apply = [&](T x, T rsd, size_t idx) {
+  const bool act = p.act;
+  const float slope = p.slope;
+  auto value = [&](T x, T rsd) -> T {
     T o;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       float v = fmaf(at<V>(x, j), sc[j], sh[j]);
-      if (p.res_mode == 1) v += at<V>(rsd, j);
-      else if (p.res_mode == 2) v += fmaf(at<V>(rsd, j), sc2[j], sh2[j]);
-      if (p.act) v = lrelu(v, p.slope);
-      at<V>(o, j) = v;
+      if (RES == 1) v += at<V>(rsd, j);
+      else if (RES == 2) v += fmaf(at<V>(rsd, j), sc2[j], sh2[j]);
+      at<V>(o, j) = act ? lrelu(v, slope) : v;
     }
-    *reinterpret_cast<T*>(p.out + idx) = o;
+    return o;
   };
   if (V == 4) {
+    T os[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) os[k] = value(xs[k], rs[k]);
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const int r = m.row + k * m.rstep;
-      if (r < m.rend) apply(xs[k], rs[k], (size_t)r * p.C + m.c);
+      if (r < m.rend) *reinterpret_cast<T*>(p.out + (size_t)r * p.C + m.c) = os[k];
     }
+    BN_TS(3)
     return;
   }
   for (int r = m.row; r < m.rend; r += m.rstep) {
     const size_t idx = (size_t)r * p.C + m.c;
     T x = *reinterpret_cast<const T*>(p.raw + idx);
     T rsd = x;
-    if (p.res_mode != 0) rsd = *reinterpret_cast<const T*>(p.res + idx);
-    apply(x, rsd, idx);
+    if (RES != 0) rsd = *reinterpret_cast<const T*>(p.res + idx);
+    *reinterpret_cast<T*>(p.out + idx) = value(x, rsd);
   }
+}
+template <int V>
+__device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
+  if (p.res_mode == 0) bn_apply_impl<V, 0>(p, bx, by, s_coef);
+  else if (p.res_mode == 1) bn_apply_impl<V, 1>(p, bx, by, s_coef);
+  else bn_apply_impl<V, 2>(p, bx, by, s_coef);
 }
 // single and paired launch forms (HP_OP_PAIR: two independent ops, one launch, flattened 2-D grids)
 #define HP_BN_KERNELS(NAME, ARGS, SHARED_DECL, SHARED_ARG)                                                        \
@@ -254,7 +275,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
     };
     if (V == 4) {
       // exactly rpl_of(4) = 4 rows per thread: all loads of all rows in flight before the first use
-      constexpr int NR = 4;
+      constexpr int NR = kBnRows;
       T g[NR], a[NR], x[NR], gg[NR], x2[NR];
       // unconditional loads from a clamped row (so that they form one straight-line batch), then a scheduling
       // barrier: otherwise the compiler folds each row's mask computation into its load block and the four
@@ -331,7 +352,7 @@ template <int V>
 __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
   const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
-  constexpr int NR = V == 4 ? 4 : 1;          // row loads first: overlaps the statistics round trip (see bn_apply_body)
+  constexpr int NR = V == 4 ? kBnRows : 1;          // row loads first: overlaps the statistics round trip (see bn_apply_body)
   T xs[NR], gs[NR];
   if (V == 4) {
 #pragma unroll
