@@ -95,22 +95,34 @@ inline dim3 colgrid_v(int M, int C, int rpl) {
 #define HP_BN_ROWS 4       // rows per thread of the float4 BatchNorm passes (tools/micro/bn_sweep.py builds 1 / 2 / 4 / 8)
 #endif
 constexpr int kBnRows = HP_BN_ROWS;
-constexpr int rpl_of(int V) { return V == 4 ? kBnRows : kRowsPerLane; }
+// rows per thread of a BatchNorm pass over an [M][C] tensor: the float4 form takes exactly kBnRows; the scalar form (C not a
+// multiple of 4: the heads' z_dim-wide BatchNorms) up to kRowsPerLane, fewer on short tensors so that ~64 workgroups exist
+// (a [512][10] tensor used to be 2 workgroups walking 16 dependent rows per thread)
+template <int V> __host__ __device__ inline int bn_rows(int M, int C) {
+  if (V == 4) return kBnRows;
+  const int cw = C < 256 ? C : 256, rl = 256 / cw;
+  const int want = (M + rl * 64 - 1) / (rl * 64);
+  return want < 1 ? 1 : (want > kRowsPerLane ? kRowsPerLane : want);
+}
 
-// fold NV partials per thread over the row lanes (thread index layout of colmap_v)
+// fold NV partials per thread over the row lanes (thread index layout of colmap_v): every (statistic, column) pair is
+// summed by a thread of its own, in row-lane order (a column group of 5 threads used to walk 12 x 51 LDS values each)
 template <int NV>
 __device__ __forceinline__ void fold_rows(const ColMap& m, double (&v)[NV], double* lds /* [NV][256] */) {
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < NV; ++k) lds[k * 256 + threadIdx.x] = m.active ? v[k] : 0.0;
   __syncthreads();
+  for (int t = threadIdx.x; t < NV * m.cw; t += 256) {
+    const int k = t / m.cw, cl = t - k * m.cw;
+    double s = 0.0;
+    for (int r = 0; r < m.rl; ++r) s += lds[k * 256 + r * m.cw + cl];
+    lds[k * 256 + cl] = s;          // row lane 0's slot: nobody else reads it
+  }
+  __syncthreads();
   if (m.active && m.rlane == 0) {
 #pragma unroll
-    for (int k = 0; k < NV; ++k) {
-      double s = 0.0;
-      for (int r = 0; r < m.rl; ++r) s += lds[k * 256 + r * m.cw + threadIdx.x];
-      v[k] = s;
-    }
+    for (int k = 0; k < NV; ++k) v[k] = lds[k * 256 + threadIdx.x];
   }
 }
 
@@ -137,10 +149,10 @@ template <int V, int RES>
 __device__ __forceinline__ void bn_apply_impl(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
   BN_TS(0)
-  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
+  const ColMap m = colmap_v<V>(p.M, p.C, bn_rows<V>(p.M, p.C), bx, by);
   // The kernel is latency-bound (one round trip for the statistics, one for the rows): issue the row loads first so
   // both round trips overlap.  UNCONDITIONAL loads (row / column clamped into the tensor; only the stores are
-  // guarded): every row of the thread is in flight at once.  (V = 4: exactly rpl_of(4) rows per thread.)
+  // guarded): every row of the thread is in flight at once.  (V = 4: exactly kBnRows rows per thread.)
   constexpr int NR = V == 4 ? kBnRows : 1;
   T xs[NR], rs[NR];
   if (V == 4) {
@@ -240,13 +252,30 @@ struct BnBwdReduceArgs {
   const float* raw2; const float* save2; double* bs2;
   const float* coef;     // act == nullptr: the activation was never stored; its sign is that of fma(raw, scale, shift)
   int M, C, has_second;
+  int rpl;               // rows per thread (bn_red_rpl): sets the grid and the number of atomic adds per statistics replica
   float slope;
 };
+// Rows per thread of HP_OP_BN_BWD_REDUCE.  Every workgroup ends in one fp64 atomic per column and statistic; with
+// 8 rows per workgroup a [2048][512] tensor sent 128 adds to each replica address (2 replicas at C = 512) and the
+// kernel took 16.8 us against 7.6 us at C = 64.  Taller workgroups (up to 8 batches of rows per thread) until at most
+// ~32 workgroups share a replica, as long as at least 64 workgroups remain.
+inline int bn_red_rpl(int M, int C) {
+  if (C % 4 != 0) return bn_rows<1>(M, C);
+  const int cg = C / 4, cw = cg < 256 ? cg : 256, rl = 256 / cw, groups = hp::cdiv(cg, cw);
+  const int R = hp_stat_repl(C);
+  int nb = 1;
+  while (nb < 8) {
+    if (hp::cdiv(M, rl * kBnRows * nb) <= 32 * R) break;
+    if (hp::cdiv(M, rl * kBnRows * nb * 2) * groups < 64) break;
+    nb *= 2;
+  }
+  return kBnRows * nb;
+}
 
 template <int V>
 __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, const int bx, const int by, double* lds) {
   using T = typename Vec<V>::T;
-  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
+  const ColMap m = colmap_v<V>(p.M, p.C, p.rpl, bx, by);
   double v[3 * V];
 #pragma unroll
   for (int j = 0; j < 3 * V; ++j) v[j] = 0.0;
@@ -274,18 +303,18 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
       *reinterpret_cast<T*>(p.gout + idx) = g;
     };
     if (V == 4) {
-      // exactly rpl_of(4) = 4 rows per thread: all loads of all rows in flight before the first use
+      // batches of kBnRows rows per thread (p.rpl / kBnRows of them): all loads of a batch in flight before the first use
       constexpr int NR = kBnRows;
       T g[NR], a[NR], x[NR], gg[NR], x2[NR];
       // unconditional loads from a clamped row (so that they form one straight-line batch), then a scheduling
       // barrier: otherwise the compiler folds each row's mask computation into its load block and the four
       // rows become four dependent round trips
       const int rlast = m.rend - 1;
-      if (m.row <= rlast) {
+      for (int r0 = m.row; r0 <= rlast; r0 += NR * m.rstep) {
         size_t idx[NR];
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          idx[k] = (size_t)min(m.row + k * m.rstep, rlast) * p.C + m.c;
+          idx[k] = (size_t)min(r0 + k * m.rstep, rlast) * p.C + m.c;
           g[k] = *reinterpret_cast<const T*>(p.g1 + idx[k]);
           x[k] = *reinterpret_cast<const T*>(p.raw + idx[k]);
         }
@@ -304,7 +333,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
-          const int r = m.row + k * m.rstep;
+          const int r = r0 + k * m.rstep;
           if (r <= rlast) accumulate(g[k], a[k], x[k], gg[k], x2[k], (size_t)r * p.C + m.c);
         }
       }
@@ -351,7 +380,7 @@ struct BnBwdApplyArgs {
 template <int V>
 __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
-  const ColMap m = colmap_v<V>(p.M, p.C, rpl_of(V), bx, by);
+  const ColMap m = colmap_v<V>(p.M, p.C, bn_rows<V>(p.M, p.C), bx, by);
   constexpr int NR = V == 4 ? kBnRows : 1;          // row loads first: overlaps the statistics round trip (see bn_apply_body)
   T xs[NR], gs[NR];
   if (V == 4) {
@@ -1015,6 +1044,7 @@ BnBwdReduceArgs bn_bwd_reduce_args(const HpOp& op, void* const* bases) {
   a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
   a.coef = ptr<const float>(op, 10, bases);
   a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
+  a.rpl = bn_red_rpl(a.M, a.C);
   return a;
 }
 BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
@@ -1058,21 +1088,21 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
     case HP_OP_BN_APPLY: {
       e.a.bn_apply = bn_apply_args(op, bases);
       e.variant = e.a.bn_apply.C % 4 == 0 ? 4 : 1;
-      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_apply.M, e.a.bn_apply.C, rpl_of(4)) : colgrid_v<1>(e.a.bn_apply.M, e.a.bn_apply.C, rpl_of(1));
+      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_apply.M, e.a.bn_apply.C, bn_rows<4>(e.a.bn_apply.M, e.a.bn_apply.C)) : colgrid_v<1>(e.a.bn_apply.M, e.a.bn_apply.C, bn_rows<1>(e.a.bn_apply.M, e.a.bn_apply.C));
       e.gx = g.x; e.gy = g.y;
       return true;
     }
     case HP_OP_BN_BWD_REDUCE: {
       e.a.bn_red = bn_bwd_reduce_args(op, bases);
       e.variant = e.a.bn_red.C % 4 == 0 ? 4 : 1;
-      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_red.M, e.a.bn_red.C, rpl_of(4)) : colgrid_v<1>(e.a.bn_red.M, e.a.bn_red.C, rpl_of(1));
+      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_red.M, e.a.bn_red.C, e.a.bn_red.rpl) : colgrid_v<1>(e.a.bn_red.M, e.a.bn_red.C, e.a.bn_red.rpl);
       e.gx = g.x; e.gy = g.y;
       return true;
     }
     case HP_OP_BN_BWD_APPLY: {
       e.a.bn_bapply = bn_bwd_apply_args(op, bases);
       e.variant = e.a.bn_bapply.C % 4 == 0 ? 4 : 1;
-      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_bapply.M, e.a.bn_bapply.C, rpl_of(4)) : colgrid_v<1>(e.a.bn_bapply.M, e.a.bn_bapply.C, rpl_of(1));
+      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_bapply.M, e.a.bn_bapply.C, bn_rows<4>(e.a.bn_bapply.M, e.a.bn_bapply.C)) : colgrid_v<1>(e.a.bn_bapply.M, e.a.bn_bapply.C, bn_rows<1>(e.a.bn_bapply.M, e.a.bn_bapply.C));
       e.gx = g.x; e.gy = g.y;
       return true;
     }
@@ -1220,6 +1250,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const SmallEntry* __restrict
 
 }  // namespace
 
+template <int V> inline int rows_per_thread(const BnApplyArgs& a) { return bn_rows<V>(a.M, a.C); }
+template <int V> inline int rows_per_thread(const BnBwdApplyArgs& a) { return bn_rows<V>(a.M, a.C); }
+template <int V> inline int rows_per_thread(const BnBwdReduceArgs& a) { return a.rpl; }
 // one launch for two independent BatchNorm-family ops of the same opcode and vector width
 #define HP_PAIR_CASE(OPCODE, NAME, ARGFN)                                                                       \
   case OPCODE: {                                                                                                \
@@ -1227,11 +1260,11 @@ __global__ __launch_bounds__(256) void chain_kernel(const SmallEntry* __restrict
     const auto b = ARGFN(opb, bases);                                                                           \
     if ((a.C % 4 == 0) != (b.C % 4 == 0)) return hipErrorInvalidValue;                                          \
     if (a.C % 4 == 0) {                                                                                         \
-      const dim3 ga = colgrid_v<4>(a.M, a.C, rpl_of(4)), gb = colgrid_v<4>(b.M, b.C, rpl_of(4));                \
+      const dim3 ga = colgrid_v<4>(a.M, a.C, rows_per_thread<4>(a)), gb = colgrid_v<4>(b.M, b.C, rows_per_thread<4>(b)); \
       hipLaunchKernelGGL(NAME##_pair_kernel<4>, dim3(ga.x * ga.y + gb.x * gb.y), dim3(256), 0, s, a, b,         \
                          (int)ga.x, (int)(ga.x * ga.y), (int)gb.x);                                             \
     } else {                                                                                                    \
-      const dim3 ga = colgrid_v<1>(a.M, a.C, rpl_of(1)), gb = colgrid_v<1>(b.M, b.C, rpl_of(1));                \
+      const dim3 ga = colgrid_v<1>(a.M, a.C, rows_per_thread<1>(a)), gb = colgrid_v<1>(b.M, b.C, rows_per_thread<1>(b)); \
       hipLaunchKernelGGL(NAME##_pair_kernel<1>, dim3(ga.x * ga.y + gb.x * gb.y), dim3(256), 0, s, a, b,         \
                          (int)ga.x, (int)(ga.x * ga.y), (int)gb.x);                                             \
     }                                                                                                           \
@@ -1261,20 +1294,20 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     }
     case HP_OP_BN_APPLY: {
       const BnApplyArgs a = bn_apply_args(op, bases);
-      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_apply_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(bn_apply_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
+      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_apply_kernel<4>, colgrid_v<4>(a.M, a.C, bn_rows<4>(a.M, a.C)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(bn_apply_kernel<1>, colgrid_v<1>(a.M, a.C, bn_rows<1>(a.M, a.C)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_BN_BWD_REDUCE: {
       const BnBwdReduceArgs a = bn_bwd_reduce_args(op, bases);
-      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
+      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, colgrid_v<4>(a.M, a.C, a.rpl), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, colgrid_v<1>(a.M, a.C, a.rpl), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_BN_BWD_APPLY: {
       const BnBwdApplyArgs a = bn_bwd_apply_args(op, bases);
-      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, colgrid_v<4>(a.M, a.C, rpl_of(4)), dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, colgrid_v<1>(a.M, a.C, rpl_of(1)), dim3(256), 0, s, a);
+      if (a.C % 4 == 0) hipLaunchKernelGGL(bn_bwd_apply_kernel<4>, colgrid_v<4>(a.M, a.C, bn_rows<4>(a.M, a.C)), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(bn_bwd_apply_kernel<1>, colgrid_v<1>(a.M, a.C, bn_rows<1>(a.M, a.C)), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_STEM_FWD: {

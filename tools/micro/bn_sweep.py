@@ -39,7 +39,7 @@ def chain(build, reps=REP):
 
 def main():
     print(os.environ.get("HIPPIE_HIP_LIB", "product library"), flush=True)
-    for M, C in ((16384, 64), (8192, 128), (4096, 256), (2048, 512), (25600, 64)):
+    for M, C in ((16384, 64), (2048, 512), (3584, 512), (512, 20), (512, 10)):
         R = P.stat_repl(C)
         def apply(ol, put, reps, res, training=1):
             raw, out, st = put(M * C * 4), put(M * C * 4), put(R * 2 * C * 8)
