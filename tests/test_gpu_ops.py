@@ -364,7 +364,9 @@ def test_wgrad_mfma_layout_identity():
     np.testing.assert_array_equal(view(gpu, slab, np.float32, 64 * 64).reshape(64, 64), xm)
 
 
-@pytest.mark.parametrize("C,M", [(64, 300), (512, 37), (20, 77), (5, 33)])
+# (the last three: workgroups several row batches tall in the reduce — few statistics replicas at C = 512 / 256 — and the
+#  scalar form with more than one row per thread)
+@pytest.mark.parametrize("C,M", [(64, 300), (512, 37), (20, 77), (5, 33), (512, 1500), (256, 5000), (10, 3000)])
 @pytest.mark.parametrize("res_mode", [0, 1, 2])
 def test_bn_apply_and_backward(C, M, res_mode):
     img = Img(5)
