@@ -463,15 +463,24 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs p) {
   }
 }
 
+// Rows per thread of the stem / tail weight-gradient reductions (batches of 8 loads); HIPPIE_WG_ROWS overrides it for
+// tools/micro/small_wgrad_sweep.py.  Measured at batch 512 (time model's stem, 25 600 rows x 64 channels), per launch in a
+// graph: 8 rows -> 60.8 us, 16 -> 33.2, 32 -> 21.0, 64 -> 18.4, 128 -> 23.9: every workgroup ends in one fp32 atomic per
+// output and same-address atomics retire at ~70 ns each, so FEWER, taller workgroups win until the serial row batches
+// take over.
+inline int small_wgrad_rows(int dflt) {
+  static const int forced = [] { const char* e = getenv("HIPPIE_WG_ROWS"); return e ? atoi(e) : 0; }();
+  return forced > 0 ? forced : dflt;
+}
 constexpr int kStemRows = 64;
-__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs p) {
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs p, int rows) {
   __shared__ double lds[3 * 256];
   const int M = p.B * p.Lout;
-  const ColMap m = colmap(M, p.C, kStemRows);      // many rows per block: the 3*C outputs are one atomic target per block
+  const ColMap m = colmap(M, p.C, rows);      // many rows per block: the 3*C outputs are one atomic target per block
   double v[3] = {0.0, 0.0, 0.0};
   if (m.active) {
     // kRowsPerLane rows per thread in batches of 8: every load of a batch is issued before the first use
-    for (int k0 = 0; k0 < kStemRows; k0 += 8) {
+    for (int k0 = 0; k0 < rows; k0 += 8) {
       float d[8], x0[8], x1[8], x2[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -797,17 +806,17 @@ __global__ void tail_bwd_x_kernel(const float* dt, const float* w, float* dact, 
 // thread = (channel, row lane); kTailRows rows (b,h) per thread, loaded in batches of 8 before use (a per-row
 // load -> use loop is one dependent memory round trip per row); fp32 atomics into zeroed DW/DB.
 constexpr int kTailRows = 32;
-__global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int bper) {
+__global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int rows) {
   __shared__ double lds[4 * 256];
   const int cw = C < 256 ? C : 256, rl = 256 / cw;
   const int tid = threadIdx.x, rlane = tid / cw;
   const int c = blockIdx.y * cw + (tid - rlane * cw);
   const bool active = rlane < rl && c < C;
   const int M = B * Lh, Lo = 2 * Lh;
-  const int row0 = blockIdx.x * rl * kTailRows + rlane;
+  const int row0 = blockIdx.x * rl * rows + rlane;
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   if (active) {
-    for (int k0 = 0; k0 < kTailRows; k0 += 8) {
+    for (int k0 = 0; k0 < rows; k0 += 8) {
       float a[8], d0[8], d1[8], d2[8], d3[8];
       bool ok[8];
 #pragma unroll
@@ -1019,6 +1028,16 @@ __global__ void step_inc_kernel(int64_t* step) { if (threadIdx.x == 0 && blockId
 
 inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / per); }
 
+// M-slices of HP_OP_LINEAR_BWD_W: every slice ends in one fp32 atomic per (n, k).  Rows per slice = 16 per row lane of the
+// workgroup (256 / min(K, 256) lanes), within [32, 128]: two batches of 8 row loads per thread.  Measured per launch in a
+// graph at M = 512 (tools/micro/linear_sweep.py): the former "1024 workgroups, 16 rows each" took 8.7-8.9 us on the
+// 20 x 20 / 20 x 30 heads (32 atomics per address, 640 workgroups of two rows per thread) against 3.2-3.5 us now.
+inline int linear_bwd_w_slices(int M, int N, int K) {
+  static const int forced = [] { const char* e = getenv("HIPPIE_LBW_ROWS"); return e ? atoi(e) : 0; }();   // (the sweep)
+  const int kw = K < 256 ? K : 256, ml = 256 / kw;
+  const int rows = forced > 0 ? forced : min(128, max(32, 16 * ml));
+  return max(1, hp::cdiv(M, rows));
+}
 BnApplyArgs bn_apply_args(const HpOp& op, void* const* bases) {
   using hp::ptr;
   const int32_t* I = op.i;
@@ -1145,8 +1164,7 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
       const int kw = a.K < 256 ? a.K : 256;
       const int ky = hp::cdiv(a.K, kw);
-      int nz = hp::cdiv(1024, a.N * ky);                      // aim at >= 1024 workgroups, >= 16 rows each
-      nz = max(1, min(nz, hp::cdiv(a.M, 16)));
+      const int nz = linear_bwd_w_slices(a.M, a.N, a.K);
       e.rows_per_z = hp::cdiv(a.M, nz);
       e.a.lin = a; e.gx = a.N; e.gy = ky; e.gz = hp::cdiv(a.M, e.rows_per_z);
       return true;
@@ -1321,7 +1339,8 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       StemArgs a{};
       a.dr = ptr<const float>(op, 0, bases); a.x = ptr<const float>(op, 1, bases); a.dw = ptr<float>(op, 2, bases);
       a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3];
-      hipLaunchKernelGGL(stem_wgrad_kernel, colgrid(a.B * a.Lout, a.C, kStemRows), dim3(256), 0, s, a);
+      const int rows = small_wgrad_rows(kStemRows);
+      hipLaunchKernelGGL(stem_wgrad_kernel, colgrid(a.B * a.Lout, a.C, rows), dim3(256), 0, s, a, rows);
       break;
     }
     case HP_OP_POOL_FWD:
@@ -1385,8 +1404,7 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
       const int kw = a.K < 256 ? a.K : 256;
       const int ky = hp::cdiv(a.K, kw);
-      int nz = hp::cdiv(1024, a.N * ky);                      // aim at >= 1024 workgroups, >= 16 rows each
-      nz = max(1, min(nz, hp::cdiv(a.M, 16)));
+      const int nz = linear_bwd_w_slices(a.M, a.N, a.K);
       const int rows_per_z = hp::cdiv(a.M, nz);
       dim3 grid(a.N, ky, hp::cdiv(a.M, rows_per_z));
       hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(256), 0, s, a, rows_per_z);
@@ -1421,9 +1439,10 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       break;
     case HP_OP_TAIL_BWD_W: {
       const int cw = I[2] < 256 ? I[2] : 256;
-      const dim3 grid(hp::cdiv(I[0] * I[1], (256 / cw) * kTailRows), hp::cdiv(I[2], cw));
+      const int rows = small_wgrad_rows(kTailRows);
+      const dim3 grid(hp::cdiv(I[0] * I[1], (256 / cw) * rows), hp::cdiv(I[2], cw));
       hipLaunchKernelGGL(tail_bwd_w_kernel, grid, dim3(256), 0, s, ptr<const float>(op, 0, bases),
-                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], 0);
+                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], rows);
       break;
     }
     case HP_OP_LOSS_FINALIZE: {
