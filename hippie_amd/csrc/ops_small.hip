@@ -352,17 +352,21 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
     }
   }
   fold_rows<3 * V>(m, v, lds);
-  if (m.active && m.rlane == 0) {
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      double* b1 = stat_replica(p.bs, p.C, bx);
-      atomic_add_f64(b1 + m.c + j, v[3 * j + 0]);
-      atomic_add_f64(b1 + p.C + m.c + j, v[3 * j + 1]);
-      if (p.has_second) {
-        double* b2 = stat_replica(p.bs2, p.C, bx);
-        atomic_add_f64(b2 + m.c + j, v[3 * j + 0]);
-        atomic_add_f64(b2 + p.C + m.c + j, v[3 * j + 2]);
-      }
+  // lds[(3 * j + s) * 256 + q] = statistic s of channel 4q + j of this workgroup's column group.  One atomic per channel and
+  // statistic from CONSECUTIVE threads on consecutive addresses (an atomic instruction costs per cache line it touches;
+  // thread q adding its own four channels spread every instruction over cw / 4 lines)
+  const int ncol = m.cw * V, c_base = by * ncol;
+  for (int o = threadIdx.x; o < ncol; o += 256) {
+    const int q = o / V, j = o - q * V, c = c_base + o;
+    if (c >= p.C) continue;
+    const double s0 = lds[(3 * j + 0) * 256 + q], s1 = lds[(3 * j + 1) * 256 + q];
+    double* b1 = stat_replica(p.bs, p.C, bx);
+    atomic_add_f64(b1 + c, s0);
+    atomic_add_f64(b1 + p.C + c, s1);
+    if (p.has_second) {
+      double* b2 = stat_replica(p.bs2, p.C, bx);
+      atomic_add_f64(b2 + c, s0);
+      atomic_add_f64(b2 + p.C + c, lds[(3 * j + 2) * 256 + q]);
     }
   }
 }
@@ -512,6 +516,59 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs p, int rows) {
   }
 }
 
+// float4 form (C a multiple of 4): 16 channel quads x 16 row lanes per workgroup, 16 rows per thread in two batches of 8
+// loads — the same 256 rows and the same number of atomics per workgroup as the scalar form's 4 row lanes x 64 rows, with
+// two dependent memory round trips instead of eight (time model's stem at batch 512: 18.4 -> see tools/micro/small_wgrad_sweep.py)
+constexpr int kStemRows4 = 16;
+__global__ __launch_bounds__(256) void stem_wgrad4_kernel(StemArgs p, int rows) {
+  __shared__ double lds[12 * 256];
+  const int M = p.B * p.Lout;
+  const ColMap m = colmap_v<4>(M, p.C, rows, blockIdx.x, blockIdx.y);
+  double v[12];
+#pragma unroll
+  for (int j = 0; j < 12; ++j) v[j] = 0.0;
+  if (m.active) {
+    for (int k0 = 0; k0 < rows; k0 += 8) {
+      float4 d[8];
+      float x0[8], x1[8], x2[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = m.row + (k0 + k) * m.rstep;
+        const bool ok = r < m.rend;
+        const int rr = ok ? r : m.rend - 1;
+        const int b = rr / p.Lout, l = rr - b * p.Lout;
+        const float* xb = p.x + (size_t)b * p.Lin;
+        const int j = 2 * l - 1;
+        d[k] = *reinterpret_cast<const float4*>(p.dr + (size_t)rr * p.C + m.c);
+        if (!ok) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        x0[k] = j >= 0 ? xb[j] : 0.f;
+        x1[k] = xb[j + 1];
+        x2[k] = j + 2 < p.Lin ? xb[j + 2] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float dj = (&d[k].x)[j];
+          v[3 * j + 0] += (double)(dj * x0[k]);
+          v[3 * j + 1] += (double)(dj * x1[k]);
+          v[3 * j + 2] += (double)(dj * x2[k]);
+        }
+      }
+    }
+  }
+  fold_rows<12>(m, v, lds);
+  // lds[k * 256 + quad] (k = 3 * (channel & 3) + tap) holds the workgroup's sums.  One atomic per OUTPUT, issued by
+  // consecutive threads on consecutive addresses: an atomic instruction costs per cache line it touches, and twelve
+  // strided instructions from 16 threads touched 72 lines where 192 consecutive outputs are 6.
+  const int c_base = blockIdx.y * m.cw * 4;
+  for (int o = threadIdx.x; o < m.cw * 12; o += 256) {
+    const int cl = o / 3, t = o - cl * 3;
+    if (c_base + cl < p.C) atomic_add_f32(p.dw + (size_t)(c_base + cl) * 3 + t, (float)lds[(3 * (cl & 3) + t) * 256 + (cl >> 2)]);
+  }
+}
+
 // ---- pool / repeat ---------------------------------------------------------------
 __global__ void pool_fwd_kernel(const float* in, float* out, int B, int L, int C) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -571,7 +628,22 @@ __device__ __forceinline__ void concat_body(const ConcatArgs& p, int bx) {
 }
 __global__ __launch_bounds__(256) void concat_kernel(ConcatArgs p) { concat_body(p, blockIdx.x); }
 struct EmbArgs { const float* d; const int64_t* idx; float* dt; int B, w, ld, col0, rows; };
+// A small table (rows * w <= 1024 floats: the 5 x 5 source / class tables): one WAVE per table element scans the batch
+// and adds its fixed-order sum to the element it owns — no atomics, bit-reproducible, and 2 560 global atomics on one
+// cache line (4.9 us) became 25 plain read-modify-writes (2.2 us).  Larger tables: one fp32 atomic per (sample, column).
 __device__ __forceinline__ void emb_bwd_body(const EmbArgs& p, int bx) {
+  const int n = p.rows * p.w;
+  if (n <= 1024) {
+    const int e = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (e >= n) return;
+    const int row = e / p.w, k = e - row * p.w;
+    float s = 0.f;
+    for (int b = lane; b < p.B; b += 64)
+      if (p.idx[b] == (int64_t)row) s += p.d[(size_t)b * p.ld + p.col0 + k];
+    s = wave_sum(s);
+    if (lane == 0) p.dt[e] += s;
+    return;
+  }
   const int id = bx * 256 + threadIdx.x;
   if (id >= p.B * p.w) return;
   const int b = id / p.w, k = id - b * p.w;
@@ -588,21 +660,81 @@ struct LinArgs {
   int M, N, K, ldx, ldy, act, has_mask, lda, accumulate;
   float slope;
 };
-// one thread per output (small K)
+// one thread per output (small K).  Statistics (the following BatchNorm's sum / sum of squares per column): the workgroup's
+// 256 outputs are folded per column in LDS and leave as ONE atomic per column and statistic from consecutive threads —
+// an atomic per output element (M*N*2 of them, ~7 cache lines per wave instruction) made the three BatchNorm-fed heads
+// 4.4-4.9 us launches against 2.6 us for the same shape without statistics.
+constexpr int kLinLdsW = 12288, kLinLdsX = 1024;      // floats of LDS for the staged weight / input rows
 __device__ __forceinline__ void linear_fwd_thread_body(const LinArgs& p, int bx) {
+  __shared__ double s_st[2][256];
+  __shared__ float s_w[kLinLdsW], s_x[kLinLdsX];
   const int id = bx * 256 + threadIdx.x;
-  if (id >= p.M * p.N) return;
-  const int m = id / p.N, n = id - m * p.N;
-  const float* x = p.X + (size_t)m * p.ldx;
-  const float* w = p.W + (size_t)n * p.K;
+  const bool valid = id < p.M * p.N;
+  const int m = valid ? id / p.N : 0, n = valid ? id - m * p.N : 0;
   float s = 0.f;
-  for (int k = 0; k < p.K; ++k) s = fmaf(x[k], w[k], s);
-  if (p.Bv != nullptr) s += p.Bv[n];
-  if (p.stats != nullptr) {
-    double* st = stat_replica(p.stats, p.N, m);
-    atomic_add_f64(st + n, (double)s);
-    atomic_add_f64(st + p.N + n, (double)s * (double)s);
+  // The weight rows and the input rows this workgroup's 256 outputs need are staged in LDS with coalesced loads (odd row
+  // stride: conflict-free column reads); the dot product then runs out of LDS in the same k order.  Read straight from
+  // global memory the loop cost ~0.12 us per k (x[k] and w[n*K+k]: two scalar round trips per step): decoder.linear_out
+  // (K = 64) was a 9.3 us launch.
+  const int KP = p.K | 1;
+  const int WN = p.N < 256 ? p.N : 256;
+  const int first = bx * 256;
+  const int m_first = first / p.N, n_first = p.N <= 256 ? 0 : first - m_first * p.N;
+  const int last = min(first + 255, p.M * p.N - 1);
+  const int nrows = last / p.N - m_first + 1;
+  // (measured per launch in a graph, batch 512: linear_out N=100 K=64 9.3 -> 5.7 us, encoder_fc.0 N=20 K=30 4.8 -> 4.4;
+  //  N=512 K=20 got SLOWER, 7.4 -> 9.9 us — 20 staging iterations per thread for 20 k-steps — hence N <= 256, K >= 24)
+  if (p.N <= 256 && p.K >= 24 && WN * KP <= kLinLdsW && nrows * KP <= kLinLdsX) {      // (uniform)
+    __syncthreads();                 // (chained launches call this body repeatedly)
+    for (int i = threadIdx.x; i < WN * p.K; i += 256) {
+      const int r = i / p.K, k = i - r * p.K;
+      int nn = n_first + r;
+      if (nn >= p.N) nn -= p.N;
+      s_w[r * KP + k] = p.W[(size_t)nn * p.K + k];
+    }
+    for (int i = threadIdx.x; i < nrows * p.K; i += 256) {
+      const int r = i / p.K, k = i - r * p.K;
+      s_x[r * KP + k] = p.X[(size_t)(m_first + r) * p.ldx + k];
+    }
+    __syncthreads();
+    if (valid) {
+      int wr = n - n_first;
+      if (wr < 0) wr += p.N;
+      const float* x = s_x + (m - m_first) * KP;
+      const float* w = s_w + wr * KP;
+      for (int k = 0; k < p.K; ++k) s = fmaf(x[k], w[k], s);
+      if (p.Bv != nullptr) s += p.Bv[n];
+    }
+  } else if (valid) {
+    const float* x = p.X + (size_t)m * p.ldx;
+    const float* w = p.W + (size_t)n * p.K;
+    for (int k = 0; k < p.K; ++k) s = fmaf(x[k], w[k], s);
+    if (p.Bv != nullptr) s += p.Bv[n];
   }
+  if (p.stats != nullptr) {          // (uniform)
+    if (p.N > 256) {
+      if (valid) {
+        double* st = stat_replica(p.stats, p.N, m);
+        atomic_add_f64(st + n, (double)s);
+        atomic_add_f64(st + p.N + n, (double)s * (double)s);
+      }
+    } else {
+      __syncthreads();               // (chained launches call this body repeatedly: the previous call's readers are done)
+      s_st[0][threadIdx.x] = valid ? (double)s : 0.0;
+      s_st[1][threadIdx.x] = valid ? (double)s * (double)s : 0.0;
+      __syncthreads();
+      if ((int)threadIdx.x < p.N) {
+        // outputs bx*256 + i of this workgroup with (bx*256 + i) % N == threadIdx.x
+        const int first = (int)(((int64_t)threadIdx.x - ((int64_t)bx * 256) % p.N + p.N) % p.N);
+        double a = 0.0, b = 0.0;
+        for (int i = first; i < 256; i += p.N) { a += s_st[0][i]; b += s_st[1][i]; }
+        double* st = stat_replica(p.stats, p.N, bx);
+        atomic_add_f64(st + threadIdx.x, a);
+        atomic_add_f64(st + p.N + threadIdx.x, b);
+      }
+    }
+  }
+  if (!valid) return;
   if (p.act) s = lrelu(s, p.slope);
   p.Y[(size_t)m * p.ldy + n] = s;
 }
@@ -859,6 +991,57 @@ __global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const 
     if (c == 0) atomic_add_f32(db, (float)v[3]);
   }
 }
+// float4 form of the same reduction (C a multiple of 4): 16 row lanes x 16 rows per thread (see stem_wgrad4_kernel)
+constexpr int kTailRows4 = 16;
+__global__ __launch_bounds__(256) void tail_bwd_w4_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int rows) {
+  __shared__ double lds[13 * 256];
+  const int M = B * Lh, Lo = 2 * Lh;
+  const ColMap m = colmap_v<4>(M, C, rows, blockIdx.x, blockIdx.y);
+  double v[13];
+#pragma unroll
+  for (int j = 0; j < 13; ++j) v[j] = 0.0;
+  if (m.active) {
+    for (int k0 = 0; k0 < rows; k0 += 8) {
+      float4 a[8];
+      float d0[8], d1[8], d2[8], d3[8];
+      bool ok[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = m.row + (k0 + k) * m.rstep;
+        ok[k] = r < m.rend;
+        const int rr = ok[k] ? r : m.rend - 1;
+        const int b = rr / Lh, h = rr - b * Lh;
+        const float* dtb = dt + (size_t)b * Lo + 2 * h;
+        a[k] = *reinterpret_cast<const float4*>(act + (size_t)rr * C + m.c);
+        d0[k] = h > 0 ? dtb[-1] : 0.f;
+        d1[k] = dtb[0];
+        d2[k] = dtb[1];
+        d3[k] = h + 1 < Lh ? dtb[2] : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (!ok[k]) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float aj = (&a[k].x)[j];
+          v[3 * j + 0] += (double)(aj * (d2[k] + d3[k]));      // tap 0: pz = 2h+1, 2h+2
+          v[3 * j + 1] += (double)(aj * (d1[k] + d2[k]));      // tap 1: pz = 2h,   2h+1
+          v[3 * j + 2] += (double)(aj * (d0[k] + d1[k]));      // tap 2: pz = 2h-1, 2h
+        }
+        v[12] += (double)(d1[k] + d2[k]);
+      }
+    }
+  }
+  fold_rows<13>(m, v, lds);
+  // one atomic per output from consecutive threads (see stem_wgrad4_kernel)
+  const int c_base = blockIdx.y * m.cw * 4;
+  for (int o = threadIdx.x; o < m.cw * 12; o += 256) {
+    const int cl = o / 3, t = o - cl * 3;
+    if (c_base + cl < C) atomic_add_f32(dw + (size_t)(c_base + cl) * 3 + t, (float)lds[(3 * (cl & 3) + t) * 256 + (cl >> 2)]);
+  }
+  if (threadIdx.x == 0 && blockIdx.y == 0) atomic_add_f32(db, (float)lds[12 * 256 + 0]);
+}
 
 // ---- slab reduce / optimiser ------------------------------------------------------
 __global__ void slab_reduce_kernel(const float* slab, float* out, int n, int nsplit, int stride) {
@@ -1032,7 +1215,8 @@ inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / p
 // workgroup (256 / min(K, 256) lanes), within [32, 128]: two batches of 8 row loads per thread.  Measured per launch in a
 // graph at M = 512 (tools/micro/linear_sweep.py): the former "1024 workgroups, 16 rows each" took 8.7-8.9 us on the
 // 20 x 20 / 20 x 30 heads (32 atomics per address, 640 workgroups of two rows per thread) against 3.2-3.5 us now.
-inline int linear_bwd_w_slices(int M, int N, int K) {
+inline int linear_bwd_w_slices(int M, int N, int K, bool one_slice = false) {
+  if (one_slice) return 1;           // flags & 1: no cross-workgroup atomics, bit-reproducible
   static const int forced = [] { const char* e = getenv("HIPPIE_LBW_ROWS"); return e ? atoi(e) : 0; }();   // (the sweep)
   const int kw = K < 256 ? K : 256, ml = 256 / kw;
   const int rows = forced > 0 ? forced : min(128, max(32, 16 * ml));
@@ -1137,7 +1321,8 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
     }
     case HP_OP_EMB_BWD: {
       EmbArgs a{ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2], I[3], I[4]};
-      e.a.emb = a; e.gx = blocks_for((int64_t)I[0] * I[1]);
+      e.a.emb = a;
+      e.gx = a.rows * a.w <= 1024 ? hp::cdiv(a.rows * a.w, 4) : blocks_for((int64_t)I[0] * I[1]);      // (emb_bwd_body: a wave per element)
       return true;
     }
     case HP_OP_LINEAR_FWD: {
@@ -1164,7 +1349,7 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
       const int kw = a.K < 256 ? a.K : 256;
       const int ky = hp::cdiv(a.K, kw);
-      const int nz = linear_bwd_w_slices(a.M, a.N, a.K);
+      const int nz = linear_bwd_w_slices(a.M, a.N, a.K, op.flags & 1);
       e.rows_per_z = hp::cdiv(a.M, nz);
       e.a.lin = a; e.gx = a.N; e.gy = ky; e.gz = hp::cdiv(a.M, e.rows_per_z);
       return true;
@@ -1339,8 +1524,14 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       StemArgs a{};
       a.dr = ptr<const float>(op, 0, bases); a.x = ptr<const float>(op, 1, bases); a.dw = ptr<float>(op, 2, bases);
       a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3];
-      const int rows = small_wgrad_rows(kStemRows);
-      hipLaunchKernelGGL(stem_wgrad_kernel, colgrid(a.B * a.Lout, a.C, rows), dim3(256), 0, s, a, rows);
+      if (a.C % 4 == 0) {
+        // flags & 1: ONE workgroup per column group walks all rows — no cross-workgroup atomics, bit-reproducible
+        const int rows = (op.flags & 1) ? hp::cdiv(hp::cdiv(a.B * a.Lout, 16), 8) * 8 : small_wgrad_rows(kStemRows4);
+        hipLaunchKernelGGL(stem_wgrad4_kernel, colgrid_v<4>(a.B * a.Lout, a.C, rows), dim3(256), 0, s, a, rows);
+      } else {
+        const int rows = small_wgrad_rows(kStemRows);
+        hipLaunchKernelGGL(stem_wgrad_kernel, colgrid(a.B * a.Lout, a.C, rows), dim3(256), 0, s, a, rows);
+      }
       break;
     }
     case HP_OP_POOL_FWD:
@@ -1404,7 +1595,7 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4];
       const int kw = a.K < 256 ? a.K : 256;
       const int ky = hp::cdiv(a.K, kw);
-      const int nz = linear_bwd_w_slices(a.M, a.N, a.K);
+      const int nz = linear_bwd_w_slices(a.M, a.N, a.K, op.flags & 1);
       const int rows_per_z = hp::cdiv(a.M, nz);
       dim3 grid(a.N, ky, hp::cdiv(a.M, rows_per_z));
       hipLaunchKernelGGL(linear_bwd_w_kernel, grid, dim3(256), 0, s, a, rows_per_z);
@@ -1439,6 +1630,12 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       break;
     case HP_OP_TAIL_BWD_W: {
       const int cw = I[2] < 256 ? I[2] : 256;
+      if (I[2] % 4 == 0) {
+        const int rows = (op.flags & 1) ? hp::cdiv(hp::cdiv(I[0] * I[1], 16), 8) * 8 : small_wgrad_rows(kTailRows4);      // flags & 1: see STEM_WGRAD
+        hipLaunchKernelGGL(tail_bwd_w4_kernel, colgrid_v<4>(I[0] * I[1], I[2], rows), dim3(256), 0, s, ptr<const float>(op, 0, bases),
+                           ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], rows);
+        break;
+      }
       const int rows = small_wgrad_rows(kTailRows);
       const dim3 grid(hp::cdiv(I[0] * I[1], (256 / cw) * rows), hp::cdiv(I[2], cw));
       hipLaunchKernelGGL(tail_bwd_w_kernel, grid, dim3(256), 0, s, ptr<const float>(op, 0, bases),

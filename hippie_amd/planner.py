@@ -208,6 +208,9 @@ class Lowering:
         if self.train.mfma_dtype not in ("f32", "bf16"):
             raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', not {self.train.mfma_dtype!r}")
         self.mm_flag = P.CONV_BF16 if self.train.mfma_dtype == "bf16" else 0
+        # deterministic_wgrad also covers the small weight-gradient reductions (stem, tail, the heads' linears): flags & 1
+        # = one workgroup per output group, no cross-workgroup atomics
+        self.det_flag = 1 if self.train.deterministic_wgrad else 0
 
     # ---- parameter declaration (own order; class_embedding last so that AdamW can skip it) ----
     def declare_encoder(self, pre):
@@ -361,7 +364,8 @@ class Lowering:
         if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
             # deferred: all wgrads of the backward pass run in one grouped launch at its end.  With the
             # whole chip shared, ~64 workgroups per problem suffice: big-weight layers are not split at all.
-            nsplit = max(1, min(64 // tiles, -(-tm.M // 256)))
+            per_problem = int(os.environ.get("HIPPIE_WGRAD_BLOCKS", "64"))      # (the variable: tools/micro sweeps)
+            nsplit = max(1, min(per_problem // tiles, -(-tm.M // 256)))
             if len(tm.taps) == 1:
                 # the 1-tap group (three shortcut convs) is too small to fill the chip at 64 blocks per problem
                 # (measured: 75 us -> 35 us with <= 512 rows per split)
@@ -540,7 +544,7 @@ class Lowering:
             self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
 
     def linear_bwd(self, M, lin, dy, ldy, x, ldx, dx=None, lddx=None, mask=None, ldmask=0, accumulate=False, note=""):
-        self.o.add(P.LINEAR_BWD_W, 0, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
+        self.o.add(P.LINEAR_BWD_W, self.det_flag, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
         if dx is not None:
             self.o.add(P.LINEAR_BWD_X, 0, i=[M, lin["N"], lin["K"], ldy, lddx, 1 if mask is not None else 0, ldmask, 1 if accumulate else 0],
                        f=[SLOPE_HEADS], buf=[dy, lin["w"].ref, dx, mask], note=note + " dX")
@@ -690,7 +694,7 @@ class Lowering:
                     self.reduce_op(spp, dst)
             sp = spp
         dr0, _ = self.apply_op(sp)
-        self.o.add(P.STEM_WGRAD, 0, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
+        self.o.add(P.STEM_WGRAD, self.det_flag, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
 
     # ---- decoder ------------------------------------------------------------------
     def decoder_fwd(self, d, din, training):
@@ -756,7 +760,7 @@ class Lowering:
         pl, B, z = self.pl, self.B, self.cfg.z_dim
         dt = pl.f32(B * 64)
         self.linear_bwd(B, d["lo"], drec, d["output_size"], d["t"], 64, dt, 64, note=d["prefix"] + "linear_out")
-        self.o.add(P.TAIL_BWD_W, 0, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
+        self.o.add(P.TAIL_BWD_W, self.det_flag, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
         G1 = pl.f32(B * 32 * 64)
         self.o.add(P.TAIL_BWD_X, 0, i=[B, 32, 64], buf=[dt, d["tail_w"].ref, G1], note=d["prefix"] + "tail dX")
         blocks = d["blocks"]

@@ -188,7 +188,9 @@ enum {
    * sum_t x[b][2l+t-1]*W[n][t] (+stats).  i[0]=B i[1]=Lin i[2]=Lout i[3]=C
    * buf: 0 X 1 W 2 OUT 3 STATS */
   HP_OP_STEM_FWD = 7,
-  /* dW[n][t] = sum_{b,l} DR[b*Lout+l][n]*x[b][2l+t-1].  buf: 0 DR 1 X 2 DW */
+  /* dW[n][t] = sum_{b,l} DR[b*Lout+l][n]*x[b][2l+t-1].  buf: 0 DR 1 X 2 DW
+   * flags & 1 (also HP_OP_TAIL_BWD_W, HP_OP_LINEAR_BWD_W): one workgroup per output group walks all rows — no
+   * cross-workgroup atomics, bit-reproducible sums (TrainCfg.deterministic_wgrad), slower. */
   HP_OP_STEM_WGRAD = 8,
   /* adaptive_avg_pool1d(x,1) (backbones.py:100): out[b][c] = mean_l in[b*L+l][c]
    * i[0]=B i[1]=L i[2]=C.  buf: 0 IN 1 OUT */
@@ -207,8 +209,8 @@ enum {
    * nn.Embedding does; the device-side guard only makes a bad label harmless).
    * buf: 0 OUT; 1+2j SRC/TABLE; 2+2j IDX(int64) */
   HP_OP_CONCAT = 13,
-  /* embedding gradient: DT[idx[b]][k] += D[b*ld + col0 + k] (fp32 atomics); rows with idx[b] outside
-   * [0, rows) are skipped.  i[0]=B i[1]=w i[2]=ld i[3]=col0 i[4]=rows.  buf: 0 D 1 IDX 2 DT */
+  /* embedding gradient: DT[idx[b]][k] += D[b*ld + col0 + k] (tables of <= 1024 floats: a wave per table element,
+   * fixed-order sums, no atomics; larger tables: fp32 atomics); rows with idx[b] outside [0, rows) are skipped.  i[0]=B i[1]=w i[2]=ld i[3]=col0 i[4]=rows.  buf: 0 D 1 IDX 2 DT */
   HP_OP_EMB_BWD = 14,
   /* nn.Linear (model.py:21-41, backbones.py:84,102,111,118,129,138):
    * Y[m*ldy+n] = act(sum_k X[m*ldx+k]*W[n*K+k] + b[n]) (+stats on the pre-activation).

@@ -58,6 +58,8 @@ def time_records(recs):
     return best
 
 
+import os
+only = set(filter(None, os.environ.get("HIPPIE_ONLY_OP", "").split(",")))       # e.g. WGRAD_GROUP: time just those launches
 rows = []
 for seg in ("fwd_train", "bwd", "opt"):
     first, count = segs[seg]
@@ -76,6 +78,8 @@ for seg in ("fwd_train", "bwd", "opt"):
         if int(r["flags"]) & P.FLAG_MEMBER:
             continue
         opc = int(r["op"])
+        if only and OPN.get(opc) not in only:
+            continue
         if opc == P.PAIR:
             mem = sorted([int(r["i"][0]), int(r["i"][1])])
         elif opc == P.WGRAD_GROUP:
