@@ -638,8 +638,16 @@ __device__ __forceinline__ void emb_bwd_body(const EmbArgs& p, int bx) {
     if (e >= n) return;
     const int row = e / p.w, k = e - row * p.w;
     float s = 0.f;
-    for (int b = lane; b < p.B; b += 64)
-      if (p.idx[b] == (int64_t)row) s += p.d[(size_t)b * p.ld + p.col0 + k];
+    for (int b0 = lane; b0 < p.B; b0 += 8 * 64) {       // 8 samples per lane and round trip: labels first, then the matching rows
+      int64_t id[8];
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) id[j] = b0 + j * 64 < p.B ? p.idx[b0 + j * 64] : -1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = id[j] == (int64_t)row ? p.d[(size_t)(b0 + j * 64) * p.ld + p.col0 + k] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[j];
+    }
     s = wave_sum(s);
     if (lane == 0) p.dt[e] += s;
     return;
