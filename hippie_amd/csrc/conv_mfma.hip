@@ -124,7 +124,7 @@ struct ConvArgs {
 };
 
 constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
-constexpr int kConvCoef = 2 * 512;      // + (scale, shift) of up to 512 input channels (HP_CONV_IN_BN)
+constexpr int kConvCoef = 4 * 512;      // + (scale, shift) of up to 512 input channels, then as many zeros (HP_CONV_IN_BN)
 constexpr int kConvCoefDr = 2 * 3 * 512;   // + the (A, B, C) of bn_dr for up to 512 channels of two sources (HP_CONV_IN_DR)
 constexpr int conv_extra_lds(int mode) { return mode == 1 ? kConvCoef : (mode == 2 ? kConvCoefDr : 0); }
 constexpr int kConvThreads = 512;
@@ -402,7 +402,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     Pref r;
     r.a = gload4(pa);
     r.b = gload4(pb);
-    if (IN_BN) { r.kq = kc * 32 + aq; r.va = ia ? 1.f : 0.f; }
+    if (IN_BN) r.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;      // a padded row reads (scale, shift) = (0, 0): its activation is exactly 0
     if (IN_DR) {
       d.a2 = gload4(pa + draw);
       d.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;      // where the evaluated dr segment is stored back (nullptr = not)
@@ -414,6 +414,13 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   const float* s_coef = smem + kConvLds;
   const bool in_bn = IN_BN && p.in_bn;
   const float in_slope = p.in_slope;
+  float4 pre_sc = make_float4(0.f, 0.f, 0.f, 0.f), pre_sh = pre_sc;      // IN_BN: (scale, shift) of the slice about to be stored
+  auto load_coef = [&](const Pref& r) {
+    if (IN_BN && in_bn) {
+      pre_sc = *reinterpret_cast<const float4*>(s_coef + r.kq);
+      pre_sh = *reinterpret_cast<const float4*>(s_coef + t.K + r.kq);
+    }
+  };
   auto stash = [&](int buf, Pref r, const PrefDr& d) {
     float* As = smem + buf * TILE;
     float* Bs = smem + 2 * TILE + buf * TILE;
@@ -431,12 +438,15 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     if (IN_BN) {
       if (in_bn) {
         // a = leaky_relu(fma(x, scale, shift)): the same two operations, on the same operands, as HP_OP_BN_APPLY
-        const float4 sc = *reinterpret_cast<const float4*>(s_coef + r.kq);
-        const float4 sh = *reinterpret_cast<const float4*>(s_coef + t.K + r.kq);
-        r.a.x = lrelu(fmaf(r.a.x, sc.x, sh.x), in_slope) * r.va;
-        r.a.y = lrelu(fmaf(r.a.y, sc.y, sh.y), in_slope) * r.va;
-        r.a.z = lrelu(fmaf(r.a.z, sc.z, sh.z), in_slope) * r.va;
-        r.a.w = lrelu(fmaf(r.a.w, sc.w, sh.w), in_slope) * r.va;
+        // leaky_relu as max(v, v * slope): for 0 <= slope <= 1 (checked by hp_program_validate) it selects the same one of
+        // the same two values as `v > 0 ? v : v * slope`, in two instructions instead of three; the padding mask is the
+        // coefficient address (zeros), not a multiply: 12 VALU operations per float4 instead of 20
+        const float4 sc = pre_sc, sh = pre_sh;      // (read from LDS at the top of the K-step: HP_KSTEP)
+        const float vx = fmaf(r.a.x, sc.x, sh.x), vy = fmaf(r.a.y, sc.y, sh.y), vz = fmaf(r.a.z, sc.z, sh.z), vw = fmaf(r.a.w, sc.w, sh.w);
+        r.a.x = fmaxf(vx, vx * in_slope);
+        r.a.y = fmaxf(vy, vy * in_slope);
+        r.a.z = fmaxf(vz, vz * in_slope);
+        r.a.w = fmaxf(vw, vw * in_slope);
       }
     }
     if (BF16) {
@@ -478,7 +488,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     if (FETCH) {                                                                                        \
       LD.a = gload4(pa);                                                                                \
       LD.b = gload4(pb);                                                                                \
-      if (IN_BN) { LD.kq = kc * 32 + aq; LD.va = ia ? 1.f : 0.f; }                                      \
+      if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
       if (IN_DR) {                                                                                      \
         D##LD.a2 = gload4(pa + draw);                                                                   \
         D##LD.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;                                        \
@@ -487,7 +497,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       __builtin_amdgcn_sched_barrier(0);                                                                \
       advance();                                                                                        \
     }                                                                                                   \
-    if (STASH) { stash((BUF) ^ 1, ST, D##ST); }                                                         \
+    if (STASH) { load_coef(ST); stash((BUF) ^ 1, ST, D##ST); }                                          \
     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc2[0], 0, 0, 0);                        \
     __syncthreads();                                                                                    \
   }
@@ -505,10 +515,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
         b4[g] = make_float4(bk[0], bk[LDBK], bk[2 * LDBK], bk[3 * LDBK]);                               \
       }                                                                                                 \
     }                                                                                                   \
+    if (STASH) load_coef(ST);      /* with the fragment reads: the LDS round trip is over before the store needs it */ \
     if (FETCH) {                                                                                        \
       LD.a = gload4(pa);                                                                                \
       LD.b = gload4(pb);                                                                                \
-      if (IN_BN) { LD.kq = kc * 32 + aq; LD.va = ia ? 1.f : 0.f; }                                      \
+      if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
       if (IN_DR) {                                                                                      \
         D##LD.a2 = gload4(pa + draw);                                                                   \
         D##LD.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;                                        \
@@ -557,11 +568,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
         const BnCoef k = bn_coef(true, p.in_Mstat, p.in_stats, t.K, c, p.gamma, p.beta, p.rmean, p.rvar, p.in_eps);
         sc_w[c] = k.scale;
         sc_w[t.K + c] = k.shift;
+        sc_w[2 * t.K + c] = 0.f;          // what a padded row reads
+        sc_w[3 * t.K + c] = 0.f;
         if (bid == 0) bn_side_effects(k, p.in_Mstat, t.K, c, p.in_save, p.rmean, p.rvar, p.in_mom, p.in_coef);
       }
       __syncthreads();
     }
   }
+  load_coef(setA);
   stash(0, setA, DsetA);
   if (nsteps > 1) setA = fetch(DsetA);       // slice 1 waits in set A
   Pref setB = setA;

@@ -260,7 +260,7 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
     if (op.op == HP_OP_CONV_TAPS) {
       ok = ok && (K % 32) == 0 && op.i[28] >= 0;
       if (op.i[28] > 0) ok = ok && op.i[29] >= 1 && op.i[30] >= 0 && (int64_t)op.i[29] * (op.i[3] - 1) + op.i[30] < op.i[28];
-      if (op.flags & HP_CONV_IN_BN) ok = ok && K <= 512 && op.i[31] > 0 && !(op.flags & HP_CONV_BN_EVAL);     // coefficient table in LDS
+      if (op.flags & HP_CONV_IN_BN) ok = ok && K <= 512 && op.i[31] > 0 && !(op.flags & HP_CONV_BN_EVAL) && op.f[2] >= 0.f && op.f[2] <= 1.f;     // coefficient table in LDS; leaky_relu evaluated as max(v, v * slope)
       if (op.flags & HP_CONV_EPI_BNRED) ok = ok && !(op.flags & (HP_CONV_BIAS | HP_CONV_STATS | HP_CONV_BN_EVAL));
       if (op.flags & HP_CONV_IN_DR) ok = ok && K <= 512 && op.i[33] > 0 && !(op.flags & (HP_CONV_IN_BN | HP_CONV_BN_EVAL));
       for (int j = 0; j < nt && j < HP_MAX_TAPS; ++j) ok = ok && (op.i[22 + j] == 0 || op.i[22 + j] == 1);
