@@ -809,9 +809,11 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
           // the activation the forward conv consumed, re-evaluated bit for bit — HERE, at LDS-store time: the loads
           // were issued one slice earlier and have been in flight under the MFMA block (a transform inside
           // load_regs would wait for them before the MFMAs)
+          // (leaky_relu as max(f, f * slope), 0 <= slope <= 1 validated: the same value as the forward conv's loader forms)
           const float keep = (okmask >> (2 * tau + j)) & 1u ? 1.f : 0.f;
-          v.x = lrelu(fmaf(v.x, xsc.x, xsh.x), xslope) * keep; v.y = lrelu(fmaf(v.y, xsc.y, xsh.y), xslope) * keep;
-          v.z = lrelu(fmaf(v.z, xsc.z, xsh.z), xslope) * keep; v.w = lrelu(fmaf(v.w, xsc.w, xsh.w), xslope) * keep;
+          const float fx = fmaf(v.x, xsc.x, xsh.x), fy = fmaf(v.y, xsc.y, xsh.y), fz = fmaf(v.z, xsc.z, xsh.z), fw = fmaf(v.w, xsc.w, xsh.w);
+          v.x = fmaxf(fx, fx * xslope) * keep; v.y = fmaxf(fy, fy * xslope) * keep;
+          v.z = fmaxf(fz, fz * xslope) * keep; v.w = fmaxf(fw, fw * xslope) * keep;
         }
         if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(smem + (1 + tau) * T) + (lr + 16 * j) * kLdtH + cq) = to_bf16x4(v);
         else *reinterpret_cast<float4*>(smem + (1 + tau) * T + (lr + 16 * j) * 64 + cq) = v;

@@ -267,7 +267,7 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
     }
     if (op.op == HP_OP_WGRAD_TAPS)
       ok = ok && (nt == 1 || nt == 3) && op.i[22] >= 1 && op.i[23] > 0 && (op.i[23] % 32) == 0 &&
-           (int64_t)op.i[22] * op.i[23] >= M;
+           (int64_t)op.i[22] * op.i[23] >= M && (!(op.flags & HP_CONV_IN_BN) || (op.f[0] >= 0.f && op.f[0] <= 1.f));
     if (!ok) {
       snprintf(buf, sizeof buf, "op %d (opcode %d): bad tap-map shape M=%d N=%d K=%d ntaps=%d", index, op.op, M, N, K, nt);
       why = buf;

@@ -302,7 +302,7 @@ def test_trainer_async_path_equals_per_step_sync_path(tmp_path, deterministic):
     import re
     for k in sd0:
         if "running_" in k:
-            H.assert_close(sd1[k].numpy(), sd0[k].numpy(), 1e-3, k)          # follow the +-lr parameter noise
+            H.assert_close(sd1[k].numpy(), sd0[k].numpy(), 5e-2, k)          # follow the +-lr parameter noise, amplified by the 6-row batch
         elif sd0[k].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, k):
             # only Adam's hard bound (every element within 2.2 * lr * steps): how many elements sit beyond rounding noise
             # depends on the order of the atomic sums in the two runs

@@ -10,7 +10,7 @@ from hippie_amd.program import Ref, TapMap   # noqa: E402
 REP = 50
 
 
-def time_op(tm, nsplit, rps, reps=REP):
+def time_op(tm, nsplit, rps, reps=REP, in_bn=False):
     nb = tm.M // tm.Lout
     off = 0
     def put(nbytes):
@@ -23,9 +23,10 @@ def time_op(tm, nsplit, rps, reps=REP):
     x = put(nb * tm.Lin * tm.K * 4)
     numel = len(tm.taps) * tm.N * tm.K
     g = put(numel * 4)
+    coef = put(2 * tm.K * 4)
     ol = P.OpList()
     for _ in range(reps):
-        ol.add(P.WGRAD_TAPS, 1, tm.ints() + [nsplit, rps, numel], [0.01], [dy, x, g])
+        ol.add(P.WGRAD_TAPS, 1 | (P.CONV_IN_BN if in_bn else 0), tm.ints() + [nsplit, rps, numel], [0.01], [dy, x, g, coef if in_bn else None])
     dev = torch.zeros(off + 256, dtype=torch.uint8, device="cuda")
     dev[: g.offset].view(torch.float32).normal_()
     prog = P.DeviceProgram(ol.array(), [dev.data_ptr()] + [0] * 5, [dev.numel(), 4, 4, 4, 4, 4])
@@ -45,10 +46,14 @@ def time_op(tm, nsplit, rps, reps=REP):
     return best
 
 
+IN_BN = len(sys.argv) > 1 and sys.argv[1] == "in_bn"      # X is a raw BatchNorm input: the loader re-evaluates the activation
+
+
 def main():
+    print("weight-gradient operand X:", "raw BatchNorm input (HP_CONV_IN_BN)" if IN_BN else "stored tensor", flush=True)
     for name, (L, N, K) in {"L4 512x512": (4, 512, 512), "L3 256x256": (7, 256, 256), "L1 64x64": (25, 64, 64)}.items():
         tiles = (N // 64) * (K // 64)
-        for wg_per_cu in (1, 2, 3, 4, 6):
+        for wg_per_cu in (3,):
             nsplit = max(1, 256 * wg_per_cu // tiles)
             row = []
             for slices in (4, 8, 16, 32):
@@ -58,7 +63,7 @@ def main():
                 M = B * L
                 ns = -(-M // rps)
                 tm = TapMap(M, N, K, L, L, L, 1, 0, [(t - 1, t) for t in range(3)])
-                us = time_op(tm, ns, rps)
+                us = time_op(tm, ns, rps, in_bn=IN_BN)
                 row.append((slices, us, 2.0 * M * N * K * 3 / us * 1e-6))
             (s0, t0, _), (s1, t1, _) = row[0], row[-1]
             slope = (t1 - t0) / (s1 - s0)
