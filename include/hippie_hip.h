@@ -129,6 +129,8 @@ enum {
    * exactly as HP_OP_BN_APPLY derives them — from IN_STATS (sums over i[31] rows; over i[31]*i[32] rows when
    * i[32] > 1), GAMMA, BETA, f[3]=eps.  Workgroup 0 also performs that BatchNorm's side effects: IN_SAVE :=
    * (mean, invstd), IN_COEF := (scale, shift) for the backward pass, running statistics update with f[4]=momentum.
+   * The slope f[2] must lie in [0, 1] (hp_program_validate): the loader forms leaky_relu as max(v, v*slope), which is
+   * then the same value as `v > 0 ? v : v*slope`.
    *
    * HP_CONV_EPI_BNRED (input-gradient convs): instead of storing acc,
    *   g = (acc [+ E_G2]) * leaky_relu'(pre),  pre = E_ACT (the activation tensor) or, when E_ACT is NULL,
@@ -156,7 +158,7 @@ enum {
    * flags: 1 = no slabs: every split adds its tile into buf[2] (the zeroed gradient tensor
    * [tap_w][N][K]) with fp32 atomics (faster, summation order not reproducible bit for bit).
    * flags: HP_CONV_IN_BN = X is the raw BatchNorm input of the forward conv: the operand is
-   * leaky_relu(fma(x, scale[k], shift[k]), f[0]) with (scale, shift) = COEF (written by the forward conv).
+   * leaky_relu(fma(x, scale[k], shift[k]), f[0]) with (scale, shift) = COEF (written by the forward conv); f[0] in [0, 1].
    * buf: 0 DY, 1 X, 2 SLAB (or gradient), 3 COEF(float[2][K]) */
   HP_OP_WGRAD_TAPS = 2,
   /* out[j] = sum_s slab[s*stride + j], j < n.  i[0]=n i[1]=nsplit i[2]=stride. buf: 0 SLAB 1 OUT */
