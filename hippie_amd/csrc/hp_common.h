@@ -30,6 +30,8 @@ hipError_t launch_wgrad_group(int ntaps, bool bf16, const void* d_probs, const v
 bool chainable(const HpOp& op);
 hipError_t build_chain(const HpOp* members, int count, void* const* bases, void** d_entries);
 hipError_t launch_chain(const void* d_entries, int count, hipStream_t s);
+bool groupable(const HpOp& op);          // may be a member of an HP_FLAG_PARALLEL chain
+hipError_t launch_small_group(const HpOp* members, const void* d_entries, int count, hipStream_t s);      // HP_FLAG_PARALLEL
 
 }  // namespace hp
 

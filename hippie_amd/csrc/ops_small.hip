@@ -629,8 +629,9 @@ __device__ __forceinline__ void concat_body(const ConcatArgs& p, int bx) {
 __global__ __launch_bounds__(256) void concat_kernel(ConcatArgs p) { concat_body(p, blockIdx.x); }
 struct EmbArgs { const float* d; const int64_t* idx; float* dt; int B, w, ld, col0, rows; };
 // A small table (rows * w <= 1024 floats: the 5 x 5 source / class tables): one WAVE per table element scans the batch
-// and adds its fixed-order sum to the element it owns — no atomics, bit-reproducible, and 2 560 global atomics on one
-// cache line (4.9 us) became 25 plain read-modify-writes (2.2 us).  Larger tables: one fp32 atomic per (sample, column).
+// and adds its fixed-order sum to the element it owns with ONE atomic (at most two ops contribute to a table per backward
+// pass: 0 + a + b does not depend on the order) — bit-reproducible, and 2 560 global atomics on one cache line (4.9 us)
+// became 25 (2.2 us).  Larger tables: one fp32 atomic per (sample, column).
 __device__ __forceinline__ void emb_bwd_body(const EmbArgs& p, int bx) {
   const int n = p.rows * p.w;
   if (n <= 1024) {
@@ -649,7 +650,7 @@ __device__ __forceinline__ void emb_bwd_body(const EmbArgs& p, int bx) {
       for (int j = 0; j < 8; ++j) s += v[j];
     }
     s = wave_sum(s);
-    if (lane == 0) p.dt[e] += s;
+    if (lane == 0) atomic_add_f32(p.dt + e, s);      // (two ops on one table may share a parallel group; 0 + a + b is order-independent)
     return;
   }
   const int id = bx * 256 + threadIdx.x;
@@ -1459,6 +1460,25 @@ __global__ __launch_bounds__(256) void chain_kernel(const SmallEntry* __restrict
   }
 }
 
+// HP_FLAG_PARALLEL: the members are independent — every workgroup runs ONE virtual block of one member.  Only the leaf
+// reductions the planner groups (hp::groupable) are dispatched here: a kernel carries the LDS of EVERY body it can reach,
+// and with the Linear forward's 56 KB of staging buffers in it the group ran two workgroups per CU (56-61 us for what ten
+// stand-alone launches do in 31 us).
+__global__ __launch_bounds__(256) void small_group_kernel(const SmallEntry* __restrict__ entries, int n) {
+  int b = blockIdx.x;
+  for (int k = 0; k < n; ++k) {
+    const SmallEntry& e = entries[k];
+    const int nb = e.gx * e.gy * e.gz;
+    if (b < nb) {
+      const int bx = b % e.gx, by = (b / e.gx) % e.gy, bz = b / (e.gx * e.gy);
+      if (e.op == HP_OP_LINEAR_BWD_W) linear_bwd_w_body(e.a.lin, e.rows_per_z, bx, by, bz);
+      else if (e.op == HP_OP_EMB_BWD) emb_bwd_body(e.a.emb, bx);
+      return;
+    }
+    b -= nb;
+  }
+}
+
 }  // namespace
 
 template <int V> inline int rows_per_thread(const BnApplyArgs& a) { return bn_rows<V>(a.M, a.C); }
@@ -1725,6 +1745,20 @@ hipError_t hp::build_chain(const HpOp* members, int count, void* const* bases, v
   hipError_t e = hipMalloc(d_entries, entries.size() * sizeof(SmallEntry));
   if (e != hipSuccess) return e;
   return hipMemcpy(*d_entries, entries.data(), entries.size() * sizeof(SmallEntry), hipMemcpyHostToDevice);
+}
+
+bool hp::groupable(const HpOp& op) { return op.op == HP_OP_LINEAR_BWD_W || op.op == HP_OP_EMB_BWD; }
+
+hipError_t hp::launch_small_group(const HpOp* members, const void* d_entries, int count, hipStream_t s) {
+  int blocks = 0;
+  void* const zero_bases[HP_NUM_SPACES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  for (int j = 0; j < count; ++j) {
+    SmallEntry e;
+    if (!small_entry(members[j], zero_bases, e)) return hipErrorInvalidValue;      // (grid only: the device table holds the pointers)
+    blocks += e.gx * e.gy * e.gz;
+  }
+  hipLaunchKernelGGL(small_group_kernel, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
+  return hipGetLastError();
 }
 
 hipError_t hp::launch_chain(const void* d_entries, int count, hipStream_t s) {

@@ -68,6 +68,7 @@ hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
   if (op.flags & HP_FLAG_MEMBER) return hipSuccess;            // done by its group / pair / chain launch
   if ((op.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK) {
     const HpProgram::Group& g = p->groups[k];
+    if (op.flags & HP_FLAG_PARALLEL) return hp::launch_small_group(&p->ops[k - (g.chain_len - 1)], g.chain, g.chain_len, s);
     return hp::launch_chain(g.chain, g.chain_len, s);
   }
   if (op.op == HP_OP_WGRAD_GROUP) {
@@ -355,7 +356,7 @@ int hp_program_validate(const HpProgram* p) {
         return fail("chain ending at op " + std::to_string(k) + ": bad length");
       for (int j = (int)k - nchain; j <= (int)k; ++j) {
         const HpOp& m = p->ops[j];
-        if ((j < (int)k && !(m.flags & HP_FLAG_MEMBER)) || !hp::chainable(m) ||
+        if ((j < (int)k && !(m.flags & HP_FLAG_MEMBER)) || !hp::chainable(m) || ((p->ops[k].flags & HP_FLAG_PARALLEL) && !hp::groupable(m)) ||
             (j < (int)k && ((m.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK)))
           return fail("chain ending at op " + std::to_string(k) + ": member " + std::to_string(j) + " is not a chainable member record");
       }

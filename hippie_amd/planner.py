@@ -77,6 +77,9 @@ class TrainCfg:
                                         # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
                                         # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
                                         # weights and AdamW stay fp32.  Own tolerance (tests/test_gpu_bf16.py), own bench line
+    group_small_wgrads: bool = True     # the small weight-gradient reductions of a backward pass (the heads' Linear dW/db, the embedding
+                                        # tables) are leaves: deferred to the end of the pass and run side by side in ONE launch
+                                        # (HP_FLAG_PARALLEL chain) instead of ten launches of ~3 us each
     reuse_workspace: bool = True        # liveness-based packing of the workspace arena (pack_workspace): tensors that only the backward
                                         # pass touches share memory once dead, and so do the eval forward's; training-forward tensors
                                         # (all needed by the backward pass) and named I/O slots keep their own memory
@@ -203,6 +206,7 @@ class Lowering:
         self.pl = Plan(cfg, batch, self.train, with_class)
         self.o = self.pl.ops
         self.pending_wgrads = []
+        self.pending_small = []              # deferred small leaf ops of the backward pass: (op, flags, i, f, buf, note)
         self.conv_rec_of = {}                # encoded OUT ref -> index of the CONV_TAPS record that produced it
         self.count_flops = False          # forward FLOPs (2*MAC, conv + linear) are counted for the training forward only
         if self.train.mfma_dtype not in ("f32", "bf16"):
@@ -544,7 +548,7 @@ class Lowering:
             self.pl.flops_fwd += 2 * M * lin["N"] * lin["K"]
 
     def linear_bwd(self, M, lin, dy, ldy, x, ldx, dx=None, lddx=None, mask=None, ldmask=0, accumulate=False, note=""):
-        self.o.add(P.LINEAR_BWD_W, self.det_flag, i=[M, lin["N"], lin["K"], ldy, ldx], buf=[dy, x, lin["w"].gref, lin["b"].gref], note=note + " dW")
+        self.small_leaf(P.LINEAR_BWD_W, self.det_flag, [M, lin["N"], lin["K"], ldy, ldx], (), [dy, x, lin["w"].gref, lin["b"].gref], note + " dW")
         if dx is not None:
             self.o.add(P.LINEAR_BWD_X, 0, i=[M, lin["N"], lin["K"], ldy, lddx, 1 if mask is not None else 0, ldmask, 1 if accumulate else 0],
                        f=[SLOPE_HEADS], buf=[dy, lin["w"].ref, dx, mask], note=note + " dX")
@@ -845,9 +849,18 @@ class Lowering:
 
     def emb_bwd(self, dcat, ld, col0):
         H = self.cfg.class_hidden_dim
-        self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0, self.cfg.num_sources], buf=[dcat, self.src, self.semb.gref], note="source_embedding grad")
+        self.small_leaf(P.EMB_BWD, 0, [self.B, H, ld, col0, self.cfg.num_sources], (), [dcat, self.src, self.semb.gref], "source_embedding grad")
         if self.with_class:
-            self.o.add(P.EMB_BWD, 0, i=[self.B, H, ld, col0 + H, self.cfg.num_classes], buf=[dcat, self.cls, self.cemb.gref], note="class_embedding grad")
+            self.small_leaf(P.EMB_BWD, 0, [self.B, H, ld, col0 + H, self.cfg.num_classes], (), [dcat, self.cls, self.cemb.gref], "class_embedding grad")
+
+    def small_leaf(self, op, flags, i, f, buf, note):
+        """A small op of the backward pass whose result nothing else in the pass reads (a weight / bias / embedding-table
+        gradient) and whose operands stay untouched to the end of the pass: emitted where it stands, or — with
+        group_small_wgrads — deferred to flush_wgrads and run side by side with the other leaves in one launch."""
+        if self.train.group_small_wgrads:
+            self.pending_small.append((op, flags, list(i), list(f), list(buf), note))
+        else:
+            self.o.add(op, flags, i=i, f=f, buf=buf, note=note)
 
     def flush_wgrads(self, seg, only_if=True):
         """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, in their own segment
@@ -862,6 +875,14 @@ class Lowering:
                 self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag, i=tm.ints() + [nsplit, rps, w.numel],
                            f=[SLOPE_BACKBONE], buf=[dy, x, w.gref, coef], note=note)
             self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
+        if only_if and self.pending_small:
+            n = len(self.pending_small)
+            for j, (op, flags, i, f, buf, note) in enumerate(self.pending_small):
+                if n > 1:
+                    flags |= P.FLAG_MEMBER if j < n - 1 else (((n - 1) << P.FLAG_CHAIN_SHIFT) | P.FLAG_PARALLEL)
+                    note += " [grouped]" if j < n - 1 else f" [group of {n} small weight gradients]"
+                self.o.add(op, flags, i=i, f=f, buf=buf, note=note)
+            self.pending_small = []
         if only_if:
             self.pending_wgrads = []
         self.o.end()

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 3
+#define HP_ABI_VERSION 4
 
 enum {
   HP_SPACE_WS = 0, HP_SPACE_PARAM = 1, HP_SPACE_GRAD = 2, HP_SPACE_BUF = 3,
@@ -77,6 +77,11 @@ static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 10
 #define HP_FLAG_CHAIN_SHIFT 16
 #define HP_FLAG_CHAIN_MASK 0xFF
 #define HP_CHAIN_MAX 64
+/* On the LAST record of a chain: the n + 1 records are INDEPENDENT of each other (no record reads what another writes) and
+ * run side by side in ONE launch — the grid is the concatenation of the members' own grids.  The planner defers the
+ * small weight-gradient reductions of a backward pass (the heads' Linear dW/db, the embedding tables) into such a group:
+ * ten 3 us launches, each mostly launch floor, become one. */
+#define HP_FLAG_PARALLEL 0x1000000
 
 /* One op record (POD, 8-byte aligned; numpy dtype mirror in hippie_amd/program.py). */
 typedef struct HpOp {

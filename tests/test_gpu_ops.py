@@ -818,3 +818,46 @@ def test_conv_in_dr_equals_bn_bwd_apply_then_conv(variant):
         np.testing.assert_array_equal(g_(sd["dr_a"], rows * K), g_(sd["dr_b"], rows * K))
         np.testing.assert_array_equal(g_(sd["dga"], K), g_(sd["dgb"], K))
         np.testing.assert_array_equal(g_(sd["dba"], K), g_(sd["dbb"], K))
+
+
+def test_parallel_group_of_small_weight_gradients_equals_standalone_launches():
+    """HP_FLAG_PARALLEL: independent small leaf ops (Linear weight / bias gradients of different layers, two embedding
+    gradients into ONE table) run side by side in one launch — against the interpreter and against one launch per record."""
+    Bn, H = 300, 5
+    img = Img(61)
+    shapes = [(20, 30), (10, 20), (20, 10), (100, 64), (512, 20)]          # (N, K) of the layers
+    members, outs = [], {}
+    for j, (N, K) in enumerate(shapes):
+        dy, x = img.f32(Bn * N), img.f32(Bn * K)
+        dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
+        members.append((P.LINEAR_BWD_W, 0, [Bn, N, K, N, K], (), [dy, x, dw, db]))
+        outs[f"dw{j}"] = (dw, N * K)
+        outs[f"db{j}"] = (db, N)
+    src = img.i64(img.rng.integers(0, 5, Bn))
+    dsemb = img.f32(5 * H, zero=True)
+    for j in range(2):                                                      # decoder-side and encoder-side contribution
+        dcat = img.f32(Bn * 30)
+        members.append((P.EMB_BWD, 0, [Bn, H, 30, 20, 5], (), [dcat, src, dsemb]))
+    outs["dsemb"] = (dsemb, 5 * H)
+    single, group = P.OpList(), P.OpList()
+    n = len(members)
+    for j, (op, fl, i, f, buf) in enumerate(members):
+        single.add(op, fl, i, f, buf)
+        group.add(op, fl | (P.FLAG_MEMBER if j < n - 1 else (((n - 1) << P.FLAG_CHAIN_SHIFT) | P.FLAG_PARALLEL)), i, f, buf)
+    gpu_single, cpu = run_both(img, single.array())
+    image = img.image()
+    dev = torch.from_numpy(image.copy()).cuda()
+    prog = P.DeviceProgram(group.array(), [dev.data_ptr()] * 6, [image.size] + [4] * 5)
+    seg = prog.capture(0, n)
+    prog.replay(seg, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    gpu_group = dev.cpu().numpy()
+    for name, (ref, cnt) in outs.items():
+        check(gpu_group, cpu, ref, cnt, rel=3e-5, what="group vs interpreter: " + name)
+        a, b = view(gpu_single, ref, np.float32, cnt), view(gpu_group, ref, np.float32, cnt)
+        assert np.abs(a - b).max() <= 2e-6 * max(np.abs(a).max(), 1e-30), name       # (fp32 atomics: last bits)
+    # a member that is not independent-launchable is refused at program creation
+    bad = group.array().copy()
+    bad[0]["op"] = P.CONV_TAPS
+    with pytest.raises(P.HipEngineError):
+        P.DeviceProgram(bad, [dev.data_ptr()] * 6, [image.size] + [4] * 5)
