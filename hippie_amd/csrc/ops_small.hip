@@ -133,6 +133,8 @@ struct BnApplyArgs {
   float* rmean2; float* rvar2; float* save2;
   int M, C, res_mode, training, act;
   int Mstat;          // rows behind the statistics: M, or M * world under sync-BatchNorm (HP_OP_STATS_SYNC)
+  int grp;            // row-sliced launch (HP_FLAG_ROWWISE): index of the workgroup's row slice; 0 otherwise.  "Workgroup 0"
+                      // (side effects, replica choice) is bx + grp == 0
   float slope, eps, momentum;
 };
 
@@ -176,7 +178,7 @@ __device__ __forceinline__ void bn_apply_impl(const BnApplyArgs& p, const int bx
       k2 = bn_coef(p.training, p.Mstat, p.stats2, p.C, c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
       s_coef[2][ci] = k2.scale; s_coef[3][ci] = k2.shift;
     }
-    if (p.training && bx == 0) {
+    if (p.training && bx + p.grp == 0) {
       bn_side_effects(k, p.Mstat, p.C, c, p.save, p.rmean, p.rvar, p.momentum);
       if (RES == 2) bn_side_effects(k2, p.Mstat, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
     }
@@ -252,6 +254,7 @@ struct BnBwdReduceArgs {
   const float* raw2; const float* save2; double* bs2;
   const float* coef;     // act == nullptr: the activation was never stored; its sign is that of fma(raw, scale, shift)
   int M, C, has_second;
+  int grp;               // row-sliced launch: see BnApplyArgs
   int rpl;               // rows per thread (bn_red_rpl): sets the grid and the number of atomic adds per statistics replica
   float slope;
 };
@@ -360,11 +363,11 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
     const int q = o / V, j = o - q * V, c = c_base + o;
     if (c >= p.C) continue;
     const double s0 = lds[(3 * j + 0) * 256 + q], s1 = lds[(3 * j + 1) * 256 + q];
-    double* b1 = stat_replica(p.bs, p.C, bx);
+    double* b1 = stat_replica(p.bs, p.C, bx + p.grp);
     atomic_add_f64(b1 + c, s0);
     atomic_add_f64(b1 + p.C + c, s1);
     if (p.has_second) {
-      double* b2 = stat_replica(p.bs2, p.C, bx);
+      double* b2 = stat_replica(p.bs2, p.C, bx + p.grp);
       atomic_add_f64(b2 + c, s0);
       atomic_add_f64(b2 + p.C + c, lds[(3 * j + 2) * 256 + q]);
     }
@@ -378,6 +381,7 @@ struct BnBwdApplyArgs {
   float* dr; float* dgamma; float* dbeta;
   int M, C;
   int Mstat;          // M * world under sync-BatchNorm: BS then holds the sums over all ranks
+  int grp;            // row-sliced launch: see BnApplyArgs
   float gscale;       // 1 / world: dgamma / dbeta are written so that the data-parallel MEAN of the ranks gives the sum
 };
 
@@ -406,7 +410,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
     stat_sum2(p.bs, p.C, c, sg, sgx);
     const BnDrCoef k = bn_dr_coef(mean, invstd, gam, sg, sgx, p.Mstat);
     s_coef[0][ci] = k.A; s_coef[1][ci] = k.B; s_coef[2][ci] = k.C;
-    if (bx == 0) { p.dgamma[c] = (float)(sgx * (double)p.gscale); p.dbeta[c] = (float)(sg * (double)p.gscale); }
+    if (bx + p.grp == 0) { p.dgamma[c] = (float)(sgx * (double)p.gscale); p.dbeta[c] = (float)(sg * (double)p.gscale); }
   }
   __syncthreads();
   if (!m.active) return;
@@ -667,6 +671,7 @@ struct LinArgs {
   const float* X; const float* W; const float* Bv; float* Y; double* stats;
   const float* DY; float* DX; const float* ACT; float* DW; float* DB;
   int M, N, K, ldx, ldy, act, has_mask, lda, accumulate;
+  int grp;            // row-sliced launch: see BnApplyArgs
   float slope;
 };
 // one thread per output (small K).  Statistics (the following BatchNorm's sum / sum of squares per column): the workgroup's
@@ -737,7 +742,7 @@ __device__ __forceinline__ void linear_fwd_thread_body(const LinArgs& p, int bx)
         const int first = (int)(((int64_t)threadIdx.x - ((int64_t)bx * 256) % p.N + p.N) % p.N);
         double a = 0.0, b = 0.0;
         for (int i = first; i < 256; i += p.N) { a += s_st[0][i]; b += s_st[1][i]; }
-        double* st = stat_replica(p.stats, p.N, bx);
+        double* st = stat_replica(p.stats, p.N, bx + p.grp);
         atomic_add_f64(st + threadIdx.x, a);
         atomic_add_f64(st + p.N + threadIdx.x, b);
       }
@@ -854,7 +859,8 @@ __device__ __forceinline__ void block_atomic_f64(double v, double* dst) {
     atomic_add_f64(dst, s);
   }
 }
-struct ReparamArgs { const float* mulv; const float* eps; float* z; double* loss; const float* dz; float* dmulv; int B, zd, lddz; float beta; };
+struct ReparamArgs { const float* mulv; const float* eps; float* z; double* loss; const float* dz; float* dmulv; int B, zd, lddz; float beta;
+                     int Bfull; };      // row-sliced launch: the batch size behind the KL mean (0 = B)
 __device__ __forceinline__ void reparam_kl_fwd_body(const ReparamArgs& p, int bx) {
   const float* mulv = p.mulv; const float* eps = p.eps; float* z = p.z; double* loss = p.loss;
   const int B = p.B, zd = p.zd;
@@ -878,7 +884,7 @@ __device__ __forceinline__ void reparam_kl_bwd_body(const ReparamArgs& p, int bx
   const int b = id / zd, j = id - b * zd;
   const float mu = mulv[(size_t)b * 2 * zd + j], lv = mulv[(size_t)b * 2 * zd + zd + j];
   const float g = dz[(size_t)b * lddz + j];
-  const float invB = 1.f / (float)B;
+  const float invB = 1.f / (float)(p.Bfull > 0 ? p.Bfull : B);
   dmulv[(size_t)b * 2 * zd + j] = g + beta * mu * invB;
   dmulv[(size_t)b * 2 * zd + zd + j] = g * eps[id] * 0.5f * expf(0.5f * lv) + beta * 0.5f * (expf(lv) - 1.f) * invB;
 }
@@ -1243,6 +1249,7 @@ BnApplyArgs bn_apply_args(const HpOp& op, void* const* bases) {
   a.rmean2 = ptr<float>(op, 12, bases); a.rvar2 = ptr<float>(op, 13, bases); a.save2 = ptr<float>(op, 14, bases);
   a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
   a.Mstat = I[0] * (I[5] > 1 ? I[5] : 1);
+  a.grp = 0;
   a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
   return a;
 }
@@ -1256,6 +1263,7 @@ BnBwdReduceArgs bn_bwd_reduce_args(const HpOp& op, void* const* bases) {
   a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
   a.coef = ptr<const float>(op, 10, bases);
   a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
+  a.grp = 0;
   a.rpl = bn_red_rpl(a.M, a.C);
   return a;
 }
@@ -1268,6 +1276,7 @@ BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
   a.M = op.i[0]; a.C = op.i[1];
   const int w = op.i[2] > 1 ? op.i[2] : 1;
   a.Mstat = a.M * w; a.gscale = 1.f / (float)w;
+  a.grp = 0;
   return a;
 }
 
@@ -1457,6 +1466,101 @@ __global__ __launch_bounds__(256) void chain_kernel(const SmallEntry* __restrict
     __threadfence();
     __syncthreads();
     __threadfence();
+  }
+}
+
+// ---- HP_FLAG_ROWWISE: a run of ROW-LOCAL small ops (the heads between two BatchNorm reductions) as one launch ------------
+// Every member maps rows of its inputs to the same rows of its outputs (column sums leave through atomics and are read by a
+// LATER launch).  Workgroup g therefore runs the whole run on rows [g*R, (g+1)*R) alone: the members' own kernel bodies on
+// a copy of their arguments whose row-indexed pointers are advanced by g*R rows and whose row count is cut to R (one
+// virtual block each: R * widest member <= 256), a workgroup barrier + fence between members.  Unlike the single-workgroup
+// chain, the dependent round trips of the run are paid once per R rows IN PARALLEL, not once per virtual block in series.
+static bool row_slice(SmallEntry& e, int r0, int R, int g) {      // (host: hp::build_rowchain)
+  switch (e.op) {
+    case HP_OP_BN_APPLY: {
+      BnApplyArgs& a = e.a.bn_apply;
+      const size_t o = (size_t)r0 * a.C;
+      a.raw += o; a.out += o;
+      if (a.res != nullptr) a.res += o;
+      a.M = std::min(R, a.M - r0); a.grp = g;
+      return true;
+    }
+    case HP_OP_BN_BWD_REDUCE: {
+      BnBwdReduceArgs& a = e.a.bn_red;
+      const size_t o = (size_t)r0 * a.C;
+      a.g1 += o; a.gout += o; a.raw += o;
+      if (a.g2 != nullptr) a.g2 += o;
+      if (a.act != nullptr) a.act += o;
+      if (a.raw2 != nullptr) a.raw2 += o;
+      a.M = std::min(R, a.M - r0); a.grp = g;
+      return true;
+    }
+    case HP_OP_BN_BWD_APPLY: {
+      BnBwdApplyArgs& a = e.a.bn_bapply;
+      const size_t o = (size_t)r0 * a.C;
+      a.g += o; a.raw += o; a.dr += o;
+      a.M = std::min(R, a.M - r0); a.grp = g;
+      return true;
+    }
+    case HP_OP_CONCAT: {
+      ConcatArgs& a = e.a.concat;
+      a.out += (size_t)r0 * a.ldo;
+      for (int j = 0; j < a.nseg; ++j) {
+        if (a.kind[j] == 0) a.src[j] += (size_t)r0 * a.ld[j];
+        else if (a.kind[j] == 1) a.idx[j] += r0;
+      }
+      a.B = std::min(R, a.B - r0);
+      return true;
+    }
+    case HP_OP_LINEAR_FWD: {
+      LinArgs& a = e.a.lin;
+      a.X += (size_t)r0 * a.ldx; a.Y += (size_t)r0 * a.ldy;
+      a.M = std::min(R, a.M - r0); a.grp = g;
+      return true;
+    }
+    case HP_OP_LINEAR_BWD_X: {
+      LinArgs& a = e.a.lin;
+      a.DY += (size_t)r0 * a.ldy; a.DX += (size_t)r0 * a.ldx;
+      if (a.has_mask) a.ACT += (size_t)r0 * a.lda;
+      a.M = std::min(R, a.M - r0);
+      return true;
+    }
+    case HP_OP_REPARAM_KL_FWD: {
+      ReparamArgs& a = e.a.rp;
+      a.mulv += (size_t)r0 * 2 * a.zd; a.eps += (size_t)r0 * a.zd; a.z += (size_t)r0 * a.zd;
+      a.B = std::min(R, a.B - r0);
+      return true;
+    }
+    case HP_OP_REPARAM_KL_BWD: {
+      ReparamArgs& a = e.a.rp;
+      a.Bfull = a.B;
+      a.mulv += (size_t)r0 * 2 * a.zd; a.eps += (size_t)r0 * a.zd; a.dz += (size_t)r0 * a.lddz; a.dmulv += (size_t)r0 * 2 * a.zd;
+      a.B = std::min(R, a.B - r0);
+      return true;
+    }
+    default:
+      return false;
+  }
+}
+
+// entries[g * n + k]: member k's arguments sliced to the rows of workgroup g (host: hp::build_rowchain).  The record is staged
+// in LDS: read through the global pointer, every argument access after a barrier was its own memory round trip (~10 us per
+// member).
+__global__ __launch_bounds__(256) void rowchain_kernel(const SmallEntry* __restrict__ entries, int n) {
+  __shared__ double lds_d[3 * 4 * 256];
+  __shared__ SmallEntry s_e;
+  float* lds_f = reinterpret_cast<float*>(lds_d);
+  const SmallEntry* mine = entries + (size_t)blockIdx.x * n;
+  for (int k = 0; k < n; ++k) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(mine + k);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_e);
+    for (int i = threadIdx.x; i < (int)(sizeof(SmallEntry) / 4); i += 256) dst[i] = src[i];
+    __syncthreads();
+    small_block(s_e, 0, 0, 0, lds_d, lds_f);
+    // The next member reads the rows this one wrote — rows of THIS workgroup only: the barrier's workgroup-scope release /
+    // acquire is all that is needed.  (An agent-scope __threadfence() here writes back the L2 on this multi-XCD part:
+    // measured ~5 us each, 10 us per member.)
+    __syncthreads();
   }
 }
 
@@ -1745,6 +1849,53 @@ hipError_t hp::build_chain(const HpOp* members, int count, void* const* bases, v
   hipError_t e = hipMalloc(d_entries, entries.size() * sizeof(SmallEntry));
   if (e != hipSuccess) return e;
   return hipMemcpy(*d_entries, entries.data(), entries.size() * sizeof(SmallEntry), hipMemcpyHostToDevice);
+}
+
+// HP_FLAG_ROWWISE: rows and per-row width of a member, or false if the op is not row-sliceable
+static bool row_shape(const HpOp& op, int& rows, int& width) {
+  const int32_t* I = op.i;
+  switch (op.op) {
+    case HP_OP_BN_APPLY: if (I[2] != 0) return false; rows = I[0]; width = I[1]; return true;       // (no residual forms in the heads)
+    case HP_OP_BN_BWD_REDUCE: rows = I[0]; width = I[1]; return true;
+    case HP_OP_BN_BWD_APPLY: rows = I[0]; width = I[1]; return true;
+    case HP_OP_CONCAT: rows = I[0]; width = I[2]; return true;
+    case HP_OP_LINEAR_FWD: rows = I[0]; width = I[1]; return I[2] < 128 && I[1] <= 256;
+    case HP_OP_LINEAR_BWD_X: rows = I[0]; width = I[2]; return I[1] < 128;
+    case HP_OP_REPARAM_KL_FWD: case HP_OP_REPARAM_KL_BWD: rows = I[0]; width = I[1]; return true;
+    default: return false;
+  }
+}
+// rows per workgroup of a row-wise chain (0 = the records do not form one): all members over the same rows, the widest
+// member's R rows fit one 256-thread virtual block
+int hp::rowchain_rows(const HpOp* members, int count) {
+  int rows = -1, wmax = 1;
+  for (int j = 0; j < count; ++j) {
+    int r, w;
+    if (!row_shape(members[j], r, w) || w < 1 || w > 64) return 0;
+    if (rows >= 0 && r != rows) return 0;
+    rows = r;
+    wmax = w > wmax ? w : wmax;
+  }
+  return rows > 0 ? 256 / wmax : 0;
+}
+hipError_t hp::build_rowchain(const HpOp* members, int count, void* const* bases, void** d_entries, int* ngroups) {
+  const int R = hp::rowchain_rows(members, count);
+  if (R < 1) return hipErrorInvalidValue;
+  const int M = members[0].i[0], G = hp::cdiv(M, R);
+  std::vector<SmallEntry> entries((size_t)G * count);
+  for (int g = 0; g < G; ++g)
+    for (int j = 0; j < count; ++j) {
+      SmallEntry& e = entries[(size_t)g * count + j];
+      if (!small_entry(members[j], bases, e) || !row_slice(e, g * R, R, g)) return hipErrorInvalidValue;
+    }
+  *ngroups = G;
+  hipError_t err = hipMalloc(d_entries, entries.size() * sizeof(SmallEntry));
+  if (err != hipSuccess) return err;
+  return hipMemcpy(*d_entries, entries.data(), entries.size() * sizeof(SmallEntry), hipMemcpyHostToDevice);
+}
+hipError_t hp::launch_rowchain(const void* d_entries, int count, int ngroups, hipStream_t s) {
+  hipLaunchKernelGGL(rowchain_kernel, dim3(ngroups), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
+  return hipGetLastError();
 }
 
 bool hp::groupable(const HpOp& op) { return op.op == HP_OP_LINEAR_BWD_W || op.op == HP_OP_EMB_BWD; }

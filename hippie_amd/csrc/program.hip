@@ -13,7 +13,7 @@ struct HpProgram {
   std::vector<hipGraphExec_t> segs;
   std::vector<hipGraph_t> graphs;
   hipStream_t capture_stream = nullptr;
-  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; bool bf16 = false; void* chain = nullptr; int chain_len = 0; };
+  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; bool bf16 = false; void* chain = nullptr; int chain_len = 0; int row_groups = 0; };
   std::vector<Group> groups;          // indexed by op index (empty entries for ops without device tables)
   bool groups_ready = false;
 };
@@ -40,7 +40,8 @@ int ensure_groups(HpProgram* p) {
     if (nchain > 0) {
       HpProgram::Group& g = p->groups[k];
       g.chain_len = nchain + 1;
-      hipError_t e = hp::build_chain(&p->ops[k - nchain], nchain + 1, p->bases, &g.chain);
+      hipError_t e = (op.flags & HP_FLAG_ROWWISE) ? hp::build_rowchain(&p->ops[k - nchain], nchain + 1, p->bases, &g.chain, &g.row_groups)
+                                                  : hp::build_chain(&p->ops[k - nchain], nchain + 1, p->bases, &g.chain);
       if (e != hipSuccess) return fail_hip("building chain table", e);
       continue;
     }
@@ -68,6 +69,7 @@ hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
   if (op.flags & HP_FLAG_MEMBER) return hipSuccess;            // done by its group / pair / chain launch
   if ((op.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK) {
     const HpProgram::Group& g = p->groups[k];
+    if (op.flags & HP_FLAG_ROWWISE) return hp::launch_rowchain(g.chain, g.chain_len, g.row_groups, s);
     if (op.flags & HP_FLAG_PARALLEL) return hp::launch_small_group(&p->ops[k - (g.chain_len - 1)], g.chain, g.chain_len, s);
     return hp::launch_chain(g.chain, g.chain_len, s);
   }
@@ -360,6 +362,8 @@ int hp_program_validate(const HpProgram* p) {
             (j < (int)k && ((m.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK)))
           return fail("chain ending at op " + std::to_string(k) + ": member " + std::to_string(j) + " is not a chainable member record");
       }
+      if ((p->ops[k].flags & HP_FLAG_ROWWISE) && ((p->ops[k].flags & HP_FLAG_PARALLEL) || hp::rowchain_rows(&p->ops[k - nchain], nchain + 1) < 1))
+        return fail("chain ending at op " + std::to_string(k) + ": not a row-wise chain (row-local members over the same rows, at most 64 wide)");
     }
     if (p->ops[k].op == HP_OP_WGRAD_GROUP) {
       const HpOp& g = p->ops[k];

@@ -123,8 +123,8 @@ class PairEngine:
         import dataclasses
         # the zipped program pairs A with B; pairs inside one model would nest
         # (and no chained launches: the zip interleaves the two models' records, a chain needs consecutive ones)
-        ta = dataclasses.replace(train_a or planner.TrainCfg(), intra_pair=False, chain_small=False, group_small_wgrads=False)
-        tb = dataclasses.replace(train_b or planner.TrainCfg(), intra_pair=False, chain_small=False, group_small_wgrads=False)
+        ta = dataclasses.replace(train_a or planner.TrainCfg(), intra_pair=False, chain_small=False, group_small_wgrads=False, fuse_heads=False)
+        tb = dataclasses.replace(train_b or planner.TrainCfg(), intra_pair=False, chain_small=False, group_small_wgrads=False, fuse_heads=False)
         plans = [planner.lower(cfg_a, batch, ta), planner.lower(cfg_b, batch, tb)]
         self.ops, self.segments, self.notes, bases_b = zip_programs(*plans)
         sa, sb = arena_sizes(plans[0]), arena_sizes(plans[1])

@@ -77,6 +77,13 @@ class TrainCfg:
                                         # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
                                         # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
                                         # weights and AdamW stay fp32.  Own tolerance (tests/test_gpu_bf16.py), own bench line
+    fuse_heads: bool = False            # runs of row-local head ops between two BatchNorm reductions (concat / Linear / BatchNorm apply /
+                                        # reparameterisation and their backward counterparts, <= 64 wide, one row per sample) execute as
+                                        # ONE launch in which every workgroup takes a few rows through the whole run (HP_FLAG_ROWWISE):
+                                        # 165 -> 151 launches per model-step, bit-identical (tests), and NO faster — each member is still
+                                        # two dependent L2 round trips (its inputs were just stored by the previous member), ~3 us, which
+                                        # is what the stand-alone launch costs including its floor (6-op run: 17 us vs 18 us).  The rows
+                                        # would have to stay in LDS across members (purpose-built bodies).  Off by default; DESIGN.md 8.
     group_small_wgrads: bool = True     # the small weight-gradient reductions of a backward pass (the heads' Linear dW/db, the embedding
                                         # tables) are leaves: deferred to the end of the pass and run side by side in ONE launch
                                         # (HP_FLAG_PARALLEL chain) instead of ten launches of ~3 us each
@@ -1102,6 +1109,8 @@ class Lowering:
         for key in ("train_zero", "eval_zero"):
             self.o.recs[segs[key]]["i"][0] = used
             self.o.recs[segs[key]]["i"][1] = 0
+        if self.train.fuse_heads and not self.train.chain_small and self.train.sync_bn_world <= 1:
+            apply_rowchains(self.o, ("fwd_train", "bwd_a", "bwd_b"), self.B)
         if self.train.chain_small and self.train.sync_bn_world <= 1:
             f_eval = self.o.segments["fwd_eval"][0]
             enc_eval_end = f_eval + self.o.segments["enc_eval"][1]
@@ -1234,6 +1243,59 @@ def pack_workspace(pl, serial_backward=True):
     pl.ws_unpacked = pl.ws_bytes
     pl.allocs = [[new_off[j], a[1], a[2]] for j, a in enumerate(allocs)]
     pl._ws = top
+
+
+def row_shape(r):
+    """(rows, width) of a record if the op is row-local and sliceable by rows (mirror of row_shape in csrc/ops_small.hip), else None."""
+    op, I = int(r["op"]), r["i"]
+    if op == P.BN_APPLY:
+        return (int(I[0]), int(I[1])) if int(I[2]) == 0 else None
+    if op in (P.BN_BWD_REDUCE, P.BN_BWD_APPLY):
+        return int(I[0]), int(I[1])
+    if op == P.CONCAT:
+        return int(I[0]), int(I[2])
+    if op == P.LINEAR_FWD:
+        return (int(I[0]), int(I[1])) if int(I[2]) < 128 and int(I[1]) <= 256 else None
+    if op == P.LINEAR_BWD_X:
+        return (int(I[0]), int(I[2])) if int(I[1]) < 128 else None
+    if op in (P.REPARAM_KL_FWD, P.REPARAM_KL_BWD):
+        return int(I[0]), int(I[1])
+    return None
+
+
+def apply_rowchains(oplist, segments, batch):
+    """Mark maximal runs (length >= 2) of consecutive row-local head records — one row per sample, at most 64 values wide —
+    as HP_FLAG_ROWWISE chains.  A run never continues INTO a training-mode BN_APPLY or a BN_BWD_APPLY: those read column
+    sums that must be complete, i.e. produced by an earlier launch.  No record moves."""
+    recs = oplist.recs
+    for seg in segments:
+        if seg not in oplist.segments:
+            continue
+        first, count = oplist.segments[seg]
+        run = []
+
+        def flush():
+            if len(run) >= 2:
+                for k in run[:-1]:
+                    recs[k]["flags"] = int(recs[k]["flags"]) | P.FLAG_MEMBER
+                    oplist.notes[k] += " [row-chained]"
+                recs[run[-1]]["flags"] = int(recs[run[-1]]["flags"]) | ((len(run) - 1) << P.FLAG_CHAIN_SHIFT) | P.FLAG_ROWWISE
+                oplist.notes[run[-1]] += f" [row-wise chain of {len(run)}]"
+            run.clear()
+
+        for k in range(first, first + count):
+            r = recs[k]
+            shp = row_shape(r)
+            fl = int(r["flags"])
+            ok = (shp is not None and shp[0] == batch and 1 <= shp[1] <= 64 and not (fl & P.FLAG_MEMBER)
+                  and not ((fl >> P.FLAG_CHAIN_SHIFT) & P.FLAG_CHAIN_MASK))
+            op = int(r["op"])
+            needs_complete_sums = (op == P.BN_APPLY and int(r["i"][3]) == 1) or op == P.BN_BWD_APPLY
+            if not ok or needs_complete_sums or len(run) >= P.CHAIN_MAX - 1:
+                flush()
+            if ok:
+                run.append(k)
+        flush()
 
 
 CHAIN_WORK_MAX = 700_000        # per-op work (FMA-equivalents) one 256-thread workgroup may take on inside a chained launch

@@ -32,6 +32,7 @@ OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k
 CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16, CONV_IN_DR = 1, 2, 4, 8, 16, 64, 128, 256, 1024
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the chain it belongs to
 FLAG_CHAIN_SHIFT, FLAG_CHAIN_MASK, CHAIN_MAX = 16, 0xFF, 64     # chained launch: see include/hippie_hip.h
+FLAG_ROWWISE = 0x2000000                                     # ... whose members are row-local: each workgroup takes R rows through all of them
 FLAG_PARALLEL = 0x1000000                                    # ... whose members are independent: one launch, concatenated grids
 STAT_REPL_MAX = 16       # HP_STAT_REPL_MAX
 

@@ -82,6 +82,11 @@ static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 10
  * small weight-gradient reductions of a backward pass (the heads' Linear dW/db, the embedding tables) into such a group:
  * ten 3 us launches, each mostly launch floor, become one. */
 #define HP_FLAG_PARALLEL 0x1000000
+/* On the LAST record of a chain: every member is ROW-LOCAL (row r of its outputs depends on row r of its inputs only; column
+ * sums leave through atomics and are read by a later launch) over the same number of rows, at most 64 values wide.  The
+ * run executes as ONE launch in which each workgroup takes R = 256 / (widest member) rows through all members — the cVAE
+ * heads between two BatchNorm reductions (model.py:21-41,51-62). */
+#define HP_FLAG_ROWWISE 0x2000000
 
 /* One op record (POD, 8-byte aligned; numpy dtype mirror in hippie_amd/program.py). */
 typedef struct HpOp {

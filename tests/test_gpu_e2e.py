@@ -21,10 +21,10 @@ def n(t):
     return t.detach().cpu().numpy()
 
 
-def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, split=False, chain=False, fuse_bn=True, fuse_apply=False):
+def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, split=False, chain=False, fuse_bn=True, fuse_apply=False, fuse_heads=False):
     cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=L, output_size2=L2 or 100)
     tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2, split_backward=split,
-                          chain_small=chain, fuse_bn=fuse_bn, fuse_bn_apply=fuse_apply)
+                          chain_small=chain, fuse_bn=fuse_bn, fuse_bn_apply=fuse_apply, fuse_heads=fuse_heads)
     eng = Engine(cfg, B, tc, with_class=with_class)
     oms = []
     for dt in (torch.float32, torch.float64):
@@ -70,12 +70,16 @@ CASES = {
     # BatchNorm-backward apply evaluated in the input-gradient convs' loaders (HP_CONV_IN_DR), wave + multimodal (two-source phases)
     "wave_fused_apply": dict(kind="unimodal", z=10, L=50, B=16, with_class=False, beta=1.0, clip=None, lr=1e-3, salt=0, fuse_apply=True),
     "multi_fused_apply": dict(kind="multimodal", z=10, L=50, L2=100, B=12, with_class=False, beta=1.0, clip=1.0, lr=1e-3, salt=7, w1=1.0, w2=0.5, fuse_apply=True),
+    # row-local runs of head ops as one launch (HP_FLAG_ROWWISE): class labels (two gathers per concat), multimodal (accumulating dX)
+    "cls_z5_rowwise_heads": dict(kind="unimodal", z=5, L=50, B=12, with_class=True, beta=0.5, clip=1.0, lr=1e-4, salt=3, fuse_heads=True),
+    "multi_rowwise_heads": dict(kind="multimodal", z=10, L=50, L2=100, B=12, with_class=False, beta=1.0, clip=1.0, lr=1e-3, salt=7, w1=1.0, w2=0.5, fuse_heads=True),
 }
 GOLDEN = {"wave": "unimodal_wave_z10_L50_B16.npz", "time_clip": "unimodal_time_z10_L100_B16_clip.npz",
           "cls_z5": "unimodal_wave_z5_L50_B12_cls.npz", "z32_L256": "unimodal_wave_z32_L256_B8.npz",
           "z32_L32": "unimodal_time_z32_L32_B8.npz", "multi": "multimodal_z10_B12.npz", "multi_c5": "multimodal_z64_L256_32_B8.npz",
           "time_clip_chained": "unimodal_time_z10_L100_B16_clip.npz", "cls_z5_unfused_bn": "unimodal_wave_z5_L50_B12_cls.npz",
-          "wave_fused_apply": "unimodal_wave_z10_L50_B16.npz", "multi_fused_apply": "multimodal_z10_B12.npz"}
+          "wave_fused_apply": "unimodal_wave_z10_L50_B16.npz", "multi_fused_apply": "multimodal_z10_B12.npz",
+          "cls_z5_rowwise_heads": "unimodal_wave_z5_L50_B12_cls.npz", "multi_rowwise_heads": "multimodal_z10_B12.npz"}
 
 
 def masked_oracle_step(eng, oms, batch, batch64, eps, c, tag):

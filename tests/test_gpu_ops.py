@@ -861,3 +861,87 @@ def test_parallel_group_of_small_weight_gradients_equals_standalone_launches():
     bad[0]["op"] = P.CONV_TAPS
     with pytest.raises(P.HipEngineError):
         P.DeviceProgram(bad, [dev.data_ptr()] * 6, [image.size] + [4] * 5)
+
+
+def test_rowwise_chain_equals_standalone_ops():
+    """HP_FLAG_ROWWISE: a run of row-local head ops as one launch in which every workgroup takes R rows through all members
+    (planner.apply_rowchains) — against the interpreter and against one launch per record, forward-style and backward-style
+    runs, a row count that is not a multiple of R."""
+    from hippie_amd import planner
+    Bn, z, H = 301, 10, 5
+    ld = 2 * z + 2 * H
+    img = Img(71)
+    # forward-style: BN_APPLY (complete statistics given) -> Linear -> reparameterise -> concat -> Linear+lrelu -> Linear+stats
+    u2 = img.f32(Bn * z)
+    st_in = img.f64(R(z) * 2 * z)
+    r = _chunk_array(img, u2).reshape(Bn, z).astype(np.float64)
+    _chunk_array(img, st_in)[:z] = r.sum(0)
+    _chunk_array(img, st_in)[z: 2 * z] = (r * r).sum(0)
+    gamma, beta, rm = img.f32(z), img.f32(z), img.f32(z, 0.1)
+    rv = img._put(np.abs(img.rng.standard_normal(z)).astype(np.float32) + 0.5)
+    save = img.f32(2 * z, zero=True)
+    encv = img.f32(Bn * z, zero=True)
+    wz, bz = img.f32(2 * z * z, 0.3), img.f32(2 * z)
+    mulv = img.f32(Bn * 2 * z, zero=True)
+    eps, zz = img.f32(Bn * z), img.f32(Bn * z, zero=True)
+    loss = img.f64(4)
+    semb = img.f32(5 * H)
+    src = img.i64(img.rng.integers(0, 5, Bn))
+    c1 = img.f32(Bn * (z + 2 * H), zero=True)
+    w0, b0 = img.f32(2 * z * (z + 2 * H), 0.3), img.f32(2 * z)
+    u3 = img.f32(Bn * 2 * z, zero=True)
+    w2, b2 = img.f32(2 * z * 2 * z, 0.3), img.f32(2 * z)
+    u4 = img.f32(Bn * 2 * z, zero=True)
+    st_out = img.f64(R(2 * z) * 4 * z)
+    # backward-style: BN_BWD_APPLY (complete sums given) -> Linear dX (masked) -> Linear dX -> BN_BWD_REDUCE
+    g, raw = img.f32(Bn * 2 * z), img.f32(Bn * 2 * z)
+    bsv = img.f64(R(2 * z) * 4 * z)
+    _chunk_array(img, bsv)[: 4 * z] = img.rng.standard_normal(4 * z)
+    save_b = img._put(np.concatenate([img.rng.standard_normal(2 * z) * 0.1, np.abs(img.rng.standard_normal(2 * z)) + 0.5]).astype(np.float32))
+    gam_b = img.f32(2 * z)
+    dr, dgam, dbet = img.f32(Bn * 2 * z, zero=True), img.f32(2 * z, zero=True), img.f32(2 * z, zero=True)
+    act = img.f32(Bn * 2 * z)
+    dx1 = img.f32(Bn * 2 * z, zero=True)
+    dx2 = img.f32(Bn * (z + 2 * H), zero=True)
+    raw_r, save_r = img.f32(Bn * (z + 2 * H)), img._put(np.concatenate([img.rng.standard_normal(z + 2 * H) * 0.1, np.abs(img.rng.standard_normal(z + 2 * H)) + 0.5]).astype(np.float32))
+    act_r = img.f32(Bn * (z + 2 * H))
+    gout_r = img.f32(Bn * (z + 2 * H), zero=True)
+    bs_r = img.f64(R(z + 2 * H) * 2 * (z + 2 * H))
+    ol = P.OpList()
+    ol.begin("fwd")
+    ol.add(P.BN_APPLY, 0, [Bn, z, 0, 1, 1], [0.2, 1e-5, 0.1], [u2, encv, st_in, gamma, beta, rm, rv, save])
+    ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, z, z, 2 * z, 0, 0], [0.2], [encv, wz, bz, mulv, None])
+    ol.add(P.REPARAM_KL_FWD, 0, [Bn, z], (), [mulv, eps, zz, loss])
+    ol.add(P.CONCAT, 0, [Bn, 3, z + 2 * H, 0, 0, z, z, 1, H, H, 2, H, 0, 0, 0, 0, 0, 5, 0], (), [c1, zz, None, semb, src, None, None])
+    ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, z + 2 * H, z + 2 * H, 2 * z, 1, 0], [0.2], [c1, w0, b0, u3, None])
+    ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, 2 * z, 2 * z, 2 * z, 0, 1], [0.2], [u3, w2, b2, u4, st_out])
+    ol.end()
+    ol.begin("bwd")
+    ol.add(P.BN_BWD_APPLY, 0, [Bn, 2 * z], (), [g, raw, save_b, bsv, gam_b, dr, dgam, dbet])
+    ol.add(P.LINEAR_BWD_X, 0, [Bn, 2 * z, 2 * z, 2 * z, 2 * z, 1, 2 * z, 0], [0.2], [dr, w2, dx1, act])
+    ol.add(P.LINEAR_BWD_X, 0, [Bn, 2 * z, z + 2 * H, 2 * z, z + 2 * H, 0, 0, 0], [0.2], [dx1, w0, dx2, None])
+    ol.add(P.BN_BWD_REDUCE, 0, [Bn, z + 2 * H, 0, 0], [0.2], [dx2, None, act_r, gout_r, raw_r, save_r, bs_r])
+    ol.end()
+    outs = dict(encv=(encv, Bn * z), save=(save, 2 * z), rm=(rm, z), rv=(rv, z), mulv=(mulv, Bn * 2 * z), zz=(zz, Bn * z), c1=(c1, Bn * (z + 2 * H)),
+                u3=(u3, Bn * 2 * z), u4=(u4, Bn * 2 * z), dr=(dr, Bn * 2 * z), dgam=(dgam, 2 * z), dbet=(dbet, 2 * z), dx1=(dx1, Bn * 2 * z),
+                dx2=(dx2, Bn * (z + 2 * H)), gout=(gout_r, Bn * (z + 2 * H)))
+    gpu_single, cpu = run_both(img, ol.array())
+    planner.apply_rowchains(ol, ("fwd", "bwd"), Bn)
+    recs = ol.array()
+    heads = [k for k, rr in enumerate(recs) if (int(rr["flags"]) >> P.FLAG_CHAIN_SHIFT) & P.FLAG_CHAIN_MASK]
+    assert heads == [5, 9] and all(int(recs[k]["flags"]) & P.FLAG_ROWWISE for k in heads)
+    image = img.image()
+    dev = torch.from_numpy(image.copy()).cuda()
+    prog = P.DeviceProgram(recs, [dev.data_ptr()] * 6, [image.size] + [4] * 5)
+    seg = prog.capture(0, len(recs))
+    prog.replay(seg, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    gpu_chain = dev.cpu().numpy()
+    for name, (ref, n) in outs.items():
+        check(gpu_chain, cpu, ref, n, rel=3e-5, what="row-wise chain vs interpreter: " + name)
+        a, b = view(gpu_single, ref, np.float32, n), view(gpu_chain, ref, np.float32, n)
+        np.testing.assert_array_equal(a, b, err_msg=name)          # same bodies, same per-row arithmetic, no atomic sum upstream
+    check_stats(gpu_chain, cpu, st_out, 2 * z, what="row-wise chain: Linear statistics")
+    check_stats(gpu_chain, cpu, bs_r, z + 2 * H, what="row-wise chain: BatchNorm-backward sums")
+    lo = view(gpu_chain, loss, np.float64, 4)
+    np.testing.assert_allclose(lo, view(cpu, loss, np.float64, 4), rtol=1e-6)          # (device expf vs numpy)

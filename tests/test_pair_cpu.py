@@ -13,8 +13,8 @@ from tests import helpers as H
 
 def test_zipped_program_equals_separate_programs():
     B, z = 4, 10
-    tcs = [planner.TrainCfg(lr=1e-3, intra_pair=False, chain_small=False, group_small_wgrads=False),
-           planner.TrainCfg(lr=1e-3, clip=1.0, intra_pair=False, chain_small=False, group_small_wgrads=False)]      # (as PairEngine lowers them)
+    tcs = [planner.TrainCfg(lr=1e-3, intra_pair=False, chain_small=False, group_small_wgrads=False, fuse_heads=False),
+           planner.TrainCfg(lr=1e-3, clip=1.0, intra_pair=False, chain_small=False, group_small_wgrads=False, fuse_heads=False)]      # (as PairEngine lowers them)
     plans = [planner.lower(planner.ModelCfg("unimodal", z, L), B, tc) for L, tc in zip((50, 100), tcs)]
     ops, segments, notes, bases_b = pair.zip_programs(*plans)
     assert len(notes) == len(ops)
