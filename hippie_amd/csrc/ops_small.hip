@@ -1461,11 +1461,10 @@ __global__ __launch_bounds__(256) void chain_kernel(const SmallEntry* __restrict
           small_block(e, bx, by, bz, lds_d, lds_f);
           __syncthreads();                 // the bodies reuse their LDS
         }
-    // the next member reads what this one wrote (global stores, fp32 / fp64 atomics): make it visible to the whole
-    // workgroup — barrier, then an agent-scope fence (release of our stores, invalidation of this CU's L1 lines)
-    __threadfence();
+    // the next member reads what this one wrote (global stores, fp32 / fp64 atomics) — all inside this ONE workgroup: the
+    // barrier's workgroup-scope release / acquire orders them.  (Round 2 first had agent-scope __threadfence() calls here:
+    // ~5 us each on this multi-XCD part, see rowchain_kernel.)
     __syncthreads();
-    __threadfence();
   }
 }
 

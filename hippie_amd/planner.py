@@ -58,7 +58,8 @@ class TrainCfg:
     fold_eval_bn: bool = True           # eval forward: BatchNorm (+residual, +leaky_relu) folded into the producing conv's epilogue
     chain_small: bool = False           # runs of consecutive small ops (the heads' Linear / BatchNorm / concat / reparameterisation /
                                         # loss ops) execute as ONE launch of one workgroup (HP_FLAG_CHAIN_SHIFT).  Correct (tests) and
-                                        # 174 -> 146 launches per model-step, but MEASURED SLOWER at batch 512 (46.9 k vs 104 k samples/s):
+                                        # 174 -> 146 launches per model-step, but MEASURED SLOWER at batch 512 (time model alone 4.55 vs
+                                        # 2.98 ms per step; 2.2x slower with the agent-scope fences the first version had between members):
                                         # one 256-thread workgroup serialises ~350 virtual blocks of dependent L2 round trips that the
                                         # stand-alone launches spread over 40 CUs each.  Off by default; DESIGN.md section 8.
     fuse_bn_apply: bool = False         # (with fuse_bn) BatchNorm-backward APPLY evaluated in the input-gradient conv's operand loader
