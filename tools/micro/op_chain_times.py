@@ -80,10 +80,13 @@ for seg in ("fwd_train", "bwd", "opt"):
         opc = int(r["op"])
         if only and OPN.get(opc) not in only:
             continue
+        nchain = (int(r["flags"]) >> P.FLAG_CHAIN_SHIFT) & P.FLAG_CHAIN_MASK
         if opc == P.PAIR:
             mem = sorted([int(r["i"][0]), int(r["i"][1])])
         elif opc == P.WGRAD_GROUP:
             mem = list(range(int(r["i"][0]), int(r["i"][0]) + int(r["i"][1])))
+        elif nchain:
+            mem = list(range(gidx - nchain, gidx))          # a chained / grouped launch: the preceding member records + this one
         else:
             mem = []
         if mem:
