@@ -148,6 +148,9 @@ class Pair:
                 e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
                 e.io("src").copy_(data[2].index_select(0, idx), non_blocking=True)
                 e.io("eps").normal_()
+                if self.groups is None and not self.overlap:
+                    e.train_step(use_graph)              # one process: nothing sits between bwd and opt -> one graph per step
+                    continue
                 e.forward(True, use_graph)
                 if self.groups is not None:
                     parallel.backward_allreduce(e, self.groups[k], use_graph, self.overlap)

@@ -311,7 +311,13 @@ class Engine:
         self.run("sf_eval" if to_eval else "sf_train", use_graph)
 
     def train_step(self, use_graph=False):
-        """forward(train) + backward + AdamW on the staged inputs; returns the scalars tensor (device)."""
+        """forward(train) + backward + AdamW on the staged inputs; returns the scalars tensor (device).  With graphs (and
+        no collectives inside the step) the three segments replay as ONE graph."""
+        if use_graph and "step" in self.plan.ops.segments and self.train_cfg.sync_bn_world <= 1:
+            self.run("step", True)
+            for p in self.num_batches_tracked:
+                self.num_batches_tracked[p] += 1
+            return self.io("scalars")
         self.forward(True, use_graph)
         self.backward(use_graph)
         self.optimizer_step(use_graph)

@@ -57,7 +57,7 @@ def zip_programs(plan_a, plan_b):
     out, notes, segments = [], [], {}
     new_a, new_b = {}, {}
     for seg, (fa, ca) in plan_a.ops.segments.items():
-        if seg in ("bwd", "enc_eval"):
+        if seg in ("bwd", "enc_eval", "step"):
             continue                      # aliases (bwd = bwd_a + wg_a + bwd_b + wg_b; enc_eval = prefix of fwd_eval)
         fb, cb = plan_b.ops.segments[seg]
         start = len(out)

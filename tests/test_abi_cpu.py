@@ -87,8 +87,9 @@ def test_planner_programs_validate_without_gpu(kind):
     rc, msg = _create(bad, sizes)
     assert rc != 0 and "required" in msg
     segs = plan.ops.segments
-    assert set(segs) == {"fwd_train", "bwd", "bwd_a", "wg_a", "bwd_b", "wg_b", "opt", "fwd_eval", "enc_eval"}
-    assert sum(c for k, (_, c) in segs.items() if k not in ("bwd", "enc_eval")) == len(ops)
+    assert set(segs) == {"fwd_train", "bwd", "bwd_a", "wg_a", "bwd_b", "wg_b", "opt", "fwd_eval", "enc_eval", "step"}
+    assert sum(c for k, (_, c) in segs.items() if k not in ("bwd", "enc_eval", "step")) == len(ops)
+    assert segs["step"] == (segs["fwd_train"][0], segs["fwd_train"][1] + segs["bwd"][1] + segs["opt"][1])      # alias: the whole step
     assert segs["enc_eval"][0] == segs["fwd_eval"][0] and 0 < segs["enc_eval"][1] < segs["fwd_eval"][1]
     # "bwd" is exactly the four sub-segments in program order
     parts = [segs[k] for k in ("bwd_a", "wg_a", "bwd_b", "wg_b")]
