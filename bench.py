@@ -64,23 +64,17 @@ def synth_dataset(n, device, seed=42, lw=50, lt=100):
 
 
 class Pair:
-    """wave + time models.  Default: two engines, each replaying its three hipGraphs on its own HIP stream
-    (the GPU overlaps the two models' kernels).  --pair: ONE zipped program (hippie_amd.pair.PairEngine:
-    every heavy op of the two models in one launch) on one stream."""
+    """wave + time models: two engines, each replaying its hipGraph(s) on its own HIP stream (the GPU overlaps the two
+    models' kernels).  (A zipped two-model program on one stream was built in round 2 and measured slower — 98.3 k vs
+    113.8 k samples/s: nothing hides the launch floors on a single stream — and removed in round 3)"""
 
-    def __init__(self, device, world, lr=1e-3, paired=False, lens=(50, 100), overlap=False, lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True):
-        self.device, self.world, self.paired, self.overlap, self.lockstep = device, world, paired, overlap, lockstep
+    def __init__(self, device, world, lr=1e-3, lens=(50, 100), overlap=False, lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True):
+        self.device, self.world, self.overlap, self.lockstep = device, world, overlap, lockstep
         self.only = None          # --only-model: step one of the two models (how much of the pair step is overlap?)
         cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
         tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws),
                planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws)]
-        if paired:
-            from hippie_amd.pair import PairEngine
-            self.pe = PairEngine(cfgs[0], cfgs[1], BATCH, tcs[0], tcs[1], device=device)
-            self.eng = self.pe.models
-        else:
-            self.pe = None
-            self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
+        self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
         self.groups = None
         if world > 1 or os.environ.get("HIPPIE_FORCE_DIST"):
@@ -127,18 +121,6 @@ class Pair:
         (the reference trains them one after the other), so unless --lockstep is given their streams are joined
         only at the ends of a run (fork()/join()), not per step: the shorter wave step does not wait for the
         time step."""
-        if self.paired:
-            src = data[2].index_select(0, idx)
-            for k, e in enumerate(self.eng):
-                e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
-                e.io("src").copy_(src, non_blocking=True)
-                e.io("eps").normal_()
-            self.pe.forward(True, use_graph)
-            self.pe.backward(use_graph)
-            if self.groups is not None:
-                parallel.allreduce_mean_(self.pe.grads, self.groups[0])   # both models: one 64 MB buffer
-            self.pe.optimizer_step(use_graph)
-            return
         if self.lockstep:
             self.fork()
         for k, (e, s) in enumerate(zip(self.eng, self.streams)):
@@ -195,21 +177,13 @@ def profile_ops(pair, data, idx, reps=5):
     of one pair-step, in an untimed eager pass over the same programs.  Returns one dict per LAUNCH:
     {model, seg, kind, note, us, flop (conv / wgrad: 2*M*N*K*taps over the launch's member records), bytes, members}."""
     rows = []
-    if pair.paired:
-        progs = [(None, pair.pe.ops, pair.pe.segments, pair.pe.notes, lambda seg: pair.pe.profile(seg))]
-        src = data[2].index_select(0, idx)
-        for k, e in enumerate(pair.eng):
-            e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1))
-            e.io("src").copy_(src)
-            e.io("eps").normal_()
-    else:
-        progs = []
-        for k, e in enumerate(pair.eng):
-            e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1))
-            e.io("src").copy_(data[2].index_select(0, idx))
-            e.io("eps").normal_()
-            progs.append((k, e.ops, e.plan.ops.segments, e.plan.ops.notes,
-                          (lambda seg, e=e: e.prog.profile(*e.plan.ops.segments[seg], torch.cuda.current_stream().cuda_stream))))
+    progs = []
+    for k, e in enumerate(pair.eng):
+        e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1))
+        e.io("src").copy_(data[2].index_select(0, idx))
+        e.io("eps").normal_()
+        progs.append((k, e.ops, e.plan.ops.segments, e.plan.ops.notes,
+                      (lambda seg, e=e: e.prog.profile(*e.plan.ops.segments[seg], torch.cuda.current_stream().cuda_stream))))
     for model, ops, segments, notes, prof in progs:
         for seg in ("fwd_train", "bwd", "opt"):
             first, count = segments[seg]
@@ -334,8 +308,8 @@ def traffic_from_pmc(args):
             d = json.load(f)
         meta = d.get("meta", {})
         same = (meta.get("csrc_digest") == csrc_digest() and
-                [meta.get(k) for k in ("batch", "z_dim", "wave_len", "time_len", "paired")] ==
-                [args.batch, args.z_dim, args.wave_len, args.time_len, bool(args.pair)])
+                [meta.get(k) for k in ("batch", "z_dim", "wave_len", "time_len")] ==
+                [args.batch, args.z_dim, args.wave_len, args.time_len])
         return (d["hbm_bytes_per_launch"], {"file": os.path.relpath(PMC_SUMMARY, ROOT), "git_head": meta.get("git_head")}) if same else (None, None)
     except Exception:
         return None, None
@@ -452,7 +426,6 @@ def main():
     ap.add_argument("--no-trainer", action="store_true", help="skip the secondary reference-API (Trainer.fit) throughput measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-reuse-ws", action="store_true", help="every workspace tensor in memory of its own (A/B against the liveness-packed arena)")
-    ap.add_argument("--pair", action="store_true", help="one zipped wave+time program (paired launches) instead of two engines on two streams")
     ap.add_argument("--overlap", action="store_true", help="decoder-side wgrad + first gradient bucket on a side stream (measured slower on ROCm 7: DESIGN.md 5.3)")
     ap.add_argument("--only-model", type=int, choices=(0, 1), default=None, help="diagnostic: step only the wave (0) or the time (1) model; the line is then NOT the headline metric")
     ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
@@ -506,7 +479,7 @@ def main():
     n_ranks_seen = dist.get_world_size() if (world > 1 or force_dist) else 1      # what the communicator says, not the flag
     dist_backend = dist.get_backend() if (world > 1 or force_dist) else None
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
-    pair = Pair(device, world, paired=args.pair, lens=(args.wave_len, args.time_len), overlap=args.overlap, lockstep=args.lockstep,
+    pair = Pair(device, world, lens=(args.wave_len, args.time_len), overlap=args.overlap, lockstep=args.lockstep,
                 fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws)
     pair.only = args.only_model
     steps_per_epoch = N_UNITS // (BATCH * world)
@@ -566,16 +539,14 @@ def main():
                     extra = "%7.2f MB %7.1f GB/s" % (r["bytes"] / 1e6, r["bytes"] / (r["us"] * 1e-6) / 1e9)
                 print("m%s %-9s %-16s %-70s %8.1f us  %s" % (r["model"], r["seg"], r["kind"], r["note"][:70], r["us"], extra), file=sys.stderr)
         traffic, traffic_src = traffic_from_pmc(args)
-        b2b = None
-        if not pair.paired:
-            try:
-                b2b_us, b2b_n = conv_back_to_back(pair)
-                b2b = {"avg_launch_us": b2b_us / b2b_n, "launches_per_step": b2b_n, "achieved": conv_flop / (b2b_us * 1e-6) / 1e12,
-                       "frac": conv_flop / (b2b_us * 1e-6) / 1e12 / PEAK_TFLOPS[args.dtype],
-                       "how": "every conv launch repeated 20x back to back in a captured graph (HIP events around the replay): without the ~4 us "
-                              "per-launch event floor of the eager pass behind `frac`; informational"}
-            except Exception as ex:          # never lose the line over the secondary figure
-                b2b = {"error": repr(ex)[:200]}
+        try:
+            b2b_us, b2b_n = conv_back_to_back(pair)
+            b2b = {"avg_launch_us": b2b_us / b2b_n, "launches_per_step": b2b_n, "achieved": conv_flop / (b2b_us * 1e-6) / 1e12,
+                   "frac": conv_flop / (b2b_us * 1e-6) / 1e12 / PEAK_TFLOPS[args.dtype],
+                   "how": "every conv launch repeated 20x back to back in a captured graph (HIP events around the replay): without the ~4 us "
+                          "per-launch event floor of the eager pass behind `frac`; informational"}
+        except Exception as ex:          # never lose the line over the secondary figure
+            b2b = {"error": repr(ex)[:200]}
         out = {
             "metric": "pretrain samples/sec (waveform+time cVAE, batch 512) at 1/2/4/8 MI355X",
             "value": BATCH * world * args.steps / dt,
@@ -590,8 +561,10 @@ def main():
                                     "fp32 arithmetic on f32 MFMA (the reference's arithmetic type; the config's bf16 wording is a separate, labelled mode)")
                        if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
                        f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "paired_launches": pair.paired, "wgrad_overlap": pair.overlap and not pair.paired, "lockstep": pair.lockstep,
-                       "final_loss_wave": loss[0], "final_loss_time": loss[1]},
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "wgrad_overlap": pair.overlap, "lockstep": pair.lockstep,
+                       "final_loss_wave": loss[0], "final_loss_time": loss[1],
+                       # every HIPPIE_* variable of this run (measurement knobs act only under HIPPIE_DEBUG_KNOBS=1): {} = the product defaults
+                       "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("HIPPIE_")}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "conv_taps_kernel + conv_taps_pair_kernel (same body: forward conv and input-gradient, f32 MFMA 32x32x2; "
@@ -611,7 +584,7 @@ def main():
                          # whole-step view: samples/s x 3 x forward FLOPs per unit, all kernels and gaps included
                          "whole_step_tflops_per_gpu": BATCH * args.steps / dt * 3.0 * sum(e.plan.flops_fwd for e in pair.eng) / BATCH / 1e12},
         }
-        if world == 1 and not args.no_trainer and not args.pair:
+        if world == 1 and not args.no_trainer:
             tr = trainer_rate(device, data) if args.dtype == "f32" else None
             out["trainer_samples_per_s"] = tr["value"] if tr else None
             out["trainer_path"] = tr

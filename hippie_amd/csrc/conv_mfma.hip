@@ -107,13 +107,6 @@ struct ConvArgs {
   int in_bn, in_Mstat;
   const double* in_stats; float* in_save; float* in_coef;
   float in_slope, in_eps, in_mom;
-  // HP_CONV_IN_DR: the A operand of source s is the BatchNorm-backward input gradient dr_s = bn_dr(G_s, RAW_s; ...),
-  // evaluated in the loader from the masked gradient and the raw BatchNorm input (HP_OP_BN_BWD_APPLY fused); the taps in
-  // wb_mask (column-tile 0 only) store the rows they evaluate to DR_s for the weight-gradient GEMM
-  int in_dr, wb_mask, dr_Mstat[2];
-  float dr_gscale;
-  const float* d_g[2]; const float* d_raw[2]; const float* d_save[2]; const double* d_bs[2]; const float* d_gamma[2];
-  float* d_dgamma[2]; float* d_dbeta[2]; float* d_dr[2];
   // HP_CONV_EPI_BNRED: BatchNorm-backward reduction of the output, fused into the epilogue
   int epi;
   const float* e_g2; const float* e_act; const float* e_raw; const float* e_save; const float* e_coef;
@@ -125,8 +118,7 @@ struct ConvArgs {
 
 constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
 constexpr int kConvCoef = 4 * 512;      // + (scale, shift) of up to 512 input channels, then as many zeros (HP_CONV_IN_BN)
-constexpr int kConvCoefDr = 2 * 3 * 512;   // + the (A, B, C) of bn_dr for up to 512 channels of two sources (HP_CONV_IN_DR)
-constexpr int conv_extra_lds(int mode) { return mode == 1 ? kConvCoef : (mode == 2 ? kConvCoefDr : 0); }
+constexpr int conv_extra_lds(int mode) { return mode == 1 ? kConvCoef : 0; }
 constexpr int kConvThreads = 512;
 
 // Shared epilogue of the conv bodies: sums the two K-halves of every quadrant through LDS, then bias / BatchNorm
@@ -319,10 +311,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
 // (Measured and removed, round 2: a 64-wide K-step — half the barriers and LDS round trips per MFMA, 126-128 VGPRs, 70 KB
 // of LDS — is no faster at K = 512 (38.1 us either way) and slower at K = 64 (17-18.6 vs 13.4 us: twice the prologue):
 // the per-slice barrier is not what limits the loop.)
-// MODE: 0 = the A operand is a stored tensor; 1 = HP_CONV_IN_BN; 2 = HP_CONV_IN_DR
+// MODE: 0 = the A operand is a stored tensor; 1 = HP_CONV_IN_BN
 template <bool W_KN, int MODE, bool BF16 = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
-  constexpr bool IN_BN = MODE == 1, IN_DR = MODE == 2;
+  constexpr bool IN_BN = MODE == 1;
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
   constexpr int LDBK = 68;   // [k][n] image row stride
   constexpr int TILE = 64 * LDA;   // 2304 floats; the [32][68] image (2176) fits too
@@ -354,31 +346,20 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   // branch-free loads let the compiler wait with counted vmcnt(N).
   // (IN_BN: kq = channel offset of the slice in the coefficient table, va = 0 for a padded row: the padding is
   // zeros of the ACTIVATION, not of the raw tensor it is computed from)
-  // (IN_DR: a2 = the raw BatchNorm input next to a = the masked gradient; kq also selects the source's coefficient
-  // table; wb != 0: the evaluated dr row segment is stored back at a + wb floats)
-  struct Pref { float4 a, b; int kq; float va; };
-  struct PrefDr { float4 a2; float* wb; };
+  struct Pref { float4 a, b; int kq; };
   // Per-tap load state: pointers advanced by a constant per K-slice, recomputed only at tap boundaries.
   const float* pa; const float* pb;
   int ia, ib;
   int n_tap = 0, kc = 0;
-  long draw = 0, dwb = 0;        // IN_DR: RAW_s - G_s and (write-back taps) DR_s - G_s, in floats; 0 for padded rows
-  int dtab = 0;                  // IN_DR: offset of the tap's source in the coefficient table
-  const bool wb_tile = IN_DR && n0 == 0;
   auto set_tap = [&](int tap) {
     const int to = t.tap_o[tap];
     const bool second = t.tap_src[tap] != 0;
     const float* wp = (second ? p.W2 : p.W) + (size_t)t.tap_w[tap] * wslab;
-    const float* ap = IN_DR ? p.d_g[second] : (second ? p.A2 : p.A);
+    const float* ap = second ? p.A2 : p.A;
     const int pos = rl + to;
     const bool oa = rvalid && pos >= 0 && pos < t.P;
     pa = oa ? ap + (size_t)(rbase + (pos >> t.sh)) * t.K + aq : hp_zero16;
     ia = oa ? 32 : 0;
-    if (IN_DR) {
-      draw = oa ? (long)(p.d_raw[second] - p.d_g[second]) : 0;
-      dwb = (oa && wb_tile && ((p.wb_mask >> tap) & 1)) ? (long)(p.d_dr[second] - p.d_g[second]) : 0;
-      dtab = second ? 3 * t.K : 0;
-    }
     bool ob;
     if (!W_KN) {
       ob = n0 + ar < t.N && !((HP_ABL & 2) && t.M >= 0);
@@ -398,16 +379,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       if (++n_tap < t.ntaps) set_tap(n_tap);
     }
   };
-  auto fetch = [&](PrefDr& d) -> Pref {
+  auto fetch = [&]() -> Pref {
     Pref r;
     r.a = gload4(pa);
     r.b = gload4(pb);
+    r.kq = 0;
     if (IN_BN) r.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;      // a padded row reads (scale, shift) = (0, 0): its activation is exactly 0
-    if (IN_DR) {
-      d.a2 = gload4(pa + draw);
-      d.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;      // where the evaluated dr segment is stored back (nullptr = not)
-      r.kq = dtab + kc * 32 + aq; r.va = ia ? 1.f : 0.f;
-    }
     advance();
     return r;
   };
@@ -421,20 +398,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       pre_sh = *reinterpret_cast<const float4*>(s_coef + t.K + r.kq);
     }
   };
-  auto stash = [&](int buf, Pref r, const PrefDr& d) {
+  auto stash = [&](int buf, Pref r) {
     float* As = smem + buf * TILE;
     float* Bs = smem + 2 * TILE + buf * TILE;
-    if (IN_DR) {
-      // dr = sc * (g - c1 - xhat * c2): HP_OP_BN_BWD_APPLY's arithmetic (bn_dr) on the way from registers to LDS
-      const float* tb = s_coef + r.kq;
-      const float4 cA = *reinterpret_cast<const float4*>(tb), cB = *reinterpret_cast<const float4*>(tb + t.K);
-      const float4 cC = *reinterpret_cast<const float4*>(tb + 2 * t.K);
-      r.a.x = bn_dr(r.a.x, d.a2.x, cA.x, cB.x, cC.x) * r.va;
-      r.a.y = bn_dr(r.a.y, d.a2.y, cA.y, cB.y, cC.y) * r.va;
-      r.a.z = bn_dr(r.a.z, d.a2.z, cA.z, cB.z, cC.z) * r.va;
-      r.a.w = bn_dr(r.a.w, d.a2.w, cA.w, cB.w, cC.w) * r.va;
-      if (d.wb != nullptr) gstore4(d.wb, r.a);
-    }
     if (IN_BN) {
       if (in_bn) {
         // a = leaky_relu(fma(x, scale, shift)): the same two operations, on the same operands, as HP_OP_BN_APPLY
@@ -489,15 +455,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       LD.a = gload4(pa);                                                                                \
       LD.b = gload4(pb);                                                                                \
       if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
-      if (IN_DR) {                                                                                      \
-        D##LD.a2 = gload4(pa + draw);                                                                   \
-        D##LD.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;                                        \
-        LD.kq = dtab + kc * 32 + aq; LD.va = ia ? 1.f : 0.f;                                            \
-      }                                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                \
       advance();                                                                                        \
     }                                                                                                   \
-    if (STASH) { load_coef(ST); stash((BUF) ^ 1, ST, D##ST); }                                          \
+    if (STASH) { load_coef(ST); stash((BUF) ^ 1, ST); }                                                 \
     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc2[0], 0, 0, 0);                        \
     __syncthreads();                                                                                    \
   }
@@ -520,16 +481,11 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       LD.a = gload4(pa);                                                                                \
       LD.b = gload4(pb);                                                                                \
       if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
-      if (IN_DR) {                                                                                      \
-        D##LD.a2 = gload4(pa + draw);                                                                   \
-        D##LD.wb = dwb ? const_cast<float*>(pa) + dwb : nullptr;                                        \
-        LD.kq = dtab + kc * 32 + aq; LD.va = ia ? 1.f : 0.f;                                            \
-      }                                                                                                 \
       __builtin_amdgcn_sched_barrier(0);                                                                \
     }                                                                                                   \
     _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                                     \
       if (g == 1 && (FETCH)) { advance(); __builtin_amdgcn_sched_barrier(0); }                          \
-      if (g == 1 && (STASH)) { stash((BUF) ^ 1, ST, D##ST); __builtin_amdgcn_sched_barrier(0); }        \
+      if (g == 1 && (STASH)) { stash((BUF) ^ 1, ST); __builtin_amdgcn_sched_barrier(0); }               \
       acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].x, b4[g].x, acc2[g], 0, 0, 0);               \
       acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].y, b4[g].y, acc2[g], 0, 0, 0);               \
       acc2[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].z, b4[g].z, acc2[g], 0, 0, 0);               \
@@ -538,26 +494,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     __syncthreads();                                                                                    \
   }
 
-  PrefDr DsetA, DsetB;
-  Pref setA = fetch(DsetA);                  // slice 0 (in flight while the coefficients are derived)
-  if (IN_DR) {
-    // every workgroup derives, per source, bn_dr's (A, B, C) of the K channels from the reduction sums exactly as
-    // bn_bwd_apply_body does; workgroup 0 writes the BatchNorm's parameter gradients (dgamma = sum g*xhat, dbeta = sum g)
-    float* tb = smem + kConvLds;
-    const bool two = p.d_g[1] != nullptr;
-    for (int c = tid; c < t.K; c += kConvThreads) {
-      for (int s_ = 0; s_ < (two ? 2 : 1); ++s_) {
-        const float mean = p.d_save[s_][c], invstd = p.d_save[s_][t.K + c], gam = p.d_gamma[s_][c];
-        double sg, sgx;
-        stat_sum2(p.d_bs[s_], t.K, c, sg, sgx);
-        float* q = tb + s_ * 3 * t.K + c;
-        const BnDrCoef k = bn_dr_coef(mean, invstd, gam, sg, sgx, p.dr_Mstat[s_]);
-        q[0] = k.A; q[t.K] = k.B; q[2 * t.K] = k.C;
-        if (bid == 0) { p.d_dgamma[s_][c] = (float)(sgx * (double)p.dr_gscale); p.d_dbeta[s_][c] = (float)(sg * (double)p.dr_gscale); }
-      }
-    }
-    __syncthreads();
-  }
+  Pref setA = fetch();                       // slice 0 (in flight while the coefficients are derived)
   if (IN_BN) {
     if (in_bn) {
       // every workgroup derives (scale, shift) of the K input channels from the producer's statistics — the same
@@ -576,10 +513,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     }
   }
   load_coef(setA);
-  stash(0, setA, DsetA);
-  if (nsteps > 1) setA = fetch(DsetA);       // slice 1 waits in set A
+  stash(0, setA);
+  if (nsteps > 1) setA = fetch();            // slice 1 waits in set A
   Pref setB = setA;
-  DsetB = DsetA;
   __syncthreads();
   HP_TS(1)
   int s = 0;
@@ -666,18 +602,6 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   a.in_save = hp::ptr<float>(op, 13, bases);
   a.in_coef = hp::ptr<float>(op, 14, bases);
   a.in_slope = op.f[2]; a.in_eps = op.f[3]; a.in_mom = op.f[4];
-  a.in_dr = (op.flags & HP_CONV_IN_DR) ? 1 : 0;
-  a.wb_mask = op.i[36];
-  const int world = op.i[35] > 1 ? op.i[35] : 1;
-  a.dr_gscale = 1.f / (float)world;
-  for (int s_ = 0; s_ < 2; ++s_) {
-    const int b0 = 24 + 8 * s_;
-    a.dr_Mstat[s_] = op.i[33 + s_] * world;
-    a.d_g[s_] = hp::ptr<const float>(op, b0 + 0, bases); a.d_raw[s_] = hp::ptr<const float>(op, b0 + 1, bases);
-    a.d_save[s_] = hp::ptr<const float>(op, b0 + 2, bases); a.d_bs[s_] = hp::ptr<const double>(op, b0 + 3, bases);
-    a.d_gamma[s_] = hp::ptr<const float>(op, b0 + 4, bases); a.d_dgamma[s_] = hp::ptr<float>(op, b0 + 5, bases);
-    a.d_dbeta[s_] = hp::ptr<float>(op, b0 + 6, bases); a.d_dr[s_] = hp::ptr<float>(op, b0 + 7, bases);
-  }
   a.epi = (op.flags & HP_CONV_EPI_BNRED) ? 1 : 0;
   a.e_g2 = hp::ptr<const float>(op, 15, bases); a.e_act = hp::ptr<const float>(op, 16, bases);
   a.e_raw = hp::ptr<const float>(op, 17, bases); a.e_save = hp::ptr<const float>(op, 18, bases);
@@ -688,16 +612,13 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   return a;
 }
 
-// operand-loader mode of a launch: 2 = HP_CONV_IN_DR, 1 = HP_CONV_IN_BN (checked per op at run time inside the
-// instantiation, so a pair may mix it with plain members), 0 = plain
-static int conv_mode(int flags) { return (flags & HP_CONV_IN_DR) ? 2 : ((flags & HP_CONV_IN_BN) ? 1 : 0); }
+// operand-loader mode of a launch: 1 = HP_CONV_IN_BN (checked per op at run time inside the instantiation, so a pair
+// may mix it with plain members), 0 = plain
+static int conv_mode(int flags) { return (flags & HP_CONV_IN_BN) ? 1 : 0; }
 
 #define HP_CONV_DISPATCH(KERNEL, KN, MODE, BF, ...)                                                     \
   do {                                                                                                  \
-    if (BF) {                                                                                           \
-      if (MODE == 2) { if (KN) hipLaunchKernelGGL((KERNEL<true, 2, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 2, true>), __VA_ARGS__); } \
-      else           { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, true>), __VA_ARGS__); } \
-    } else if (MODE == 2) { if (KN) hipLaunchKernelGGL((KERNEL<true, 2, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 2, false>), __VA_ARGS__); } \
+    if (BF)               { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, true>), __VA_ARGS__); } \
     else if (MODE == 1)   { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, false>), __VA_ARGS__); } \
     else                  { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, false>), __VA_ARGS__); } \
   } while (0)
@@ -705,7 +626,6 @@ static int conv_mode(int flags) { return (flags & HP_CONV_IN_DR) ? 2 : ((flags &
 hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* bases, hipStream_t s) {
   if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & HP_CONV_BF16) != (opb.flags & HP_CONV_BF16)) return hipErrorInvalidValue;
   const int ma = conv_mode(opa.flags), mb = conv_mode(opb.flags);
-  if ((ma == 2) != (mb == 2)) return hipErrorInvalidValue;          // IN_DR members pair only with IN_DR members
   const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
   const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
   const bool kn = opa.flags & 1, bf = opa.flags & HP_CONV_BF16;
@@ -948,13 +868,17 @@ hipError_t hp::build_wgrad_group(const HpOp* members, int count, void* const* ba
   std::stable_sort(blocks.begin(), blocks.end(), [&](const int4& a, const int4& b) {
     return probs[a.x].rows_per_split > probs[b.x].rows_per_split;
   });
+  *d_probs = *d_blocks = nullptr;
   hipError_t e = hipMalloc(d_probs, probs.size() * sizeof(WgradArgs));
-  if (e != hipSuccess) return e;
-  e = hipMalloc(d_blocks, blocks.size() * sizeof(int4));
-  if (e != hipSuccess) return e;
-  e = hipMemcpy(*d_probs, probs.data(), probs.size() * sizeof(WgradArgs), hipMemcpyHostToDevice);
-  if (e != hipSuccess) return e;
-  e = hipMemcpy(*d_blocks, blocks.data(), blocks.size() * sizeof(int4), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(d_blocks, blocks.size() * sizeof(int4));
+  if (e == hipSuccess) e = hipMemcpy(*d_probs, probs.data(), probs.size() * sizeof(WgradArgs), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(*d_blocks, blocks.data(), blocks.size() * sizeof(int4), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {      // nothing half-built survives a failure
+    if (*d_probs) hipFree(*d_probs);
+    if (*d_blocks) hipFree(*d_blocks);
+    *d_probs = *d_blocks = nullptr;
+    return e;
+  }
   *nblocks = (int)blocks.size();
   return e;
 }

@@ -26,15 +26,10 @@ hipError_t launch_conv_pair(const HpOp& a, const HpOp& b, void* const* bases, hi
 hipError_t launch_small_pair(const HpOp& a, const HpOp& b, void* const* bases, hipStream_t s);   // BN family
 hipError_t build_wgrad_group(const HpOp* members, int count, void* const* bases, void** d_probs, void** d_blocks, int* nblocks);
 hipError_t launch_wgrad_group(int ntaps, bool bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s);
-// chained launch of small ops (ops_small.hip): one workgroup runs the member records in program order
-bool chainable(const HpOp& op);
-hipError_t build_chain(const HpOp* members, int count, void* const* bases, void** d_entries);
-hipError_t launch_chain(const void* d_entries, int count, hipStream_t s);
-int rowchain_rows(const HpOp* members, int count);        // HP_FLAG_ROWWISE: rows per workgroup, 0 = not a valid row-wise chain
-hipError_t build_rowchain(const HpOp* members, int count, void* const* bases, void** d_entries, int* ngroups);
-hipError_t launch_rowchain(const void* d_entries, int count, int ngroups, hipStream_t s);
-bool groupable(const HpOp& op);          // may be a member of an HP_FLAG_PARALLEL chain
-hipError_t launch_small_group(const HpOp* members, const void* d_entries, int count, hipStream_t s);      // HP_FLAG_PARALLEL
+// small-leaf group (ops_small.hip): independent LINEAR_BWD_W / EMB_BWD records in one launch
+bool groupable(const HpOp& op);
+hipError_t build_small_group(const HpOp* members, int count, void* const* bases, void** d_entries);
+hipError_t launch_small_group(const HpOp* members, const void* d_entries, int count, hipStream_t s);
 
 }  // namespace hp
 

@@ -133,8 +133,6 @@ struct BnApplyArgs {
   float* rmean2; float* rvar2; float* save2;
   int M, C, res_mode, training, act;
   int Mstat;          // rows behind the statistics: M, or M * world under sync-BatchNorm (HP_OP_STATS_SYNC)
-  int grp;            // row-sliced launch (HP_FLAG_ROWWISE): index of the workgroup's row slice; 0 otherwise.  "Workgroup 0"
-                      // (side effects, replica choice) is bx + grp == 0
   float slope, eps, momentum;
 };
 
@@ -178,7 +176,7 @@ __device__ __forceinline__ void bn_apply_impl(const BnApplyArgs& p, const int bx
       k2 = bn_coef(p.training, p.Mstat, p.stats2, p.C, c, p.gamma2, p.beta2, p.rmean2, p.rvar2, p.eps);
       s_coef[2][ci] = k2.scale; s_coef[3][ci] = k2.shift;
     }
-    if (p.training && bx + p.grp == 0) {
+    if (p.training && bx == 0) {
       bn_side_effects(k, p.Mstat, p.C, c, p.save, p.rmean, p.rvar, p.momentum);
       if (RES == 2) bn_side_effects(k2, p.Mstat, p.C, c, p.save2, p.rmean2, p.rvar2, p.momentum);
     }
@@ -254,7 +252,6 @@ struct BnBwdReduceArgs {
   const float* raw2; const float* save2; double* bs2;
   const float* coef;     // act == nullptr: the activation was never stored; its sign is that of fma(raw, scale, shift)
   int M, C, has_second;
-  int grp;               // row-sliced launch: see BnApplyArgs
   int rpl;               // rows per thread (bn_red_rpl): sets the grid and the number of atomic adds per statistics replica
   float slope;
 };
@@ -363,11 +360,11 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
     const int q = o / V, j = o - q * V, c = c_base + o;
     if (c >= p.C) continue;
     const double s0 = lds[(3 * j + 0) * 256 + q], s1 = lds[(3 * j + 1) * 256 + q];
-    double* b1 = stat_replica(p.bs, p.C, bx + p.grp);
+    double* b1 = stat_replica(p.bs, p.C, bx);
     atomic_add_f64(b1 + c, s0);
     atomic_add_f64(b1 + p.C + c, s1);
     if (p.has_second) {
-      double* b2 = stat_replica(p.bs2, p.C, bx + p.grp);
+      double* b2 = stat_replica(p.bs2, p.C, bx);
       atomic_add_f64(b2 + c, s0);
       atomic_add_f64(b2 + p.C + c, lds[(3 * j + 2) * 256 + q]);
     }
@@ -381,7 +378,6 @@ struct BnBwdApplyArgs {
   float* dr; float* dgamma; float* dbeta;
   int M, C;
   int Mstat;          // M * world under sync-BatchNorm: BS then holds the sums over all ranks
-  int grp;            // row-sliced launch: see BnApplyArgs
   float gscale;       // 1 / world: dgamma / dbeta are written so that the data-parallel MEAN of the ranks gives the sum
 };
 
@@ -410,7 +406,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
     stat_sum2(p.bs, p.C, c, sg, sgx);
     const BnDrCoef k = bn_dr_coef(mean, invstd, gam, sg, sgx, p.Mstat);
     s_coef[0][ci] = k.A; s_coef[1][ci] = k.B; s_coef[2][ci] = k.C;
-    if (bx + p.grp == 0) { p.dgamma[c] = (float)(sgx * (double)p.gscale); p.dbeta[c] = (float)(sg * (double)p.gscale); }
+    if (bx == 0) { p.dgamma[c] = (float)(sgx * (double)p.gscale); p.dbeta[c] = (float)(sg * (double)p.gscale); }
   }
   __syncthreads();
   if (!m.active) return;
@@ -476,8 +472,15 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs p) {
 // graph: 8 rows -> 60.8 us, 16 -> 33.2, 32 -> 21.0, 64 -> 18.4, 128 -> 23.9: every workgroup ends in one fp32 atomic per
 // output and same-address atomics retire at ~70 ns each, so FEWER, taller workgroups win until the serial row batches
 // take over.
+// measurement knobs are honoured only under HIPPIE_DEBUG_KNOBS=1 (hippie_amd/program.py: debug_knob)
+inline int debug_knob_int(const char* name) {
+  const char* on = getenv("HIPPIE_DEBUG_KNOBS");
+  if (on == nullptr || on[0] != '1') return 0;
+  const char* e = getenv(name);
+  return e ? atoi(e) : 0;
+}
 inline int small_wgrad_rows(int dflt) {
-  static const int forced = [] { const char* e = getenv("HIPPIE_WG_ROWS"); return e ? atoi(e) : 0; }();
+  static const int forced = debug_knob_int("HIPPIE_WG_ROWS");
   return forced > 0 ? forced : dflt;
 }
 constexpr int kStemRows = 64;
@@ -631,14 +634,15 @@ __device__ __forceinline__ void concat_body(const ConcatArgs& p, int bx) {
   p.out[id] = v;
 }
 __global__ __launch_bounds__(256) void concat_kernel(ConcatArgs p) { concat_body(p, blockIdx.x); }
-struct EmbArgs { const float* d; const int64_t* idx; float* dt; int B, w, ld, col0, rows; };
+struct EmbArgs { const float* d; const int64_t* idx; float* dt; int B, w, ld, col0, rows; int det; };
 // A small table (rows * w <= 1024 floats: the 5 x 5 source / class tables): one WAVE per table element scans the batch
 // and adds its fixed-order sum to the element it owns with ONE atomic (at most two ops contribute to a table per backward
 // pass: 0 + a + b does not depend on the order) — bit-reproducible, and 2 560 global atomics on one cache line (4.9 us)
-// became 25 (2.2 us).  Larger tables: one fp32 atomic per (sample, column).
+// became 25 (2.2 us).  Larger tables: one fp32 atomic per (sample, column) — unless flags & 1 (deterministic_wgrad): then
+// the wave-per-element form at any size (ordered sums; slower for big tables, which the reference's scripts never build).
 __device__ __forceinline__ void emb_bwd_body(const EmbArgs& p, int bx) {
   const int n = p.rows * p.w;
-  if (n <= 1024) {
+  if (n <= 1024 || p.det) {
     const int e = bx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (e >= n) return;
     const int row = e / p.w, k = e - row * p.w;
@@ -671,7 +675,6 @@ struct LinArgs {
   const float* X; const float* W; const float* Bv; float* Y; double* stats;
   const float* DY; float* DX; const float* ACT; float* DW; float* DB;
   int M, N, K, ldx, ldy, act, has_mask, lda, accumulate;
-  int grp;            // row-sliced launch: see BnApplyArgs
   float slope;
 };
 // one thread per output (small K).  Statistics (the following BatchNorm's sum / sum of squares per column): the workgroup's
@@ -699,7 +702,7 @@ __device__ __forceinline__ void linear_fwd_thread_body(const LinArgs& p, int bx)
   // (measured per launch in a graph, batch 512: linear_out N=100 K=64 9.3 -> 5.7 us, encoder_fc.0 N=20 K=30 4.8 -> 4.4;
   //  N=512 K=20 got SLOWER, 7.4 -> 9.9 us — 20 staging iterations per thread for 20 k-steps — hence N <= 256, K >= 24)
   if (p.N <= 256 && p.K >= 24 && WN * KP <= kLinLdsW && nrows * KP <= kLinLdsX) {      // (uniform)
-    __syncthreads();                 // (chained launches call this body repeatedly)
+    __syncthreads();                 // (the body may be called repeatedly by one workgroup)
     for (int i = threadIdx.x; i < WN * p.K; i += 256) {
       const int r = i / p.K, k = i - r * p.K;
       int nn = n_first + r;
@@ -733,7 +736,7 @@ __device__ __forceinline__ void linear_fwd_thread_body(const LinArgs& p, int bx)
         atomic_add_f64(st + p.N + n, (double)s * (double)s);
       }
     } else {
-      __syncthreads();               // (chained launches call this body repeatedly: the previous call's readers are done)
+      __syncthreads();               // (the body may be called repeatedly by one workgroup: the previous call's readers are done)
       s_st[0][threadIdx.x] = valid ? (double)s : 0.0;
       s_st[1][threadIdx.x] = valid ? (double)s * (double)s : 0.0;
       __syncthreads();
@@ -742,7 +745,7 @@ __device__ __forceinline__ void linear_fwd_thread_body(const LinArgs& p, int bx)
         const int first = (int)(((int64_t)threadIdx.x - ((int64_t)bx * 256) % p.N + p.N) % p.N);
         double a = 0.0, b = 0.0;
         for (int i = first; i < 256; i += p.N) { a += s_st[0][i]; b += s_st[1][i]; }
-        double* st = stat_replica(p.stats, p.N, bx + p.grp);
+        double* st = stat_replica(p.stats, p.N, bx);
         atomic_add_f64(st + threadIdx.x, a);
         atomic_add_f64(st + p.N + threadIdx.x, b);
       }
@@ -804,7 +807,7 @@ __global__ __launch_bounds__(256) void linear_bwd_x_wave_kernel(LinArgs p) {
 // block = (output row n, chunk of <=256 input columns, slice of M); fp32 atomics into zeroed DW/DB
 __device__ __forceinline__ void linear_bwd_w_body(const LinArgs& p, int rows_per_z, int bx, int by, int bz) {
   __shared__ double lds[2 * 256];
-  __syncthreads();                      // (chained launches call this body repeatedly: the previous call's readers are done)
+  __syncthreads();                      // (the body may be called repeatedly by one workgroup: the previous call's readers are done)
   const int n = bx;
   const int kw = p.K < 256 ? p.K : 256;
   const int ml = 256 / kw;
@@ -859,8 +862,7 @@ __device__ __forceinline__ void block_atomic_f64(double v, double* dst) {
     atomic_add_f64(dst, s);
   }
 }
-struct ReparamArgs { const float* mulv; const float* eps; float* z; double* loss; const float* dz; float* dmulv; int B, zd, lddz; float beta;
-                     int Bfull; };      // row-sliced launch: the batch size behind the KL mean (0 = B)
+struct ReparamArgs { const float* mulv; const float* eps; float* z; double* loss; const float* dz; float* dmulv; int B, zd, lddz; float beta; };
 __device__ __forceinline__ void reparam_kl_fwd_body(const ReparamArgs& p, int bx) {
   const float* mulv = p.mulv; const float* eps = p.eps; float* z = p.z; double* loss = p.loss;
   const int B = p.B, zd = p.zd;
@@ -884,7 +886,7 @@ __device__ __forceinline__ void reparam_kl_bwd_body(const ReparamArgs& p, int bx
   const int b = id / zd, j = id - b * zd;
   const float mu = mulv[(size_t)b * 2 * zd + j], lv = mulv[(size_t)b * 2 * zd + zd + j];
   const float g = dz[(size_t)b * lddz + j];
-  const float invB = 1.f / (float)(p.Bfull > 0 ? p.Bfull : B);
+  const float invB = 1.f / (float)B;
   dmulv[(size_t)b * 2 * zd + j] = g + beta * mu * invB;
   dmulv[(size_t)b * 2 * zd + zd + j] = g * eps[id] * 0.5f * expf(0.5f * lv) + beta * 0.5f * (expf(lv) - 1.f) * invB;
 }
@@ -1232,7 +1234,7 @@ inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / p
 // 20 x 20 / 20 x 30 heads (32 atomics per address, 640 workgroups of two rows per thread) against 3.2-3.5 us now.
 inline int linear_bwd_w_slices(int M, int N, int K, bool one_slice = false) {
   if (one_slice) return 1;           // flags & 1: no cross-workgroup atomics, bit-reproducible
-  static const int forced = [] { const char* e = getenv("HIPPIE_LBW_ROWS"); return e ? atoi(e) : 0; }();   // (the sweep)
+  static const int forced = debug_knob_int("HIPPIE_LBW_ROWS");   // (the sweep)
   const int kw = K < 256 ? K : 256, ml = 256 / kw;
   const int rows = forced > 0 ? forced : min(128, max(32, 16 * ml));
   return max(1, hp::cdiv(M, rows));
@@ -1249,7 +1251,6 @@ BnApplyArgs bn_apply_args(const HpOp& op, void* const* bases) {
   a.rmean2 = ptr<float>(op, 12, bases); a.rvar2 = ptr<float>(op, 13, bases); a.save2 = ptr<float>(op, 14, bases);
   a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
   a.Mstat = I[0] * (I[5] > 1 ? I[5] : 1);
-  a.grp = 0;
   a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
   return a;
 }
@@ -1263,7 +1264,6 @@ BnBwdReduceArgs bn_bwd_reduce_args(const HpOp& op, void* const* bases) {
   a.raw2 = ptr<const float>(op, 7, bases); a.save2 = ptr<const float>(op, 8, bases); a.bs2 = ptr<double>(op, 9, bases);
   a.coef = ptr<const float>(op, 10, bases);
   a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
-  a.grp = 0;
   a.rpl = bn_red_rpl(a.M, a.C);
   return a;
 }
@@ -1276,89 +1276,30 @@ BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
   a.M = op.i[0]; a.C = op.i[1];
   const int w = op.i[2] > 1 ? op.i[2] : 1;
   a.Mstat = a.M * w; a.gscale = 1.f / (float)w;
-  a.grp = 0;
   return a;
 }
 
 
-// ---- chained launches ---------------------------------------------------------------------------------------------
-// The heads of the cVAE (hippie/model.py:21-41,51-62) are ~35 dependent launches per model-step of a few thousand
-// FMAs each: pure launch latency.  A CHAIN runs a run of such ops, in program order, inside ONE launch of ONE
-// 256-thread workgroup: each member's own kernel body is executed over its virtual grid, with a workgroup barrier
-// and an agent-scope fence between blocks and members (the members communicate through global memory and fp64
-// atomics, which live in L2: the fence drops the CU's L1 lines).  Same bodies => same arithmetic as the stand-alone
-// launches; only the order of the fp64 / fp32 atomic sums differs.
+// ---- argument records of the small ops that are launched from a table (the small-leaf group) or share their argument
+// decoding with it --------------------------------------------------------------------------------------------------
 struct SmallEntry {
   int op, variant;          // HP_OP_* ; variant: BatchNorm family vector width (4 / 1)
   int gx, gy, gz;           // virtual grid of 256-thread blocks
   int rows_per_z;           // LINEAR_BWD_W
-  union {
-    BnApplyArgs bn_apply; BnBwdReduceArgs bn_red; BnBwdApplyArgs bn_bapply; ConcatArgs concat; LinArgs lin; EmbArgs emb;
-    ReparamArgs rp; MseArgs mse; LossArgs loss;
-    struct { int64_t* step; } stepinc;
-    struct { uint4* p16; size_t n16; uint8_t* tail; int ntail; } zero;
-  } a;
+  union { LinArgs lin; EmbArgs emb; ReparamArgs rp; MseArgs mse; LossArgs loss; } a;
 };
 
-// args + grid of one chainable op; false if the op (or this shape of it) has no chainable body
+// args + grid of one such op; false for any other opcode
 bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
   using hp::ptr;
   const int32_t* I = op.i;
   e.op = op.op; e.variant = 0; e.gx = e.gy = e.gz = 1; e.rows_per_z = 0;
   switch (op.op) {
-    case HP_OP_BN_APPLY: {
-      e.a.bn_apply = bn_apply_args(op, bases);
-      e.variant = e.a.bn_apply.C % 4 == 0 ? 4 : 1;
-      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_apply.M, e.a.bn_apply.C, bn_rows<4>(e.a.bn_apply.M, e.a.bn_apply.C)) : colgrid_v<1>(e.a.bn_apply.M, e.a.bn_apply.C, bn_rows<1>(e.a.bn_apply.M, e.a.bn_apply.C));
-      e.gx = g.x; e.gy = g.y;
-      return true;
-    }
-    case HP_OP_BN_BWD_REDUCE: {
-      e.a.bn_red = bn_bwd_reduce_args(op, bases);
-      e.variant = e.a.bn_red.C % 4 == 0 ? 4 : 1;
-      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_red.M, e.a.bn_red.C, e.a.bn_red.rpl) : colgrid_v<1>(e.a.bn_red.M, e.a.bn_red.C, e.a.bn_red.rpl);
-      e.gx = g.x; e.gy = g.y;
-      return true;
-    }
-    case HP_OP_BN_BWD_APPLY: {
-      e.a.bn_bapply = bn_bwd_apply_args(op, bases);
-      e.variant = e.a.bn_bapply.C % 4 == 0 ? 4 : 1;
-      const dim3 g = e.variant == 4 ? colgrid_v<4>(e.a.bn_bapply.M, e.a.bn_bapply.C, bn_rows<4>(e.a.bn_bapply.M, e.a.bn_bapply.C)) : colgrid_v<1>(e.a.bn_bapply.M, e.a.bn_bapply.C, bn_rows<1>(e.a.bn_bapply.M, e.a.bn_bapply.C));
-      e.gx = g.x; e.gy = g.y;
-      return true;
-    }
-    case HP_OP_CONCAT: {
-      ConcatArgs a{};
-      a.out = ptr<float>(op, 0, bases); a.B = I[0]; a.nseg = I[1]; a.ldo = I[2];
-      for (int j = 0; j < 4; ++j) {
-        a.kind[j] = I[4 + 3 * j]; a.w[j] = I[5 + 3 * j]; a.ld[j] = I[6 + 3 * j]; a.rows[j] = I[16 + j];
-        a.src[j] = ptr<const float>(op, 1 + 2 * j, bases); a.idx[j] = ptr<const int64_t>(op, 2 + 2 * j, bases);
-      }
-      e.a.concat = a; e.gx = blocks_for((int64_t)a.B * a.ldo);
-      return true;
-    }
     case HP_OP_EMB_BWD: {
-      EmbArgs a{ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2], I[3], I[4]};
+      EmbArgs a{ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2], I[3], I[4], op.flags & 1};
       e.a.emb = a;
-      e.gx = a.rows * a.w <= 1024 ? hp::cdiv(a.rows * a.w, 4) : blocks_for((int64_t)I[0] * I[1]);      // (emb_bwd_body: a wave per element)
+      e.gx = (a.rows * a.w <= 1024 || a.det) ? hp::cdiv(a.rows * a.w, 4) : blocks_for((int64_t)I[0] * I[1]);      // (emb_bwd_body: a wave per element)
       return true;
-    }
-    case HP_OP_LINEAR_FWD: {
-      LinArgs a{};
-      a.X = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.Bv = ptr<const float>(op, 2, bases);
-      a.Y = ptr<float>(op, 3, bases); a.stats = I[6] ? ptr<double>(op, 4, bases) : nullptr;
-      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldx = I[3]; a.ldy = I[4]; a.act = I[5]; a.slope = op.f[0];
-      e.a.lin = a; e.gx = blocks_for((int64_t)a.M * a.N);
-      return a.K < 128;                       // long contractions use the wave-per-output kernel (not chainable)
-    }
-    case HP_OP_LINEAR_BWD_X: {
-      LinArgs a{};
-      a.DY = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.DX = ptr<float>(op, 2, bases);
-      a.ACT = ptr<const float>(op, 3, bases);
-      a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4]; a.has_mask = I[5]; a.lda = I[6]; a.accumulate = I[7];
-      a.slope = op.f[0];
-      e.a.lin = a; e.gx = blocks_for((int64_t)a.M * a.K);
-      return !(a.N >= 128 && (int64_t)a.M * a.K <= (1 << 20));
     }
     case HP_OP_LINEAR_BWD_W: {
       LinArgs a{};
@@ -1396,177 +1337,15 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
       e.a.loss = a;
       return true;
     }
-    case HP_OP_STEP_INC:
-      e.a.stepinc.step = ptr<int64_t>(op, 0, bases);
-      return true;
-    case HP_OP_ZERO: {
-      uint8_t* dst = ptr<uint8_t>(op, 0, bases);
-      const size_t nbytes = (size_t)(uint32_t)I[0] + ((size_t)(uint32_t)I[1] << 32);
-      e.a.zero.p16 = reinterpret_cast<uint4*>(dst); e.a.zero.n16 = nbytes >> 4;
-      e.a.zero.tail = dst + ((nbytes >> 4) << 4); e.a.zero.ntail = (int)(nbytes & 15);
-      e.gx = (int)std::min<size_t>(2048, std::max<size_t>(1, (e.a.zero.n16 + 255) / 256));
-      return ((uintptr_t)dst & 15) == 0 && nbytes > 0;
-    }
     default:
       return false;
   }
 }
 
-__device__ __forceinline__ void zero_body(uint4* p16, size_t n16, uint8_t* tail, int ntail, int bx, int nblk) {
-  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n16; i += (size_t)nblk * 256) p16[i] = z;
-  if (bx == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
-}
-
-// one virtual block of one chained op
-__device__ __forceinline__ void small_block(const SmallEntry& e, int bx, int by, int bz, double* lds_d, float* lds_f) {
-  switch (e.op) {
-    case HP_OP_BN_APPLY:
-      if (e.variant == 4) bn_apply_body<4>(e.a.bn_apply, bx, by, reinterpret_cast<float(*)[256 * 4]>(lds_f));
-      else bn_apply_body<1>(e.a.bn_apply, bx, by, reinterpret_cast<float(*)[256]>(lds_f));
-      break;
-    case HP_OP_BN_BWD_REDUCE:
-      if (e.variant == 4) bn_bwd_reduce_body<4>(e.a.bn_red, bx, by, lds_d);
-      else bn_bwd_reduce_body<1>(e.a.bn_red, bx, by, lds_d);
-      break;
-    case HP_OP_BN_BWD_APPLY:
-      if (e.variant == 4) bn_bwd_apply_body<4>(e.a.bn_bapply, bx, by, reinterpret_cast<float(*)[256 * 4]>(lds_f));
-      else bn_bwd_apply_body<1>(e.a.bn_bapply, bx, by, reinterpret_cast<float(*)[256]>(lds_f));
-      break;
-    case HP_OP_CONCAT: concat_body(e.a.concat, bx); break;
-    case HP_OP_EMB_BWD: emb_bwd_body(e.a.emb, bx); break;
-    case HP_OP_LINEAR_FWD: linear_fwd_thread_body(e.a.lin, bx); break;
-    case HP_OP_LINEAR_BWD_X: linear_bwd_x_body(e.a.lin, bx); break;
-    case HP_OP_LINEAR_BWD_W: linear_bwd_w_body(e.a.lin, e.rows_per_z, bx, by, bz); break;
-    case HP_OP_REPARAM_KL_FWD: reparam_kl_fwd_body(e.a.rp, bx); break;
-    case HP_OP_REPARAM_KL_BWD: reparam_kl_bwd_body(e.a.rp, bx); break;
-    case HP_OP_MSE_FWD_BWD: mse_body(e.a.mse, bx); break;
-    case HP_OP_LOSS_FINALIZE: loss_finalize_body(e.a.loss); break;
-    case HP_OP_STEP_INC: if (threadIdx.x == 0) e.a.stepinc.step[0] += 1; break;
-    case HP_OP_ZERO: zero_body(e.a.zero.p16, e.a.zero.n16, e.a.zero.tail, e.a.zero.ntail, bx, e.gx); break;
-    default: break;
-  }
-}
-
-__global__ __launch_bounds__(256) void chain_kernel(const SmallEntry* __restrict__ entries, int n) {
-  // LDS of the BatchNorm bodies (the largest users): double[3*4*256] for the backward reduction, float[5][256*4] for the applies
-  __shared__ double lds_d[3 * 4 * 256];
-  float* lds_f = reinterpret_cast<float*>(lds_d);
-  for (int k = 0; k < n; ++k) {
-    const SmallEntry& e = entries[k];
-    const int gx = e.gx, gy = e.gy, gz = e.gz;
-    for (int bz = 0; bz < gz; ++bz)
-      for (int by = 0; by < gy; ++by)
-        for (int bx = 0; bx < gx; ++bx) {
-          small_block(e, bx, by, bz, lds_d, lds_f);
-          __syncthreads();                 // the bodies reuse their LDS
-        }
-    // the next member reads what this one wrote (global stores, fp32 / fp64 atomics) — all inside this ONE workgroup: the
-    // barrier's workgroup-scope release / acquire orders them.  (Round 2 first had agent-scope __threadfence() calls here:
-    // ~5 us each on this multi-XCD part, see rowchain_kernel.)
-    __syncthreads();
-  }
-}
-
-// ---- HP_FLAG_ROWWISE: a run of ROW-LOCAL small ops (the heads between two BatchNorm reductions) as one launch ------------
-// Every member maps rows of its inputs to the same rows of its outputs (column sums leave through atomics and are read by a
-// LATER launch).  Workgroup g therefore runs the whole run on rows [g*R, (g+1)*R) alone: the members' own kernel bodies on
-// a copy of their arguments whose row-indexed pointers are advanced by g*R rows and whose row count is cut to R (one
-// virtual block each: R * widest member <= 256), a workgroup barrier + fence between members.  Unlike the single-workgroup
-// chain, the dependent round trips of the run are paid once per R rows IN PARALLEL, not once per virtual block in series.
-static bool row_slice(SmallEntry& e, int r0, int R, int g) {      // (host: hp::build_rowchain)
-  switch (e.op) {
-    case HP_OP_BN_APPLY: {
-      BnApplyArgs& a = e.a.bn_apply;
-      const size_t o = (size_t)r0 * a.C;
-      a.raw += o; a.out += o;
-      if (a.res != nullptr) a.res += o;
-      a.M = std::min(R, a.M - r0); a.grp = g;
-      return true;
-    }
-    case HP_OP_BN_BWD_REDUCE: {
-      BnBwdReduceArgs& a = e.a.bn_red;
-      const size_t o = (size_t)r0 * a.C;
-      a.g1 += o; a.gout += o; a.raw += o;
-      if (a.g2 != nullptr) a.g2 += o;
-      if (a.act != nullptr) a.act += o;
-      if (a.raw2 != nullptr) a.raw2 += o;
-      a.M = std::min(R, a.M - r0); a.grp = g;
-      return true;
-    }
-    case HP_OP_BN_BWD_APPLY: {
-      BnBwdApplyArgs& a = e.a.bn_bapply;
-      const size_t o = (size_t)r0 * a.C;
-      a.g += o; a.raw += o; a.dr += o;
-      a.M = std::min(R, a.M - r0); a.grp = g;
-      return true;
-    }
-    case HP_OP_CONCAT: {
-      ConcatArgs& a = e.a.concat;
-      a.out += (size_t)r0 * a.ldo;
-      for (int j = 0; j < a.nseg; ++j) {
-        if (a.kind[j] == 0) a.src[j] += (size_t)r0 * a.ld[j];
-        else if (a.kind[j] == 1) a.idx[j] += r0;
-      }
-      a.B = std::min(R, a.B - r0);
-      return true;
-    }
-    case HP_OP_LINEAR_FWD: {
-      LinArgs& a = e.a.lin;
-      a.X += (size_t)r0 * a.ldx; a.Y += (size_t)r0 * a.ldy;
-      a.M = std::min(R, a.M - r0); a.grp = g;
-      return true;
-    }
-    case HP_OP_LINEAR_BWD_X: {
-      LinArgs& a = e.a.lin;
-      a.DY += (size_t)r0 * a.ldy; a.DX += (size_t)r0 * a.ldx;
-      if (a.has_mask) a.ACT += (size_t)r0 * a.lda;
-      a.M = std::min(R, a.M - r0);
-      return true;
-    }
-    case HP_OP_REPARAM_KL_FWD: {
-      ReparamArgs& a = e.a.rp;
-      a.mulv += (size_t)r0 * 2 * a.zd; a.eps += (size_t)r0 * a.zd; a.z += (size_t)r0 * a.zd;
-      a.B = std::min(R, a.B - r0);
-      return true;
-    }
-    case HP_OP_REPARAM_KL_BWD: {
-      ReparamArgs& a = e.a.rp;
-      a.Bfull = a.B;
-      a.mulv += (size_t)r0 * 2 * a.zd; a.eps += (size_t)r0 * a.zd; a.dz += (size_t)r0 * a.lddz; a.dmulv += (size_t)r0 * 2 * a.zd;
-      a.B = std::min(R, a.B - r0);
-      return true;
-    }
-    default:
-      return false;
-  }
-}
-
-// entries[g * n + k]: member k's arguments sliced to the rows of workgroup g (host: hp::build_rowchain).  The record is staged
-// in LDS: read through the global pointer, every argument access after a barrier was its own memory round trip (~10 us per
-// member).
-__global__ __launch_bounds__(256) void rowchain_kernel(const SmallEntry* __restrict__ entries, int n) {
-  __shared__ double lds_d[3 * 4 * 256];
-  __shared__ SmallEntry s_e;
-  float* lds_f = reinterpret_cast<float*>(lds_d);
-  const SmallEntry* mine = entries + (size_t)blockIdx.x * n;
-  for (int k = 0; k < n; ++k) {
-    const uint32_t* src = reinterpret_cast<const uint32_t*>(mine + k);
-    uint32_t* dst = reinterpret_cast<uint32_t*>(&s_e);
-    for (int i = threadIdx.x; i < (int)(sizeof(SmallEntry) / 4); i += 256) dst[i] = src[i];
-    __syncthreads();
-    small_block(s_e, 0, 0, 0, lds_d, lds_f);
-    // The next member reads the rows this one wrote — rows of THIS workgroup only: the barrier's workgroup-scope release /
-    // acquire is all that is needed.  (An agent-scope __threadfence() here writes back the L2 on this multi-XCD part:
-    // measured ~5 us each, 10 us per member.)
-    __syncthreads();
-  }
-}
-
-// HP_FLAG_PARALLEL: the members are independent — every workgroup runs ONE virtual block of one member.  Only the leaf
-// reductions the planner groups (hp::groupable) are dispatched here: a kernel carries the LDS of EVERY body it can reach,
-// and with the Linear forward's 56 KB of staging buffers in it the group ran two workgroups per CU (56-61 us for what ten
-// stand-alone launches do in 31 us).
+// Small-leaf group (HP_FLAG_GROUP_SHIFT): the members are independent — every workgroup runs ONE virtual block of one
+// member.  Only the leaf reductions the planner groups (hp::groupable) are dispatched here: a kernel carries the LDS of
+// EVERY body it can reach (a first version went through a switch over all small bodies and ran two workgroups per CU: 56-61 us
+// for what ten stand-alone launches do in 31 us).
 __global__ __launch_bounds__(256) void small_group_kernel(const SmallEntry* __restrict__ entries, int n) {
   int b = blockIdx.x;
   for (int k = 0; k < n; ++k) {
@@ -1834,70 +1613,20 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
 }
 
 
-// ---- HP chained launch: host side ---------------------------------------------------------------------------------
-bool hp::chainable(const HpOp& op) {
-  SmallEntry e;
-  void* const zero_bases[HP_NUM_SPACES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  return small_entry(op, zero_bases, e);
-}
+// ---- small-leaf group: host side ------------------------------------------------------------------------------------
+bool hp::groupable(const HpOp& op) { return op.op == HP_OP_LINEAR_BWD_W || op.op == HP_OP_EMB_BWD; }
 
-hipError_t hp::build_chain(const HpOp* members, int count, void* const* bases, void** d_entries) {
+hipError_t hp::build_small_group(const HpOp* members, int count, void* const* bases, void** d_entries) {
   std::vector<SmallEntry> entries(count);
   for (int j = 0; j < count; ++j)
-    if (!small_entry(members[j], bases, entries[j])) return hipErrorInvalidValue;
+    if (!hp::groupable(members[j]) || !small_entry(members[j], bases, entries[j])) return hipErrorInvalidValue;
+  *d_entries = nullptr;
   hipError_t e = hipMalloc(d_entries, entries.size() * sizeof(SmallEntry));
   if (e != hipSuccess) return e;
-  return hipMemcpy(*d_entries, entries.data(), entries.size() * sizeof(SmallEntry), hipMemcpyHostToDevice);
+  e = hipMemcpy(*d_entries, entries.data(), entries.size() * sizeof(SmallEntry), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(*d_entries); *d_entries = nullptr; }
+  return e;
 }
-
-// HP_FLAG_ROWWISE: rows and per-row width of a member, or false if the op is not row-sliceable
-static bool row_shape(const HpOp& op, int& rows, int& width) {
-  const int32_t* I = op.i;
-  switch (op.op) {
-    case HP_OP_BN_APPLY: if (I[2] != 0) return false; rows = I[0]; width = I[1]; return true;       // (no residual forms in the heads)
-    case HP_OP_BN_BWD_REDUCE: rows = I[0]; width = I[1]; return true;
-    case HP_OP_BN_BWD_APPLY: rows = I[0]; width = I[1]; return true;
-    case HP_OP_CONCAT: rows = I[0]; width = I[2]; return true;
-    case HP_OP_LINEAR_FWD: rows = I[0]; width = I[1]; return I[2] < 128 && I[1] <= 256;
-    case HP_OP_LINEAR_BWD_X: rows = I[0]; width = I[2]; return I[1] < 128;
-    case HP_OP_REPARAM_KL_FWD: case HP_OP_REPARAM_KL_BWD: rows = I[0]; width = I[1]; return true;
-    default: return false;
-  }
-}
-// rows per workgroup of a row-wise chain (0 = the records do not form one): all members over the same rows, the widest
-// member's R rows fit one 256-thread virtual block
-int hp::rowchain_rows(const HpOp* members, int count) {
-  int rows = -1, wmax = 1;
-  for (int j = 0; j < count; ++j) {
-    int r, w;
-    if (!row_shape(members[j], r, w) || w < 1 || w > 64) return 0;
-    if (rows >= 0 && r != rows) return 0;
-    rows = r;
-    wmax = w > wmax ? w : wmax;
-  }
-  return rows > 0 ? 256 / wmax : 0;
-}
-hipError_t hp::build_rowchain(const HpOp* members, int count, void* const* bases, void** d_entries, int* ngroups) {
-  const int R = hp::rowchain_rows(members, count);
-  if (R < 1) return hipErrorInvalidValue;
-  const int M = members[0].i[0], G = hp::cdiv(M, R);
-  std::vector<SmallEntry> entries((size_t)G * count);
-  for (int g = 0; g < G; ++g)
-    for (int j = 0; j < count; ++j) {
-      SmallEntry& e = entries[(size_t)g * count + j];
-      if (!small_entry(members[j], bases, e) || !row_slice(e, g * R, R, g)) return hipErrorInvalidValue;
-    }
-  *ngroups = G;
-  hipError_t err = hipMalloc(d_entries, entries.size() * sizeof(SmallEntry));
-  if (err != hipSuccess) return err;
-  return hipMemcpy(*d_entries, entries.data(), entries.size() * sizeof(SmallEntry), hipMemcpyHostToDevice);
-}
-hipError_t hp::launch_rowchain(const void* d_entries, int count, int ngroups, hipStream_t s) {
-  hipLaunchKernelGGL(rowchain_kernel, dim3(ngroups), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
-  return hipGetLastError();
-}
-
-bool hp::groupable(const HpOp& op) { return op.op == HP_OP_LINEAR_BWD_W || op.op == HP_OP_EMB_BWD; }
 
 hipError_t hp::launch_small_group(const HpOp* members, const void* d_entries, int count, hipStream_t s) {
   int blocks = 0;
@@ -1908,10 +1637,5 @@ hipError_t hp::launch_small_group(const HpOp* members, const void* d_entries, in
     blocks += e.gx * e.gy * e.gz;
   }
   hipLaunchKernelGGL(small_group_kernel, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
-  return hipGetLastError();
-}
-
-hipError_t hp::launch_chain(const void* d_entries, int count, hipStream_t s) {
-  hipLaunchKernelGGL(chain_kernel, dim3(1), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
   return hipGetLastError();
 }

@@ -13,7 +13,7 @@ struct HpProgram {
   std::vector<hipGraphExec_t> segs;
   std::vector<hipGraph_t> graphs;
   hipStream_t capture_stream = nullptr;
-  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; bool bf16 = false; void* chain = nullptr; int chain_len = 0; int row_groups = 0; };
+  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; bool bf16 = false; void* leaves = nullptr; int n_leaves = 0; };
   std::vector<Group> groups;          // indexed by op index (empty entries for ops without device tables)
   bool groups_ready = false;
 };
@@ -30,29 +30,70 @@ int fail_hip(const char* what, hipError_t e) {
   return 1;
 }
 
-// device tables of every WGRAD_GROUP op (lazily: program creation / validation must work without a GPU)
+void free_groups(std::vector<HpProgram::Group>& groups) {
+  for (auto& g : groups) {
+    if (g.probs) hipFree(g.probs);
+    if (g.blocks) hipFree(g.blocks);
+    if (g.leaves) hipFree(g.leaves);
+  }
+  groups.clear();
+}
+
+// device tables of every WGRAD_GROUP op and small-leaf group (lazily: program creation / validation must work without a
+// GPU).  Built into a temporary and swapped in only when complete: a failure half way frees what was built so far.
 int ensure_groups(HpProgram* p) {
   if (p->groups_ready) return 0;
-  p->groups.assign(p->ops.size(), HpProgram::Group());
+  std::vector<HpProgram::Group> groups(p->ops.size());
   for (size_t k = 0; k < p->ops.size(); ++k) {
     const HpOp& op = p->ops[k];
-    const int nchain = (op.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK;
-    if (nchain > 0) {
-      HpProgram::Group& g = p->groups[k];
-      g.chain_len = nchain + 1;
-      hipError_t e = (op.flags & HP_FLAG_ROWWISE) ? hp::build_rowchain(&p->ops[k - nchain], nchain + 1, p->bases, &g.chain, &g.row_groups)
-                                                  : hp::build_chain(&p->ops[k - nchain], nchain + 1, p->bases, &g.chain);
-      if (e != hipSuccess) return fail_hip("building chain table", e);
-      continue;
+    const int ngroup = (op.flags >> HP_FLAG_GROUP_SHIFT) & HP_FLAG_GROUP_MASK;
+    HpProgram::Group& g = groups[k];
+    hipError_t e = hipSuccess;
+    if (ngroup > 0) {
+      g.n_leaves = ngroup + 1;
+      e = hp::build_small_group(&p->ops[k - ngroup], ngroup + 1, p->bases, &g.leaves);
+    } else if (op.op == HP_OP_WGRAD_GROUP) {
+      g.ntaps = op.i[2];
+      g.bf16 = (p->ops[op.i[0]].flags & HP_CONV_BF16) != 0;
+      e = hp::build_wgrad_group(&p->ops[op.i[0]], op.i[1], p->bases, &g.probs, &g.blocks, &g.nblocks);
     }
-    if (op.op != HP_OP_WGRAD_GROUP) continue;
-    HpProgram::Group& g = p->groups[k];
-    g.ntaps = op.i[2];
-    g.bf16 = (p->ops[op.i[0]].flags & HP_CONV_BF16) != 0;
-    hipError_t e = hp::build_wgrad_group(&p->ops[op.i[0]], op.i[1], p->bases, &g.probs, &g.blocks, &g.nblocks);
-    if (e != hipSuccess) return fail_hip("building wgrad group tables", e);
+    if (e != hipSuccess) {
+      free_groups(groups);
+      return fail_hip("building group tables", e);
+    }
   }
+  p->groups.swap(groups);
   p->groups_ready = true;
+  return 0;
+}
+
+// A run / capture / profile range must not cut through a launch unit: members execute at their closing record (PAIR,
+// WGRAD_GROUP, small-leaf group), so a range holding members without their closing record would silently skip them and a
+// range holding a closing record without its members would run ops outside the range.
+int check_range(const HpProgram* p, int first, int count, const char* who) {
+  const int last = first + count;       // exclusive
+  for (int k = first; k < last; ++k) {
+    const HpOp& op = p->ops[k];
+    int lo = k, hi = k;                 // the records this closing record executes
+    const int ngroup = (op.flags >> HP_FLAG_GROUP_SHIFT) & HP_FLAG_GROUP_MASK;
+    if (ngroup > 0) lo = k - ngroup;
+    else if (op.op == HP_OP_WGRAD_GROUP) { lo = op.i[0]; hi = op.i[0] + op.i[1] - 1; }
+    else if (op.op == HP_OP_PAIR) { lo = op.i[0] < op.i[1] ? op.i[0] : op.i[1]; hi = op.i[0] < op.i[1] ? op.i[1] : op.i[0]; }
+    if (lo < first || hi >= last)
+      return fail(std::string(who) + ": the range cuts through the launch unit closed by op " + std::to_string(k));
+  }
+  // every member inside the range needs its closing record inside it too
+  std::vector<char> covered(count > 0 ? count : 0, 0);
+  for (int k = first; k < last; ++k) {
+    const HpOp& op = p->ops[k];
+    const int ngroup = (op.flags >> HP_FLAG_GROUP_SHIFT) & HP_FLAG_GROUP_MASK;
+    if (ngroup > 0) for (int j = k - ngroup; j < k; ++j) covered[j - first] = 1;
+    else if (op.op == HP_OP_WGRAD_GROUP) for (int j = op.i[0]; j < op.i[0] + op.i[1]; ++j) covered[j - first] = 1;
+    else if (op.op == HP_OP_PAIR) { covered[op.i[0] - first] = 1; covered[op.i[1] - first] = 1; }
+  }
+  for (int k = first; k < last; ++k)
+    if ((p->ops[k].flags & HP_FLAG_MEMBER) && !covered[k - first])
+      return fail(std::string(who) + ": member op " + std::to_string(k) + " is inside the range but its group / pair record is not");
   return 0;
 }
 
@@ -66,12 +107,10 @@ hipError_t dispatch(const HpOp& op, void* const* bases, hipStream_t s) {
 
 hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
   const HpOp& op = p->ops[k];
-  if (op.flags & HP_FLAG_MEMBER) return hipSuccess;            // done by its group / pair / chain launch
-  if ((op.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK) {
+  if (op.flags & HP_FLAG_MEMBER) return hipSuccess;            // done by its group / pair launch
+  if ((op.flags >> HP_FLAG_GROUP_SHIFT) & HP_FLAG_GROUP_MASK) {
     const HpProgram::Group& g = p->groups[k];
-    if (op.flags & HP_FLAG_ROWWISE) return hp::launch_rowchain(g.chain, g.chain_len, g.row_groups, s);
-    if (op.flags & HP_FLAG_PARALLEL) return hp::launch_small_group(&p->ops[k - (g.chain_len - 1)], g.chain, g.chain_len, s);
-    return hp::launch_chain(g.chain, g.chain_len, s);
+    return hp::launch_small_group(&p->ops[k - (g.n_leaves - 1)], g.leaves, g.n_leaves, s);
   }
   if (op.op == HP_OP_WGRAD_GROUP) {
     const HpProgram::Group& g = p->groups[k];
@@ -106,19 +145,8 @@ int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
         if (I[22 + j]) { src1 = true; w1 = I[16 + j] + 1 > w1 ? I[16 + j] + 1 : w1; }
         else { src0 = true; w0 = I[16 + j] + 1 > w0 ? I[16 + j] + 1 : w0; }
       }
-      const bool in_dr = op.flags & HP_CONV_IN_DR;
-      if (src0) { if (!in_dr) need[0] = rows_in() * K * f4; need[1] = w0 * N * K * f4; }
-      if (src1) { if (!in_dr) need[10] = rows_in() * K * f4; need[11] = w1 * N * K * f4; }
-      if (in_dr) {
-        for (int s_ = 0; s_ < 2; ++s_) {
-          if (!(s_ == 0 ? src0 : src1)) continue;
-          const int b0 = 24 + 8 * s_;
-          need[b0] = need[b0 + 1] = rows_in() * K * f4;            // G, RAW
-          need[b0 + 2] = 2 * K * f4; need[b0 + 3] = stat(K);       // SAVE, BS
-          need[b0 + 4] = need[b0 + 5] = need[b0 + 6] = K * f4;     // GAMMA, DGAMMA, DBETA
-          if (op.buf[b0 + 7] != HP_NULL) need[b0 + 7] = rows_in() * K * f4;
-        }
-      }
+      if (src0) { need[0] = rows_in() * K * f4; need[1] = w0 * N * K * f4; }
+      if (src1) { need[10] = rows_in() * K * f4; need[11] = w1 * N * K * f4; }
       need[2] = out_rows * N * f4;
       if (op.flags & HP_CONV_IN_BN) { need[5] = need[6] = need[7] = need[8] = K * f4; need[12] = stat(K); need[13] = need[14] = 2 * K * f4; }
       if (op.flags & HP_CONV_EPI_BNRED) {
@@ -265,7 +293,6 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
       if (op.i[28] > 0) ok = ok && op.i[29] >= 1 && op.i[30] >= 0 && (int64_t)op.i[29] * (op.i[3] - 1) + op.i[30] < op.i[28];
       if (op.flags & HP_CONV_IN_BN) ok = ok && K <= 512 && op.i[31] > 0 && !(op.flags & HP_CONV_BN_EVAL) && op.f[2] >= 0.f && op.f[2] <= 1.f;     // coefficient table in LDS; leaky_relu evaluated as max(v, v * slope)
       if (op.flags & HP_CONV_EPI_BNRED) ok = ok && !(op.flags & (HP_CONV_BIAS | HP_CONV_STATS | HP_CONV_BN_EVAL));
-      if (op.flags & HP_CONV_IN_DR) ok = ok && K <= 512 && op.i[33] > 0 && !(op.flags & (HP_CONV_IN_BN | HP_CONV_BN_EVAL));
       for (int j = 0; j < nt && j < HP_MAX_TAPS; ++j) ok = ok && (op.i[22 + j] == 0 || op.i[22 + j] == 1);
     }
     if (op.op == HP_OP_WGRAD_TAPS)
@@ -328,7 +355,7 @@ int hp_program_destroy(HpProgram* p) {
   if (!p) return 0;
   for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
   for (auto g : p->graphs) if (g) hipGraphDestroy(g);
-  for (auto& g : p->groups) { if (g.probs) hipFree(g.probs); if (g.blocks) hipFree(g.blocks); if (g.chain) hipFree(g.chain); }
+  free_groups(p->groups);
   if (p->capture_stream) hipStreamDestroy(p->capture_stream);
   delete p;
   return 0;
@@ -346,24 +373,21 @@ int hp_program_validate(const HpProgram* p) {
       const HpOp& a = p->ops[g.i[0]];
       const HpOp& b = p->ops[g.i[1]];
       const bool kind_ok = a.op == b.op && (a.flags & HP_FLAG_MEMBER) && (b.flags & HP_FLAG_MEMBER) &&
-                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & HP_CONV_BF16) == (b.flags & HP_CONV_BF16) &&
-                             (a.flags & HP_CONV_IN_DR) == (b.flags & HP_CONV_IN_DR)) ||
+                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & HP_CONV_BF16) == (b.flags & HP_CONV_BF16)) ||
                             ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
                              (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
       if (!kind_ok) return fail("pair op " + std::to_string(k) + ": members are not two pairable ops of one kind");
     }
-    const int nchain = (p->ops[k].flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK;
-    if (nchain > 0) {
-      if (nchain >= HP_CHAIN_MAX || (int)k - nchain < 0 || (p->ops[k].flags & HP_FLAG_MEMBER))
-        return fail("chain ending at op " + std::to_string(k) + ": bad length");
-      for (int j = (int)k - nchain; j <= (int)k; ++j) {
+    const int ngroup = (p->ops[k].flags >> HP_FLAG_GROUP_SHIFT) & HP_FLAG_GROUP_MASK;
+    if (ngroup > 0) {
+      if (ngroup >= HP_GROUP_MAX || (int)k - ngroup < 0 || (p->ops[k].flags & HP_FLAG_MEMBER))
+        return fail("small-leaf group ending at op " + std::to_string(k) + ": bad length");
+      for (int j = (int)k - ngroup; j <= (int)k; ++j) {
         const HpOp& m = p->ops[j];
-        if ((j < (int)k && !(m.flags & HP_FLAG_MEMBER)) || !hp::chainable(m) || ((p->ops[k].flags & HP_FLAG_PARALLEL) && !hp::groupable(m)) ||
-            (j < (int)k && ((m.flags >> HP_FLAG_CHAIN_SHIFT) & HP_FLAG_CHAIN_MASK)))
-          return fail("chain ending at op " + std::to_string(k) + ": member " + std::to_string(j) + " is not a chainable member record");
+        if ((j < (int)k && !(m.flags & HP_FLAG_MEMBER)) || !hp::groupable(m) ||
+            (j < (int)k && ((m.flags >> HP_FLAG_GROUP_SHIFT) & HP_FLAG_GROUP_MASK)))
+          return fail("small-leaf group ending at op " + std::to_string(k) + ": member " + std::to_string(j) + " is not a groupable member record");
       }
-      if ((p->ops[k].flags & HP_FLAG_ROWWISE) && ((p->ops[k].flags & HP_FLAG_PARALLEL) || hp::rowchain_rows(&p->ops[k - nchain], nchain + 1) < 1))
-        return fail("chain ending at op " + std::to_string(k) + ": not a row-wise chain (row-local members over the same rows, at most 64 wide)");
     }
     if (p->ops[k].op == HP_OP_WGRAD_GROUP) {
       const HpOp& g = p->ops[k];
@@ -382,6 +406,7 @@ int hp_program_run(HpProgram* p, int first, int count, void* stream) {
   if (!p) return fail("hp_program_run: null program");
   if (first < 0 || count < 0 || first + count > (int)p->ops.size()) return fail("hp_program_run: range out of bounds");
   hipStream_t s = (hipStream_t)stream;
+  if (check_range(p, first, count, "hp_program_run")) return 1;
   if (ensure_groups(p)) return 1;
   for (int k = first; k < first + count; ++k) {
     hipError_t e = run_one(p, k, s);
@@ -397,6 +422,7 @@ int hp_program_run(HpProgram* p, int first, int count, void* stream) {
 int hp_program_capture(HpProgram* p, int first, int count, int* seg) {
   if (!p || !seg) return fail("hp_program_capture: null argument");
   if (first < 0 || count <= 0 || first + count > (int)p->ops.size()) return fail("hp_program_capture: range out of bounds");
+  if (check_range(p, first, count, "hp_program_capture")) return 1;
   hipError_t e;
   if (!p->capture_stream) {
     e = hipStreamCreateWithFlags(&p->capture_stream, hipStreamNonBlocking);
@@ -435,19 +461,21 @@ int hp_program_profile(HpProgram* p, int first, int count, void* stream, float* 
   if (!p || !out_ms) return fail("hp_program_profile: null argument");
   if (first < 0 || count < 0 || first + count > (int)p->ops.size()) return fail("hp_program_profile: range out of bounds");
   hipStream_t s = (hipStream_t)stream;
-  std::vector<hipEvent_t> ev(count + 1);
-  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return fail("hipEventCreate failed");
+  if (check_range(p, first, count, "hp_program_profile")) return 1;
   if (ensure_groups(p)) return 1;
+  std::vector<hipEvent_t> ev(count + 1, nullptr);
+  auto destroy = [&]() { for (auto& x : ev) if (x) hipEventDestroy(x); };
+  for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) { destroy(); return fail("hipEventCreate failed"); }
   hipEventRecord(ev[0], s);
   for (int k = 0; k < count; ++k) {
     hipError_t e = run_one(p, first + k, s);
-    if (e != hipSuccess) return fail_hip("profile launch", e);
+    if (e != hipSuccess) { hipStreamSynchronize(s); destroy(); return fail_hip("profile launch", e); }
     hipEventRecord(ev[k + 1], s);
   }
   hipError_t e = hipStreamSynchronize(s);
-  if (e != hipSuccess) return fail_hip("hipStreamSynchronize", e);
+  if (e != hipSuccess) { destroy(); return fail_hip("hipStreamSynchronize", e); }
   for (int k = 0; k < count; ++k) hipEventElapsedTime(&out_ms[k], ev[k], ev[k + 1]);
-  for (auto& x : ev) hipEventDestroy(x);
+  destroy();
   return 0;
 }
 

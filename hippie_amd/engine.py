@@ -18,13 +18,8 @@ from .program import DeviceProgram, HipEngineError
 
 
 class Engine:
-    # Provider of the reparameterisation noise when set_inputs() is not handed one: None = torch's device generator
-    # (`torch.randn_like(std)`, hippie/model.py:48); a callable(engine) -> [B, z] tensor lets a caller run a whole
-    # pipeline (Trainer.fit, scripts) on a prescribed noise sequence — the pipeline parity test does.
-    eps_source = None
-
     def __init__(self, cfg: planner.ModelCfg, batch: int, train: planner.TrainCfg = None, with_class=False,
-                 device=None, share_params_from: "Engine" = None, _view=None):
+                 device=None, share_params_from: "Engine" = None):
         if not torch.cuda.is_available():
             raise HipEngineError("hippie_amd.Engine needs an MI355X (torch.cuda.is_available() is False); no CPU fallback")
         P.load_library()
@@ -35,14 +30,11 @@ class Engine:
         self._side = None
         self._sync_cache = {}
         self.sync_group = None          # process group of the sync-BatchNorm collectives (None = WORLD)
-        if _view is not None:
-            # a view over one model's slice of joint arenas owned by a PairEngine (which runs the program)
-            self.plan, (self.ws, self.params, self.grads, self.bufs, self.m, self.v) = _view
-            self.ops = self.plan.ops.array()
-            self.prog = None
-            self.num_batches_tracked = {k: 0 for k in self.plan.bn_keys}
-            self._init_bn_defaults()
-            return
+        # Provider of the reparameterisation noise when set_inputs() is not handed one: None = torch's device generator
+        # (`torch.randn_like(std)`, hippie/model.py:48); a callable(engine) -> [B, z] tensor lets a caller run a whole
+        # pipeline (Trainer.fit, scripts) on a prescribed noise sequence — the pipeline parity test does.  Per engine
+        # (the model containers hand their own `eps_source` down): nothing process-wide.
+        self.eps_source = None
         self.plan = planner.lower(cfg, batch, self.train_cfg, with_class)
         self.ops = self.plan.ops.array()
         n = self.plan.n_param_floats
@@ -191,8 +183,8 @@ class Engine:
             self.io("cls").copy_(cls, non_blocking=True)
         elif self.with_class:
             raise ValueError("engine was lowered with class labels; pass cls")
-        if eps is None and Engine.eps_source is not None:
-            eps = Engine.eps_source(self)
+        if eps is None and self.eps_source is not None:
+            eps = self.eps_source(self)
         if eps is None:
             self.io("eps").normal_()          # torch.randn_like(std), hippie/model.py:48
         else:

@@ -48,6 +48,9 @@ class _Net:
         # "sync": labels are range-checked on the host before every forward (IndexError at once, like nn.Embedding);
         # "deferred": device-side flag, raised by check_deferred_errors() — Trainer.fit does that once per epoch
         self.label_check = "sync"
+        # callable(engine) -> [B, z] reparameterisation noise for every forward of THIS network that is not handed one
+        # (None: torch's device generator); handed down to the engines
+        self.eps_source = None
 
     # -- engine cache -----------------------------------------------------------------
     def engine(self, batch, with_class) -> Engine:
@@ -55,6 +58,7 @@ class _Net:
         eng = self._engines.get(key)
         if eng is None:
             eng = Engine(self.cfg, key[0], self._train_cfg, with_class=key[1], device=self.device, share_params_from=self._root)
+            eng.eps_source = self.eps_source
             if self._root is None:
                 self._root = eng
                 if self._pending_sd is not None:
@@ -78,14 +82,22 @@ class _Net:
             train_cfg = replace(train_cfg, deterministic_wgrad=True)
         self._train_cfg = train_cfg
         keep = self._root
+        self.check_deferred_errors()          # a pending bad-label flag lives on the engines dropped below: report it first
         self._engines = {}
         if keep is not None:
             eng = Engine(self.cfg, keep.B, train_cfg, with_class=keep.with_class, device=self.device, share_params_from=keep)
+            eng.eps_source = self.eps_source
             if reset_optimizer:
                 eng.reset_optimizer_state()
             self._root = eng
             self._engines[(keep.B, keep.with_class)] = eng
         self._generation += 1
+
+    def set_eps_source(self, fn):
+        """Prescribe the reparameterisation noise of this network's forwards (None = torch's device generator)."""
+        self.eps_source = fn
+        for eng in self._engines.values():
+            eng.eps_source = fn
 
     def _any_engine(self) -> Engine:
         if self._root is None:

@@ -56,17 +56,6 @@ class TrainCfg:
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
     fold_eval_bn: bool = True           # eval forward: BatchNorm (+residual, +leaky_relu) folded into the producing conv's epilogue
-    chain_small: bool = False           # runs of consecutive small ops (the heads' Linear / BatchNorm / concat / reparameterisation /
-                                        # loss ops) execute as ONE launch of one workgroup (HP_FLAG_CHAIN_SHIFT).  Correct (tests) and
-                                        # 174 -> 146 launches per model-step, but MEASURED SLOWER at batch 512 (time model alone 4.55 vs
-                                        # 2.98 ms per step; 2.2x slower with the agent-scope fences the first version had between members):
-                                        # one 256-thread workgroup serialises ~350 virtual blocks of dependent L2 round trips that the
-                                        # stand-alone launches spread over 40 CUs each.  Off by default; DESIGN.md section 8.
-    fuse_bn_apply: bool = False         # (with fuse_bn) BatchNorm-backward APPLY evaluated in the input-gradient conv's operand loader
-                                        # (HP_CONV_IN_DR), which writes dr back for the grouped weight-gradient launch: 174 -> 142
-                                        # launches per model-step, bit-identical results, but MEASURED SLOWER at batch 512 (100.9 k vs
-                                        # 104.7 k samples/s): the loader's second operand stream + 12 VALU ops per float4 + 14 spilled
-                                        # VGPRs cost each input-gradient conv 5-12 us, more than the 5-8 us launch it replaces.  Off.
     fuse_bn: bool = True                # training: a block's inner BatchNorm + leaky_relu is evaluated in its consumers' operand
                                         # loaders (HP_CONV_IN_BN: the activation tensor is never written) and the BatchNorm-backward
                                         # reduction runs in the epilogue of the input-gradient conv that produces its operand
@@ -78,16 +67,9 @@ class TrainCfg:
                                         # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
                                         # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
                                         # weights and AdamW stay fp32.  Own tolerance (tests/test_gpu_bf16.py), own bench line
-    fuse_heads: bool = False            # runs of row-local head ops between two BatchNorm reductions (concat / Linear / BatchNorm apply /
-                                        # reparameterisation and their backward counterparts, <= 64 wide, one row per sample) execute as
-                                        # ONE launch in which every workgroup takes a few rows through the whole run (HP_FLAG_ROWWISE):
-                                        # 165 -> 151 launches per model-step, bit-identical (tests), and NO faster — each member is still
-                                        # two dependent L2 round trips (its inputs were just stored by the previous member), ~3 us, which
-                                        # is what the stand-alone launch costs including its floor (6-op run: 17 us vs 18 us).  The rows
-                                        # would have to stay in LDS across members (purpose-built bodies).  Off by default; DESIGN.md 8.
     group_small_wgrads: bool = True     # the small weight-gradient reductions of a backward pass (the heads' Linear dW/db, the embedding
                                         # tables) are leaves: deferred to the end of the pass and run side by side in ONE launch
-                                        # (HP_FLAG_PARALLEL chain) instead of ten launches of ~3 us each
+                                        # (HP_FLAG_GROUP) instead of ten launches of ~3 us each
     reuse_workspace: bool = True        # liveness-based packing of the workspace arena (pack_workspace): tensors that only the backward
                                         # pass touches share memory once dead, and so do the eval forward's; training-forward tensors
                                         # (all needed by the backward pass) and named I/O slots keep their own memory
@@ -298,7 +280,7 @@ class Lowering:
 
     # ---- op emitters --------------------------------------------------------------
     def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note="", a2=None, w2: PInfo = None,
-             in_bn=None, epi=None, wb_taps=()):
+             in_bn=None, epi=None):
         """One HP_OP_CONV_TAPS record.  in_bn = dict(bn, stats, M): the A operand is leaky_relu(bn(a)) evaluated in
         the loader (HP_CONV_IN_BN).  epi = a reduction spec (red_spec): HP_OP_BN_BWD_REDUCE fused into the epilogue,
         `out` must be the spec's g tensor."""
@@ -306,28 +288,10 @@ class Lowering:
         flags |= self.mm_flag
         ii = tm.conv_ints() + [0, 0]
         ff = [0.0] * 6
-        bufs = [a, w.ref, out, bias.ref if bias is not None else None, stats] + [None] * 35
+        bufs = [a, w.ref, out, bias.ref if bias is not None else None, stats] + [None] * 19
         ii += [0] * (40 - len(ii))
         if a2 is not None:
             bufs[10], bufs[11] = a2, w2.ref
-        lazy = [x for x in (a, a2) if isinstance(x, dict)]
-        if lazy:
-            # the operand(s) are BatchNorm-backward input gradients evaluated in the loader (HP_CONV_IN_DR): no stored tensor
-            assert all(isinstance(x, dict) for x in (a, a2) if x is not None) and in_bn is None
-            flags |= P.CONV_IN_DR
-            bufs[0] = None
-            if a2 is not None:
-                bufs[10] = None
-            for s_, d in enumerate(lazy):
-                b0 = 24 + 8 * s_
-                bufs[b0: b0 + 8] = [d["g"], d["raw"], d["save"], d["bs"], d["gamma"], d["dgamma"], d["dbeta"], d["dr"]]
-                ii[33 + s_] = d["M"]
-            ii[35] = self.train.sync_bn_world
-            mask = 0
-            for j in wb_taps:
-                mask |= 1 << j
-            ii[36] = mask
-            note += " <- bn-bwd-apply in the loader"
         if in_bn is not None:
             bn = in_bn["bn"]
             flags |= P.CONV_IN_BN
@@ -369,14 +333,12 @@ class Lowering:
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note="", coef=None):
         """coef: x is the raw input of a BatchNorm whose activation was never stored (HP_CONV_IN_BN on the forward
         conv): the kernel re-evaluates leaky_relu(fma(x, scale, shift)) from (scale, shift) = coef."""
-        if isinstance(dy, dict):
-            dy = dy["dr"]               # written back by the input-gradient conv that evaluates it (HP_CONV_IN_DR)
         xf = (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
         if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
             # deferred: all wgrads of the backward pass run in one grouped launch at its end.  With the
             # whole chip shared, ~64 workgroups per problem suffice: big-weight layers are not split at all.
-            per_problem = int(os.environ.get("HIPPIE_WGRAD_BLOCKS", "64"))      # (the variable: tools/micro sweeps)
+            per_problem = int(P.debug_knob("HIPPIE_WGRAD_BLOCKS", "64"))      # (the knob: tools/micro sweeps)
             nsplit = max(1, min(per_problem // tiles, -(-tm.M // 256)))
             if len(tm.taps) == 1:
                 # the 1-tap group (three shortcut convs) is too small to fill the chip at 64 blocks per problem
@@ -499,25 +461,9 @@ class Lowering:
                    f=[sp["slope"]], buf=bufs, note=bn["prefix"] + " bwd-reduce")
         self.reduce_sync(sp)
 
-    @property
-    def fuse_dr(self):
-        """BatchNorm-backward apply evaluated in the input-gradient conv's loader (HP_CONV_IN_DR): needs the deferred
-        grouped weight-gradient launch (it reads the dr tensors the convs write back)."""
-        t = self.train
-        return t.fuse_bn and t.fuse_bn_apply and t.grouped_wgrad and not t.deterministic_wgrad
-
-    def lazy_dr(self, sp, second=False):
-        """descriptor of dr = bn_bwd_apply(sp) for conv(a=...): evaluated by the consuming conv, which also writes it to `dr`"""
-        bn = sp["bn_b"] if second else sp["bn"]
-        return dict(g=sp["g"], raw=sp["raw_b"] if second else sp["raw"], save=bn["save"], bs=sp["bs_b"] if second else sp["bs"],
-                    gamma=bn["gamma"].ref, dgamma=bn["gamma"].gref, dbeta=bn["beta"].gref, dr=self.pl.f32(sp["M"] * sp["C"]), M=sp["M"])
-
-    def apply_op(self, sp, lazy=False):
-        """-> (dr, dr_b): gradients of the BatchNorm inputs (conv outputs).  lazy (and fuse_dr): descriptors instead of
-        tensors — no launch; the consuming input-gradient conv evaluates them (its `dr` member is what wgrad() gets)."""
+    def apply_op(self, sp):
+        """-> (dr, dr_b): gradients of the BatchNorm inputs (conv outputs)."""
         M, C, bn, bn_b, W = sp["M"], sp["C"], sp["bn"], sp["bn_b"], self.train.sync_bn_world
-        if lazy and self.fuse_dr:
-            return self.lazy_dr(sp), (self.lazy_dr(sp, True) if bn_b is not None else None)
         dr = self.pl.f32(M * C)
         self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[sp["g"], sp["raw"], bn["save"], sp["bs"], bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
                    note=bn["prefix"] + " bwd-apply")
@@ -536,15 +482,14 @@ class Lowering:
         dr, dr_b = self.apply_op(sp)
         return sp["g"], dr, dr_b
 
-    def dgrad_reduce(self, tm, dr, w, sp, note, wb_taps=(1,)):
-        """Input-gradient conv whose output feeds the BatchNorm-backward reduction `sp` (fused when fuse_bn).
-        wb_taps: for a lazy dr operand, the taps that write it back (stride-1 k=3: the centre tap touches every row once)."""
+    def dgrad_reduce(self, tm, dr, w, sp, note):
+        """Input-gradient conv whose output feeds the BatchNorm-backward reduction `sp` (fused when fuse_bn)."""
         if self.train.fuse_bn:
-            self.conv(tm, dr, w, sp["g"], w_kn=True, epi=sp, note=note, wb_taps=wb_taps)
+            self.conv(tm, dr, w, sp["g"], w_kn=True, epi=sp, note=note)
             self.reduce_sync(sp)
         else:
             tmp = self.pl.f32(tm.out_rows * tm.N)
-            self.conv(tm, dr, w, tmp, w_kn=True, note=note, wb_taps=wb_taps)
+            self.conv(tm, dr, w, tmp, w_kn=True, note=note)
             self.reduce_op(sp, tmp)
 
     def linear_fwd(self, M, lin, x, ldx, y, ldy, act=False, stats=None, note=""):
@@ -673,13 +618,13 @@ class Lowering:
             Lo, Li = blk["Lout"], blk["Lin"]
             Mo = B * Lo
             p = blk["prefix"]
-            dr2, drs = self.apply_op(sp, lazy=True)
+            dr2, drs = self.apply_op(sp)
             stored = blk["a1"] is not None
             self.wgrad(blk["tm2"], dr2, blk["a1"] if stored else blk["r1"], blk["conv2"], note=p + "conv2 wgrad",
                        coef=None if stored else blk["bn1"]["coef"])
             sp1 = self.red_spec(Mo, blk["bn1"], blk["a1"], blk["r1"])
             self.dgrad_reduce(self.map_dgrad(Lo, Lo, cout, cout), dr2, blk["conv2"], sp1, p + "conv2 dgrad")
-            dr1, _ = self.apply_op(sp1, lazy=True)
+            dr1, _ = self.apply_op(sp1)
             self.wgrad(blk["tm1"], dr1, blk["x"], blk["conv1"], note=p + "conv1 wgrad")
             if s == 1:
                 # d/dx = conv1 path + identity shortcut (this block's masked gradient)
@@ -694,9 +639,7 @@ class Lowering:
                 dst = spp["g"] if fuse else pl.f32(B * Li * cin)
                 tms = self.map_dgrad_s2_phases(Li, Lo, cin, cout)
                 for q, tm in enumerate(tms):
-                    # (lazy operands: the even-row op's two taps touch every row of dr1 and of drs once -> they write them back)
                     self.conv(tm, dr1, blk["conv1"], dst, w_kn=True, a2=drs, w2=blk["sc"], epi=spp if fuse else None,
-                              wb_taps=(0, 1) if tm.out_o == 0 else (),
                               note=p + "conv1 + shortcut dgrad, " + ("even" if tm.out_o == 0 else "odd") + " rows")
                 if len(tms) == 2:
                     self.pair_last_two("pair " + p + "conv1 + shortcut dgrad (even | odd rows)")
@@ -793,7 +736,7 @@ class Lowering:
             Li, Lo = blk["Lin"], blk["Lout"]
             Mi = B * Li
             p = blk["prefix"]
-            dr1, drs = self.apply_op(sp, lazy=True)
+            dr1, drs = self.apply_op(sp)
             stored = blk["a2"] is not None
             x1, c1 = (blk["a2"], None) if stored else (blk["r2"], blk["bn2"]["coef"])
             sp2 = self.red_spec(Mi, blk["bn2"], blk["a2"], blk["r2"])
@@ -806,18 +749,16 @@ class Lowering:
                 self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=p + "shortcut (resize) wgrad")
                 fuse = self.train.fuse_bn
                 da2 = sp2["g"] if fuse else pl.f32(Mi * cin)
-                # (lazy operands: taps 1 (offset 0) and 0 (offset 1) of the 6-tap map touch the even / odd rows once)
                 self.conv(self.map_dgrad_up(Li, cin, cout), dr1, blk["conv1"], da2, w_kn=True, epi=sp2 if fuse else None,
-                          wb_taps=(1, 0), note=p + "conv1 (resize) dgrad")
+                          note=p + "conv1 (resize) dgrad")
                 side = pl.f32(Mi * cin)
-                self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, wb_taps=(1, 0),
-                          note=p + "shortcut (resize) dgrad")
+                self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, note=p + "shortcut (resize) dgrad")
                 self.pair_last_two("pair " + p + "resize dgrads")
                 if fuse:
                     self.reduce_sync(sp2)
                 else:
                     self.reduce_op(sp2, da2)
-            dr2, _ = self.apply_op(sp2, lazy=True)
+            dr2, _ = self.apply_op(sp2)
             self.wgrad(blk["tm2"], dr2, blk["x"], blk["conv2"], note=p + "conv2 wgrad")
             tm = self.map_dgrad(Li, Li, cin, cin)
             if bi > 0:
@@ -828,7 +769,7 @@ class Lowering:
                 sp = spp
             else:
                 G1 = pl.f32(Mi * cin)
-                self.conv(tm, dr2, blk["conv2"], G1, w_kn=True, note=p + "conv2 dgrad", wb_taps=(1,))
+                self.conv(tm, dr2, blk["conv2"], G1, w_kn=True, note=p + "conv2 dgrad")
                 G2 = side
         dy = pl.f32(B * 512)
         self.o.add(P.REPEAT_BWD, 0, i=[B, 4, 512, 1], buf=[G1, G2, dy], note=d["prefix"] + "interpolate x4 bwd")
@@ -857,9 +798,9 @@ class Lowering:
 
     def emb_bwd(self, dcat, ld, col0):
         H = self.cfg.class_hidden_dim
-        self.small_leaf(P.EMB_BWD, 0, [self.B, H, ld, col0, self.cfg.num_sources], (), [dcat, self.src, self.semb.gref], "source_embedding grad")
+        self.small_leaf(P.EMB_BWD, self.det_flag, [self.B, H, ld, col0, self.cfg.num_sources], (), [dcat, self.src, self.semb.gref], "source_embedding grad")
         if self.with_class:
-            self.small_leaf(P.EMB_BWD, 0, [self.B, H, ld, col0 + H, self.cfg.num_classes], (), [dcat, self.cls, self.cemb.gref], "class_embedding grad")
+            self.small_leaf(P.EMB_BWD, self.det_flag, [self.B, H, ld, col0 + H, self.cfg.num_classes], (), [dcat, self.cls, self.cemb.gref], "class_embedding grad")
 
     def small_leaf(self, op, flags, i, f, buf, note):
         """A small op of the backward pass whose result nothing else in the pass reads (a weight / bias / embedding-table
@@ -887,7 +828,7 @@ class Lowering:
             n = len(self.pending_small)
             for j, (op, flags, i, f, buf, note) in enumerate(self.pending_small):
                 if n > 1:
-                    flags |= P.FLAG_MEMBER if j < n - 1 else (((n - 1) << P.FLAG_CHAIN_SHIFT) | P.FLAG_PARALLEL)
+                    flags |= P.FLAG_MEMBER if j < n - 1 else ((n - 1) << P.FLAG_GROUP_SHIFT)
                     note += " [grouped]" if j < n - 1 else f" [group of {n} small weight gradients]"
                 self.o.add(op, flags, i=i, f=f, buf=buf, note=note)
             self.pending_small = []
@@ -1079,7 +1020,7 @@ class Lowering:
             n = pl.n_active
             t = self.train
             if t.optimizer == "adamw":
-                self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="adam step += 1")       # (first: chains with the ZERO below)
+                self.o.add(P.STEP_INC, 0, buf=[self.step_ref], note="adam step += 1")
             if self.train.clip > 0:
                 # the accumulator is zeroed HERE (not only by the forward's statistics memset): optimizer.step() may
                 # run more than once per forward (a closure, a second step()) and must not double-count the norm
@@ -1117,19 +1058,13 @@ class Lowering:
         for key in ("train_zero", "eval_zero"):
             self.o.recs[segs[key]]["i"][0] = used
             self.o.recs[segs[key]]["i"][1] = 0
-        if self.train.fuse_heads and not self.train.chain_small and self.train.sync_bn_world <= 1:
-            apply_rowchains(self.o, ("fwd_train", "bwd_a", "bwd_b"), self.B)
-        if self.train.chain_small and self.train.sync_bn_world <= 1:
-            f_eval = self.o.segments["fwd_eval"][0]
-            enc_eval_end = f_eval + self.o.segments["enc_eval"][1]
-            apply_chains(self.o, ("fwd_train", "bwd_a", "bwd_b", "opt", "fwd_eval"), breaks={enc_eval_end})
         slab = pl.ws(4 * max(pl.slab_need, 4))
         for r in self.o.recs:
             if int(r["op"]) == P.WGRAD_TAPS and not (int(r["flags"]) & 1):
                 r["buf"][2] = slab.encode()
             elif int(r["op"]) == P.SLAB_REDUCE:
                 r["buf"][0] = slab.encode()
-        if self.train.reuse_workspace and not os.environ.get("HIPPIE_NO_WS_REUSE"):     # (the variable: A/B runs of unmodified callers)
+        if self.train.reuse_workspace and not P.debug_knob("HIPPIE_NO_WS_REUSE"):     # (the knob: A/B runs of unmodified callers)
             pack_workspace(pl, serial_backward=not self.train.split_backward)
         return pl
 
@@ -1140,7 +1075,7 @@ def pack_workspace(pl, serial_backward=True):
     Two classes of allocations are packed, each into a region of its own: those that only records of the backward pass
     touch, and those that only records of the eval forward touch.  Inside a class an allocation is live from the first
     to the last record that names it — counted at the position where the record EXECUTES: members of a WGRAD_GROUP /
-    PAIR / chained launch run at their group record, so the operands of the grouped weight-gradient GEMMs stay live to
+    PAIR / small-leaf group launch run at their group record, so the operands of the grouped weight-gradient GEMMs stay live to
     the end of the backward pass — and two allocations share memory only when one is dead strictly before the other is
     born.  Everything else (training-forward tensors, which the backward pass reads; named I/O slots; the statistics
     region; the slabs) keeps memory of its own, so training and eval passes may be interleaved in any order.
@@ -1167,8 +1102,8 @@ def pack_workspace(pl, serial_backward=True):
                 at[k] = g
         elif op == P.PAIR:
             at[int(r["i"][0])] = at[int(r["i"][1])] = g
-        n_chain = (int(r["flags"]) >> P.FLAG_CHAIN_SHIFT) & 0xFF
-        for k in range(g - n_chain, g):
+        n_group = (int(r["flags"]) >> P.FLAG_GROUP_SHIFT) & P.FLAG_GROUP_MASK
+        for k in range(g - n_group, g):
             at[k] = g
 
     def seg_of(k):
@@ -1251,124 +1186,6 @@ def pack_workspace(pl, serial_backward=True):
     pl.ws_unpacked = pl.ws_bytes
     pl.allocs = [[new_off[j], a[1], a[2]] for j, a in enumerate(allocs)]
     pl._ws = top
-
-
-def row_shape(r):
-    """(rows, width) of a record if the op is row-local and sliceable by rows (mirror of row_shape in csrc/ops_small.hip), else None."""
-    op, I = int(r["op"]), r["i"]
-    if op == P.BN_APPLY:
-        return (int(I[0]), int(I[1])) if int(I[2]) == 0 else None
-    if op in (P.BN_BWD_REDUCE, P.BN_BWD_APPLY):
-        return int(I[0]), int(I[1])
-    if op == P.CONCAT:
-        return int(I[0]), int(I[2])
-    if op == P.LINEAR_FWD:
-        return (int(I[0]), int(I[1])) if int(I[2]) < 128 and int(I[1]) <= 256 else None
-    if op == P.LINEAR_BWD_X:
-        return (int(I[0]), int(I[2])) if int(I[1]) < 128 else None
-    if op in (P.REPARAM_KL_FWD, P.REPARAM_KL_BWD):
-        return int(I[0]), int(I[1])
-    return None
-
-
-def apply_rowchains(oplist, segments, batch):
-    """Mark maximal runs (length >= 2) of consecutive row-local head records — one row per sample, at most 64 values wide —
-    as HP_FLAG_ROWWISE chains.  A run never continues INTO a training-mode BN_APPLY or a BN_BWD_APPLY: those read column
-    sums that must be complete, i.e. produced by an earlier launch.  No record moves."""
-    recs = oplist.recs
-    for seg in segments:
-        if seg not in oplist.segments:
-            continue
-        first, count = oplist.segments[seg]
-        run = []
-
-        def flush():
-            if len(run) >= 2:
-                for k in run[:-1]:
-                    recs[k]["flags"] = int(recs[k]["flags"]) | P.FLAG_MEMBER
-                    oplist.notes[k] += " [row-chained]"
-                recs[run[-1]]["flags"] = int(recs[run[-1]]["flags"]) | ((len(run) - 1) << P.FLAG_CHAIN_SHIFT) | P.FLAG_ROWWISE
-                oplist.notes[run[-1]] += f" [row-wise chain of {len(run)}]"
-            run.clear()
-
-        for k in range(first, first + count):
-            r = recs[k]
-            shp = row_shape(r)
-            fl = int(r["flags"])
-            ok = (shp is not None and shp[0] == batch and 1 <= shp[1] <= 64 and not (fl & P.FLAG_MEMBER)
-                  and not ((fl >> P.FLAG_CHAIN_SHIFT) & P.FLAG_CHAIN_MASK))
-            op = int(r["op"])
-            needs_complete_sums = (op == P.BN_APPLY and int(r["i"][3]) == 1) or op == P.BN_BWD_APPLY
-            if not ok or needs_complete_sums or len(run) >= P.CHAIN_MAX - 1:
-                flush()
-            if ok:
-                run.append(k)
-        flush()
-
-
-CHAIN_WORK_MAX = 700_000        # per-op work (FMA-equivalents) one 256-thread workgroup may take on inside a chained launch
-
-
-def chain_work(r):
-    """Cost estimate of one record if it is chainable (the C side has the authoritative list: hp::chainable), else None."""
-    op, I = int(r["op"]), r["i"]
-    if op in (P.LINEAR_FWD, P.LINEAR_BWD_X, P.LINEAR_BWD_W):
-        M, N, K = int(I[0]), int(I[1]), int(I[2])
-        if op == P.LINEAR_FWD and K >= 128:
-            return None
-        if op == P.LINEAR_BWD_X and N >= 128 and M * K <= (1 << 20):
-            return None
-        return M * N * K
-    if op in (P.BN_APPLY, P.BN_BWD_REDUCE, P.BN_BWD_APPLY):
-        return int(I[0]) * int(I[1]) * 8
-    if op == P.CONCAT:
-        return int(I[0]) * int(I[2]) * 2
-    if op == P.EMB_BWD:
-        return int(I[0]) * int(I[1]) * 2
-    if op in (P.REPARAM_KL_FWD, P.REPARAM_KL_BWD):
-        return int(I[0]) * int(I[1]) * 30
-    if op == P.MSE_FWD_BWD:
-        return int(I[0]) * 6
-    if op in (P.LOSS_FINALIZE, P.STEP_INC):
-        return 1
-    if op == P.ZERO:
-        nbytes = int(I[0]) + (int(I[1]) << 32)
-        return nbytes // 4 if nbytes % 16 == 0 or True else None
-    return None
-
-
-def apply_chains(oplist, segments, breaks=()):
-    """Mark maximal runs (length >= 2) of consecutive chainable records inside each named segment: all but the last
-    become members, the last carries the run length (HP_FLAG_CHAIN_SHIFT).  No record moves, so indices held by PAIR /
-    WGRAD_GROUP records and segment bounds stay valid.  A run never crosses an index in `breaks` (segment aliases that
-    end inside a segment)."""
-    recs = oplist.recs
-    for seg in segments:
-        if seg not in oplist.segments:
-            continue
-        first, count = oplist.segments[seg]
-        run = []
-
-        def flush():
-            if len(run) >= 2:
-                for k in run[:-1]:
-                    recs[k]["flags"] = int(recs[k]["flags"]) | P.FLAG_MEMBER
-                    oplist.notes[k] += " [chained]"
-                recs[run[-1]]["flags"] = int(recs[run[-1]]["flags"]) | ((len(run) - 1) << P.FLAG_CHAIN_SHIFT)
-                oplist.notes[run[-1]] += f" [chain of {len(run)}]"
-            run.clear()
-
-        for k in range(first, first + count):
-            r = recs[k]
-            w = chain_work(r)
-            ok = w is not None and w <= CHAIN_WORK_MAX and not (int(r["flags"]) & P.FLAG_MEMBER)
-            if k in breaks or len(run) >= P.CHAIN_MAX - 1:
-                flush()
-            if ok:
-                run.append(k)
-            else:
-                flush()
-        flush()
 
 
 def lower(cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, **kw) -> Plan:

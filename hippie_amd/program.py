@@ -16,11 +16,11 @@ WS, PARAM, GRAD, BUF, ADAM_M, ADAM_V = range(6)
 NUM_SPACES = 6
 NULL = -1
 MAX_TAPS = 6
-NI, NF, NB = 40, 8, 40
+NI, NF, NB = 40, 8, 24
 
 OP_DTYPE = np.dtype([("op", "<i4"), ("flags", "<i4"), ("i", "<i4", (NI,)), ("f", "<f4", (NF,)),
                      ("buf", "<i8", (NB,))], align=True)
-assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 520
+assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
 
 (CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
  POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
@@ -29,11 +29,9 @@ assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 520
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
-CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16, CONV_IN_DR = 1, 2, 4, 8, 16, 64, 128, 256, 1024
-FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the chain it belongs to
-FLAG_CHAIN_SHIFT, FLAG_CHAIN_MASK, CHAIN_MAX = 16, 0xFF, 64     # chained launch: see include/hippie_hip.h
-FLAG_ROWWISE = 0x2000000                                     # ... whose members are row-local: each workgroup takes R rows through all of them
-FLAG_PARALLEL = 0x1000000                                    # ... whose members are independent: one launch, concatenated grids
+CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 1, 2, 4, 8, 16, 64, 128, 256
+FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the small-leaf group it belongs to
+FLAG_GROUP_SHIFT, FLAG_GROUP_MASK, GROUP_MAX = 16, 0xFF, 64     # small-leaf group: see include/hippie_hip.h
 STAT_REPL_MAX = 16       # HP_STAT_REPL_MAX
 
 
@@ -132,8 +130,20 @@ class OpList:
 
 # ---- shared library ---------------------------------------------------------------
 _LIB = None
-ABI_VERSION = 4          # include/hippie_hip.h: HP_ABI_VERSION
-LIB_PATH = os.environ.get("HIPPIE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")   # (the variable: kernel-variant experiments)
+ABI_VERSION = 5          # include/hippie_hip.h: HP_ABI_VERSION
+
+
+def debug_knob(name, default=None):
+    """Measurement knobs (tools/micro sweeps, A/B runs: HIPPIE_HIP_LIB, HIPPIE_WGRAD_BLOCKS, HIPPIE_NO_WS_REUSE, and in the
+    library HIPPIE_WG_ROWS, HIPPIE_LBW_ROWS) change which library is loaded, the lowering or a summation order.  They are
+    honoured ONLY when HIPPIE_DEBUG_KNOBS=1 is set as well, and bench.py records every HIPPIE_* variable it ran under
+    (`env_overrides`), so no measurement is silently made on a non-default configuration."""
+    if os.environ.get("HIPPIE_DEBUG_KNOBS") != "1":
+        return default
+    return os.environ.get(name, default)
+
+
+LIB_PATH = debug_knob("HIPPIE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")
 
 EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",
            "hp_program_validate", "hp_program_run", "hp_program_capture", "hp_program_replay", "hp_program_profile",

@@ -70,8 +70,20 @@ class Trainer:
             module.model.deterministic = True
             module._apply_cfg()
         module.set_gradient_clip(self.gradient_clip_val)
+        # The asynchronous mode (device-side label flag, per-step losses kept on the device) is a property of THIS loop,
+        # which raises the deferred errors at every epoch end.  Outside it — `model(...)`, `get_embeddings` after fit() —
+        # nobody would, so both settings are restored on the way out: labels are range-checked on the host again
+        # (IndexError at once, like nn.Embedding, hippie/model.py:65-66).
+        saved = (module.sync_every_step, module.model.label_check)
         module.sync_every_step = self.sync_every_step
         module.model.label_check = "sync" if self.sync_every_step else "deferred"
+        try:
+            return self._fit(module, train_dataloaders, val_dataloaders)
+        finally:
+            module.sync_every_step, module.model.label_check = saved
+            module.model.check_deferred_errors()
+
+    def _fit(self, module, train_dataloaders, val_dataloaders):
         dev = self._dev(module)
         if val_dataloaders is not None and self.num_sanity_val_steps:
             self.validate(module, val_dataloaders, self.num_sanity_val_steps)

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 4
+#define HP_ABI_VERSION 5
 
 enum {
   HP_SPACE_WS = 0, HP_SPACE_PARAM = 1, HP_SPACE_GRAD = 2, HP_SPACE_BUF = 3,
@@ -64,29 +64,20 @@ static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 10
 }
 #define HP_OP_NI 40
 #define HP_OP_NF 8
-#define HP_OP_NB 40
+#define HP_OP_NB 24
 
-/* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op: the program executor skips it
- * (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
+/* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op, or of a small-leaf group (below): the
+ * program executor skips it (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
 #define HP_FLAG_MEMBER 0x200
-/* Chained launch: bits 16..23 of `flags` of a record = number n of IMMEDIATELY PRECEDING records (all flagged
- * HP_FLAG_MEMBER) that, together with this record, are executed in program order by ONE launch of one workgroup
- * (n + 1 small ops: the Linear / BatchNorm / concat / reparameterisation / loss ops of the cVAE heads, each a few
- * thousand FMAs, i.e. pure launch latency).  Arithmetic per op is unchanged (the members' own kernel bodies run);
- * hp_run_op and the reference interpreter ignore the field and execute each record on its own. */
-#define HP_FLAG_CHAIN_SHIFT 16
-#define HP_FLAG_CHAIN_MASK 0xFF
-#define HP_CHAIN_MAX 64
-/* On the LAST record of a chain: the n + 1 records are INDEPENDENT of each other (no record reads what another writes) and
- * run side by side in ONE launch — the grid is the concatenation of the members' own grids.  The planner defers the
- * small weight-gradient reductions of a backward pass (the heads' Linear dW/db, the embedding tables) into such a group:
- * ten 3 us launches, each mostly launch floor, become one. */
-#define HP_FLAG_PARALLEL 0x1000000
-/* On the LAST record of a chain: every member is ROW-LOCAL (row r of its outputs depends on row r of its inputs only; column
- * sums leave through atomics and are read by a later launch) over the same number of rows, at most 64 values wide.  The
- * run executes as ONE launch in which each workgroup takes R = 256 / (widest member) rows through all members — the cVAE
- * heads between two BatchNorm reductions (model.py:21-41,51-62). */
-#define HP_FLAG_ROWWISE 0x2000000
+/* Small-leaf group: bits 16..23 of `flags` of a record = number n of IMMEDIATELY PRECEDING records (all flagged
+ * HP_FLAG_MEMBER) that, together with this record, are INDEPENDENT of each other (no record reads what another writes) and
+ * run side by side in ONE launch whose grid is the concatenation of the members' own grids.  Members are
+ * HP_OP_LINEAR_BWD_W / HP_OP_EMB_BWD records: the planner defers the small weight-gradient reductions of a backward pass
+ * (the heads' Linear dW/db, the embedding tables) into such a group — ten 3 us launches, each mostly launch floor, become
+ * one.  hp_run_op and the reference interpreter ignore the field and execute each record on its own. */
+#define HP_FLAG_GROUP_SHIFT 16
+#define HP_FLAG_GROUP_MASK 0xFF
+#define HP_GROUP_MAX 64
 
 /* One op record (POD, 8-byte aligned; numpy dtype mirror in hippie_amd/program.py). */
 typedef struct HpOp {
@@ -116,7 +107,6 @@ typedef struct HpOp {
 #define HP_CONV_ACT      16    /* ... followed by leaky_relu */
 #define HP_CONV_IN_BN    64    /* training-mode BatchNorm + leaky_relu of the INPUT applied in the operand loader */
 #define HP_CONV_EPI_BNRED 128  /* BatchNorm-backward reduction fused into the epilogue (input-gradient convs) */
-#define HP_CONV_IN_DR    1024  /* the A operand is a BatchNorm-backward input gradient evaluated in the operand loader (below) */
 #define HP_CONV_BF16     256   /* CONV_TAPS / WGRAD_TAPS: both GEMM operands are rounded to bfloat16 (nearest even) when staged into
                                 * LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors in HBM, BatchNorm
                                 * statistics, epilogues and the optimiser stay fp32.  The separately labelled reduced-precision mode
@@ -148,19 +138,10 @@ enum {
    *   (and the same sums for a second BatchNorm fed by the same g: E_RAW2, E_SAVE2, E_BS2)  —  HP_OP_BN_BWD_REDUCE
    *   on this conv's output, fused.  f[5]=slope of that leaky_relu.
    *
-   * HP_CONV_IN_DR (input-gradient convs): the A operand of source s (s = tap_src) is
-   *   dr_s = sc * (G_s - c1 - xhat * c2),  xhat = (RAW_s - mean) * invstd,  c1 = sum(g)/Ms, c2 = sum(g*xhat)/Ms, sc = gamma*invstd
-   *   — HP_OP_BN_BWD_APPLY (the second half of ATen native_batch_norm_backward) evaluated on the way into LDS, bit for bit
-   *   (bn_dr in hp_common.h); the sums come from BS_s (i[33+s] rows, x i[35] ranks under sync-BatchNorm), mean/invstd from
-   *   SAVE_s.  Workgroup 0 writes DGAMMA_s = sum g*xhat, DBETA_s = sum g (x 1/i[35]).  The taps in the bit mask i[36] store
-   *   the rows they evaluate to DR_s (column-tile 0 only): the planner picks taps that together touch every row once, so DR_s
-   *   is the complete tensor the weight-gradient GEMM reads later.  A / A2 are unused.
-   *
    * buf: 0 A, 1 W, 2 OUT, 3 BIAS, 4 STATS(double[R][2][N]), 5 GAMMA 6 BETA 7 RMEAN 8 RVAR (of the epilogue BN with
    *      BN_EVAL, of the input BN with IN_BN), 9 RES(or NULL), 10 A2, 11 W2,
    *      12 IN_STATS(double[R][2][K]) 13 IN_SAVE(float[2][K]) 14 IN_COEF(float[2][K]),
-   *      15 E_G2 16 E_ACT 17 E_RAW 18 E_SAVE 19 E_COEF 20 E_BS 21 E_RAW2 22 E_SAVE2 23 E_BS2,
-   *      24+8s .. 31+8s (s = 0, 1): G_s RAW_s SAVE_s BS_s GAMMA_s DGAMMA_s DBETA_s DR_s */
+   *      15 E_G2 16 E_ACT 17 E_RAW 18 E_SAVE 19 E_COEF 20 E_BS 21 E_RAW2 22 E_SAVE2 23 E_BS2 */
   HP_OP_CONV_TAPS = 1,
   /* slab[split][tap_w][n][k] = sum_{m in split} DY[m][n] * X[src(m,tap)][k]; f32 MFMA.
    * Replaces the weight-gradient half of ATen convolution_backward.
@@ -222,7 +203,8 @@ enum {
    * buf: 0 OUT; 1+2j SRC/TABLE; 2+2j IDX(int64) */
   HP_OP_CONCAT = 13,
   /* embedding gradient: DT[idx[b]][k] += D[b*ld + col0 + k] (tables of <= 1024 floats: a wave per table element,
-   * fixed-order sums, no atomics; larger tables: fp32 atomics); rows with idx[b] outside [0, rows) are skipped.  i[0]=B i[1]=w i[2]=ld i[3]=col0 i[4]=rows.  buf: 0 D 1 IDX 2 DT */
+   * fixed-order sums, no atomics; larger tables: fp32 atomics unless flags & 1, which selects the ordered form at any size);
+   * rows with idx[b] outside [0, rows) are skipped.  i[0]=B i[1]=w i[2]=ld i[3]=col0 i[4]=rows.  buf: 0 D 1 IDX 2 DT */
   HP_OP_EMB_BWD = 14,
   /* nn.Linear (model.py:21-41, backbones.py:84,102,111,118,129,138):
    * Y[m*ldy+n] = act(sum_k X[m*ldx+k]*W[n*K+k] + b[n]) (+stats on the pre-activation).

@@ -281,6 +281,7 @@ class Ctx:
     def lrelu(self, name, x, slope):
         """F.leaky_relu at the named site (backbones.py:37,40,66,69,95; nn.LeakyReLU(0.2) in model.py:24,27,37,40)."""
         self.sites.append(name)
+        self.tap(name + "#pre", x)              # the pre-activation: tests bound every sign difference by its magnitude
         if self.masks is not None:
             m = self.masks[name]
             assert m.shape == x.shape and m.dtype == torch.bool, (name, tuple(m.shape), tuple(x.shape))

@@ -14,7 +14,7 @@ import numpy as np
 NULL = -1
 STAT_REPL_MAX = 16
 MASK = (1 << 56) - 1
-CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16, CONV_IN_DR = 64, 128, 256, 1024
+CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 64, 128, 256
 
 
 def _bf16(x):
@@ -155,19 +155,8 @@ def run(ops, A: Arenas, first=0, count=None):
                 Ms = int(i[31]) * max(1, int(i[32]))
                 mean, var, invstd, sc_in, sh_in = _bn_coef(A, True, Ms, K, b[12], b[5], b[6], b[7], b[8], f[3])
                 coefs = (sc_in, sh_in)
-            dr_src = {}
-            if flags & CONV_IN_DR:      # HP_OP_BN_BWD_APPLY of (G_s, RAW_s) evaluated in the loader; written back to DR_s
-                world = max(1, int(i[35]))
-                for s_ in sorted({t_[2] for t_ in taps}):
-                    b0 = 24 + 8 * s_
-                    g_ = A.f32(b[b0], nin * K).reshape(nin, K)
-                    raw_ = A.f32(b[b0 + 1], nin * K).reshape(nin, K)
-                    dr_src[s_] = _bn_dr(A, g_, raw_, b[b0 + 2], b[b0 + 3], b[b0 + 4], b[b0 + 5], b[b0 + 6], K, int(i[33 + s_]) * world, world)
-                    if int(b[b0 + 7]) != NULL:
-                        # (the kernel's write-back taps cover every row exactly once; rows no tap covers do not exist in the planner's maps)
-                        A.f32(b[b0 + 7], nin * K)[:] = dr_src[s_].reshape(-1)
             for off, w, srcsel in taps:
-                X = dr_src[srcsel] if flags & CONV_IN_DR else A.f32(b[10] if srcsel else b[0], nin * K).reshape(nin, K)
+                X = A.f32(b[10] if srcsel else b[0], nin * K).reshape(nin, K)
                 W = A.f32(b[11] if srcsel else b[1], (w + 1) * N * K)
                 src, ok = _src_rows(M, Lout, Lin, Pb, a, sh, off)
                 Xs = X[src]

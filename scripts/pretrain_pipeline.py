@@ -117,7 +117,9 @@ class _Concat:
         return _L()
 
 
-def main(argv=None):
+def main(argv=None, eps_source=None):
+    """eps_source: callable(engine) -> [B, z] noise for every forward of the networks built here (parity tests run the whole
+    pipeline on a prescribed sequence); None = torch's device generator, as the reference's torch.randn_like."""
     args = build_parser().parse_args(argv)
     if args.model_type != "unimodal":
         raise SystemExit("the reference's multimodal script branch builds EphysDatasetLabeled(mode='both'), which its own "
@@ -149,6 +151,8 @@ def main(argv=None):
 
     wave_net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=50, class_hidden_dim=5, num_sources=num_sources, num_classes=5)
     time_net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=100, class_hidden_dim=5, num_sources=num_sources, num_classes=5)
+    wave_net.set_eps_source(eps_source)
+    time_net.set_eps_source(eps_source)
     # the unimodal branch builds its modules WITHOUT beta= (scripts/...:178-183), so --beta is ignored here too
     wave_mod = hippieUnimodalEmbeddingModelCVAE(wave_net, learning_rate=args.learning_rate, weight_decay=args.weight_decay)
     time_mod = hippieUnimodalEmbeddingModelCVAE(time_net, learning_rate=args.learning_rate, weight_decay=args.weight_decay)
@@ -187,11 +191,11 @@ def main(argv=None):
     with open(os.path.join(args.output_dir, "run_config.json"), "w") as f:
         json.dump(vars(args), f)
     if args.supervised:
-        paths.update(supervised_stage(args, num_sources, trw.best_model_path, trt.best_model_path, fit))
+        paths.update(supervised_stage(args, num_sources, trw.best_model_path, trt.best_model_path, fit, eps_source))
     return paths
 
 
-def supervised_stage(args, num_sources, wave_path, time_path, fit):
+def supervised_stage(args, num_sources, wave_path, time_path, fit, eps_source=None):
     """scripts/train_model_with_multimodal.py:349-616 (unimodal branch)."""
     from sklearn.metrics import balanced_accuracy_score, confusion_matrix
     from sklearn.neighbors import KNeighborsClassifier
@@ -231,6 +235,7 @@ def supervised_stage(args, num_sources, wave_path, time_path, fit):
     for kind, L, ckpt, tr_t, va_t in (("wave", 50, wave_path, tr_wave, va_wave), ("time", 100, time_path, tr_time, va_time)):
         net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=L, class_hidden_dim=5, num_sources=num_sources,
                                  num_classes=num_class_labels)
+        net.set_eps_source(eps_source)
         mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay)
         if ckpt:
             sd = torch.load(ckpt, weights_only=False)["state_dict"]

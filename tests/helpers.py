@@ -110,26 +110,34 @@ def parity(mine, ref32, ref64, msg="", rel=1e-4, slack=3.0):
     return e_mine, e_ref
 
 
-def activation_masks(plan, ops, read_f32, B):
-    """{site -> bool tensor in the oracle's layout ([B,C,L] / [B,C])}: which branch of each leaky-ReLU the
-    implementation under test took, read back from its workspace.  Sites (Plan.act_sites, names = the oracle's
-    cvae_oracle.Ctx.lrelu) are either stored activations (out > 0 <=> in > 0 for a positive slope) or — where the
-    activation only ever exists inside the consumers' operand loaders (HP_CONV_IN_BN) — the raw BatchNorm input plus
-    the stored (scale, shift): the branch is the sign of fma(raw, scale, shift), which float64 evaluates exactly
-    (the product of two float32 is exact in float64 and the sum keeps its sign).
+def pre_activations(plan, ops, read_f32, B):
+    """{site -> float64 array in the oracle's layout ([B,C,L] / [B,C])}: the INPUT of each leaky-ReLU of the training forward
+    as the implementation under test evaluated it, read back from its workspace.  Sites (Plan.act_sites, names = the
+    oracle's cvae_oracle.Ctx.lrelu) are either stored activations (out > 0 <=> in > 0 for a positive slope; in = out or
+    out / slope) or — where the activation only ever exists inside the consumers' operand loaders (HP_CONV_IN_BN) — the raw
+    BatchNorm input plus the stored (scale, shift): the input is fma(raw, scale, shift), which float64 evaluates exactly
+    up to its last rounding (the product of two float32 is exact in float64 and the sum keeps its sign).
     read_f32(byte_offset, count) -> numpy float32 array."""
-    masks = {}
+    pres = {}
     for site in plan.act_sites:
         key, M, C = site["key"], site["M"], site["C"]
+        head = M == B and key.split(".")[0] in HEAD_SITES
         if site["kind"] == "tensor":
-            pre = np.asarray(read_f32(site["out"].offset, M * C)).reshape(B, M // B, C)
+            out = np.asarray(read_f32(site["out"].offset, M * C)).reshape(B, M // B, C).astype(np.float64)
+            slope = planner.SLOPE_HEADS if head else planner.SLOPE_BACKBONE
+            pre = np.where(out > 0, out, out / slope)
         else:
             raw = np.asarray(read_f32(site["raw"].offset, M * C)).reshape(B, M // B, C).astype(np.float64)
             cf = np.asarray(read_f32(site["coef"].offset, 2 * C)).astype(np.float64)
             pre = raw * cf[None, None, :C] + cf[None, None, C:]
-        m = torch.from_numpy(np.ascontiguousarray((pre > 0).transpose(0, 2, 1)))
-        masks[key] = m[:, :, 0] if M == B and key.split(".")[0] in HEAD_SITES else m
-    return masks
+        pre = np.ascontiguousarray(pre.transpose(0, 2, 1))
+        pres[key] = pre[:, :, 0] if head else pre
+    return pres
+
+
+def activation_masks(plan, ops, read_f32, B):
+    """{site -> bool tensor}: which branch of each leaky-ReLU the implementation under test took (pre_activations > 0)."""
+    return {k: torch.from_numpy(v > 0) for k, v in pre_activations(plan, ops, read_f32, B).items()}
 
 
 HEAD_SITES = ("encoder_fc", "fusion_encoder", "decoder_fc", "decoder_fc_mod1", "decoder_fc_mod2")
@@ -137,6 +145,43 @@ HEAD_SITES = ("encoder_fc", "fusion_encoder", "decoder_fc", "decoder_fc_mod1", "
 
 def engine_masks(eng):
     return activation_masks(eng.plan, eng.ops, lambda off, n: eng.ws[off: off + 4 * n].view(torch.float32).cpu().numpy(), eng.B)
+
+
+def engine_pre_activations(eng):
+    return pre_activations(eng.plan, eng.ops, lambda off, n: eng.ws[off: off + 4 * n].view(torch.float32).cpu().numpy(), eng.B)
+
+
+FLIP_BUDGET = 1e-5          # leaky-ReLU inputs whose sign may differ from the free-running float64 oracle's, as a fraction of all of them
+
+
+def assert_flip_budget(pres, taps32, taps64, tag, budget=FLIP_BUDGET, rel=1e-4):
+    """The UNMASKED anchor of the gradient tests.  `pres` = the implementation's leaky-ReLU inputs (pre_activations),
+    taps32 / taps64 = the free-running float32 / float64 oracle's taps (Ctx.lrelu records `site#pre`).  Asserts
+      1. every site's input tensor meets the parity criterion against the free-running float64 oracle (1e-4 of the
+         tensor's max, or 3x the float32 reference path's own error): an implementation that took the wrong branch on
+         clearly non-zero values upstream cannot pass, whatever masks the gradient comparison later injects;
+      2. the signs differ on at most `budget` of all elements (1e-5: ~10x what float32 rounding produces here);
+      3. every element whose sign differs is unresolvable at the parity bar: |pre64| <= rel * max|pre64| of its tensor
+         (implied by 1; asserted on its own so that the failure names the element).
+    Returns (flips, elements, worst |pre64| / max|pre64| over the flipped elements)."""
+    flips = total = 0
+    worst = 0.0
+    for key, mine in pres.items():
+        ref64 = taps64[key + "#pre"].detach().numpy().astype(np.float64)
+        ref32 = taps32[key + "#pre"].detach().numpy().astype(np.float64)
+        assert mine.shape == ref64.shape, (key, mine.shape, ref64.shape)
+        parity(mine, ref32, ref64, f"{tag} leaky-ReLU input {key}", rel=rel)
+        diff = (mine > 0) != (ref64 > 0)
+        total += diff.size
+        if diff.any():
+            flips += int(diff.sum())
+            mag = np.abs(ref64[diff]).max() / np.abs(ref64).max()
+            e32 = relerr(ref32, ref64)
+            assert mag <= max(rel, 3.0 * e32), f"{tag} {key}: an element with |pre| = {mag:.2e} of the tensor's max changed sign"
+            worst = max(worst, mag)
+    allowed = int(np.ceil(budget * total))
+    assert flips <= allowed, f"{tag}: {flips} leaky-ReLU sign differences over {total} elements (budget {allowed})"
+    return flips, total, worst
 
 
 def arena_masks(plan, ops, A):

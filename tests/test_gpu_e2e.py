@@ -21,10 +21,10 @@ def n(t):
     return t.detach().cpu().numpy()
 
 
-def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, split=False, chain=False, fuse_bn=True, fuse_apply=False, fuse_heads=False):
+def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, split=False, fuse_bn=True):
     cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=L, output_size2=L2 or 100)
     tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2, split_backward=split,
-                          chain_small=chain, fuse_bn=fuse_bn, fuse_bn_apply=fuse_apply, fuse_heads=fuse_heads)
+                          fuse_bn=fuse_bn)
     eng = Engine(cfg, B, tc, with_class=with_class)
     oms = []
     for dt in (torch.float32, torch.float64):
@@ -64,28 +64,20 @@ CASES = {
     "multi": dict(kind="multimodal", z=10, L=50, L2=100, B=12, with_class=False, beta=1.0, clip=1.0, lr=1e-3, salt=7, w1=1.0, w2=0.5),
     # BASELINE config 5's per-rank model (multimodal, z=64, wave 256 + time 32) at the fixture's tiny batch
     "multi_c5": dict(kind="multimodal", z=64, L=256, L2=32, B=8, with_class=False, beta=1.0, clip=1.0, lr=1e-3, salt=8, w1=1.0, w2=1.0),
-    # the optional lowerings: chained launches of the small head ops; one launch per BatchNorm pass (no loader / epilogue fusion)
-    "time_clip_chained": dict(kind="unimodal", z=10, L=100, B=16, with_class=False, beta=1.0, clip=1.0, lr=1e-3, salt=0, chain=True),
+    # the optional lowering: one launch per BatchNorm pass (no loader / epilogue fusion)
     "cls_z5_unfused_bn": dict(kind="unimodal", z=5, L=50, B=12, with_class=True, beta=0.5, clip=1.0, lr=1e-4, salt=3, fuse_bn=False),
-    # BatchNorm-backward apply evaluated in the input-gradient convs' loaders (HP_CONV_IN_DR), wave + multimodal (two-source phases)
-    "wave_fused_apply": dict(kind="unimodal", z=10, L=50, B=16, with_class=False, beta=1.0, clip=None, lr=1e-3, salt=0, fuse_apply=True),
-    "multi_fused_apply": dict(kind="multimodal", z=10, L=50, L2=100, B=12, with_class=False, beta=1.0, clip=1.0, lr=1e-3, salt=7, w1=1.0, w2=0.5, fuse_apply=True),
-    # row-local runs of head ops as one launch (HP_FLAG_ROWWISE): class labels (two gathers per concat), multimodal (accumulating dX)
-    "cls_z5_rowwise_heads": dict(kind="unimodal", z=5, L=50, B=12, with_class=True, beta=0.5, clip=1.0, lr=1e-4, salt=3, fuse_heads=True),
-    "multi_rowwise_heads": dict(kind="multimodal", z=10, L=50, L2=100, B=12, with_class=False, beta=1.0, clip=1.0, lr=1e-3, salt=7, w1=1.0, w2=0.5, fuse_heads=True),
 }
 GOLDEN = {"wave": "unimodal_wave_z10_L50_B16.npz", "time_clip": "unimodal_time_z10_L100_B16_clip.npz",
           "cls_z5": "unimodal_wave_z5_L50_B12_cls.npz", "z32_L256": "unimodal_wave_z32_L256_B8.npz",
           "z32_L32": "unimodal_time_z32_L32_B8.npz", "multi": "multimodal_z10_B12.npz", "multi_c5": "multimodal_z64_L256_32_B8.npz",
-          "time_clip_chained": "unimodal_time_z10_L100_B16_clip.npz", "cls_z5_unfused_bn": "unimodal_wave_z5_L50_B12_cls.npz",
-          "wave_fused_apply": "unimodal_wave_z10_L50_B16.npz", "multi_fused_apply": "multimodal_z10_B12.npz",
-          "cls_z5_rowwise_heads": "unimodal_wave_z5_L50_B12_cls.npz", "multi_rowwise_heads": "multimodal_z10_B12.npz"}
+          "cls_z5_unfused_bn": "unimodal_wave_z5_L50_B12_cls.npz"}
 
 
 def masked_oracle_step(eng, oms, batch, batch64, eps, c, tag):
     """Engine training forward + backward, then BOTH oracles (float32 and float64) re-evaluated on the leaky-ReLU
     branches the engine actually took (helpers.engine_masks -> OracleModel.forward(masks=...)): the comparison of
-    gradients is then decidable at the 1e-4 bar whatever the number of near-zero activations.  Returns
+    gradients is then decidable at the 1e-4 bar whatever the number of near-zero activations.  Before that, the engine's
+    branches themselves are held against the free-running oracle (flip budget).  Returns
     (engine outputs, oracle32 outs/losses, oracle64 outs/losses, flips vs the UNMASKED float64 oracle)."""
     for om in oms:
         for k in om.param_keys:
@@ -93,15 +85,21 @@ def masked_oracle_step(eng, oms, batch, batch64, eps, c, tag):
     outs = eng.forward(True)
     eng.backward()
     torch.cuda.synchronize()
-    masks = H.engine_masks(eng)
-    # diagnostic only: how many branches differ from the free-running float64 oracle (on throw-away copies:
-    # a training forward mutates the running statistics)
-    free = O.OracleModel(c["kind"], c["z"], c["L"], output_size2=c.get("L2"), salt=c["salt"], dtype=torch.float64)
-    taps_free = {}
-    with torch.no_grad():
-        free.forward(batch64, eps.double(), True, taps=taps_free)
-    flips, sites = H.count_mask_flips(masks, taps_free)
-    print(f"[{tag}] leaky-ReLU branches differing from the free-running f64 oracle: {flips} over {sites} activation tensors")
+    pres = H.engine_pre_activations(eng)
+    masks = {k: torch.from_numpy(v > 0) for k, v in pres.items()}
+    # The UNMASKED anchor: against the FREE-RUNNING oracles (throw-away copies: a training forward mutates the running
+    # statistics) every leaky-ReLU input tensor of the engine meets the parity criterion, at most 1e-5 of the signs differ,
+    # and every element whose sign differs is closer to zero than the parity bar resolves (helpers.assert_flip_budget).
+    # Only then are both oracles re-evaluated on the engine's branches for the gradient comparison.
+    taps_free = []
+    for dt, b_, e_ in ((torch.float32, batch, eps), (torch.float64, batch64, eps.double())):
+        free = O.OracleModel(c["kind"], c["z"], c["L"], output_size2=c.get("L2"), salt=c["salt"], dtype=dt)
+        taps_free.append({})
+        with torch.no_grad():
+            free.forward(b_, e_, True, taps=taps_free[-1])
+    flips, elems, worst = H.assert_flip_budget(pres, taps_free[0], taps_free[1], tag)
+    print(f"[{tag}] leaky-ReLU inputs whose sign differs from the free-running f64 oracle: {flips} of {elems} "
+          f"(budget {int(np.ceil(H.FLIP_BUDGET * elems))}); largest |pre| among them {worst:.2e} of its tensor's max")
     outs32 = oms[0].forward(batch, eps, True, masks=masks)
     ls32 = oms[0].losses(batch, outs32, c["beta"], c.get("w1", 1.0), c.get("w2", 1.0))
     ls32[0].backward()
@@ -340,57 +338,6 @@ def test_state_dict_roundtrip_and_reference_keys():
     cfgm = planner.ModelCfg(kind="multimodal", z_dim=10, output_size=50, output_size2=100)
     engm = Engine(cfgm, 4)
     assert sorted(engm.state_dict().keys()) == sorted(k for k, _, _ in man["multimodal_z10_o50_100"])
-
-
-def test_pair_engine_equals_two_engines():
-    """The zipped wave+time program (paired launches, one grouped wgrad) against two separate engines."""
-    from hippie_amd.pair import PairEngine
-    z, B = 10, 24
-    cfgs = [planner.ModelCfg("unimodal", z, 50), planner.ModelCfg("unimodal", z, 100)]
-    tcs = [planner.TrainCfg(lr=1e-6, clip=0.0), planner.TrainCfg(lr=1e-6, clip=1.0)]
-    pe = PairEngine(cfgs[0], cfgs[1], B, tcs[0], tcs[1])
-    singles = [Engine(c, B, t) for c, t in zip(cfgs, tcs)]
-    for k, L in enumerate((50, 100)):
-        om = O.OracleModel("unimodal", z, L, salt=20 + k)
-        sd = {kk: v.detach() for kk, v in om.state.items()}
-        x, src, cls, eps = O.synth_inputs(B, L, z, salt=20 + k)
-        for e in (pe.models[k], singles[k]):
-            e.load_state_dict(sd)
-            e.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
-    # gradients of the zipped program against the float64 oracle on the zipped program's own leaky-ReLU branches
-    pe.forward(True)
-    pe.backward()
-    torch.cuda.synchronize()
-    for k, L in enumerate((50, 100)):
-        x, src, cls, eps = O.synth_inputs(B, L, z, salt=20 + k)
-        masks = H.engine_masks(pe.models[k])
-        oms = [O.OracleModel("unimodal", z, L, salt=20 + k, dtype=dt) for dt in (torch.float32, torch.float64)]
-        for om, dt in zip(oms, (torch.float32, torch.float64)):
-            o = om.forward((x.to(dt), src, None), eps.to(dt), True, masks=masks)
-            om.losses((x.to(dt), src, None), o)[0].backward()
-        ga = pe.models[k].grad_dict()
-        for kk, gr in oms[0].grads().items():
-            if gr is None or re.search(H.ZERO_GRAD_RE, kk):
-                continue
-            H.parity(n(ga[kk]), n(gr), n(oms[1].grads()[kk]), f"pair model {k} grad {kk}")
-    for k, e in enumerate(pe.models):        # the probe forward above advanced the running statistics: restore them
-        e.load_state_dict(singles[k].state_dict())
-    for it, use_graph in enumerate((False, True, True)):
-        pe.train_step(use_graph=use_graph)
-        for e in singles:
-            e.train_step(use_graph=False)
-        torch.cuda.synchronize()
-        for k in range(2):
-            print(f"[pair] iteration {it} model {k}: pair {pe.models[k].scalars()} single {singles[k].scalars()}")
-            np.testing.assert_allclose(pe.models[k].scalars(), singles[k].scalars(), rtol=2e-5, err_msg=f"iteration {it} model {k}")
-    for k in range(2):
-        assert pe.models[k].adam_step == 3
-        a, b = pe.models[k].state_dict(), singles[k].state_dict()
-        for kk in a:
-            if "running_" in kk:
-                np.testing.assert_allclose(n(a[kk]), n(b[kk]), rtol=1e-4, atol=1e-4 * float(b[kk].abs().max()), err_msg=kk)   # follow the +-lr parameter noise
-            elif a[kk].dtype.is_floating_point and not re.search(H.ZERO_GRAD_RE, kk):
-                H.assert_adam_close(n(a[kk]), n(b[kk]), 1e-6, kk, steps=3, frac=5e-2)
 
 
 @pytest.mark.parametrize("B,L", [(2, 50), (3, 100), (65, 33), (513, 50)])

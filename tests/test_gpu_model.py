@@ -321,3 +321,28 @@ def test_trainer_reports_bad_labels_at_epoch_end():
     with pytest.raises(IndexError):
         Trainer(max_epochs=1, enable_checkpointing=False).fit(mod, train)
     assert all(torch.isfinite(v).all() for v in net.state_dict().values() if v.dtype.is_floating_point)   # the kernels stayed safe
+
+
+def test_label_checks_are_immediate_again_after_fit():
+    """Trainer.fit runs with a deferred (device-side) label check; once it returns, `module(batch)` and the embedding path
+    must raise IndexError at the call, like nn.Embedding (hippie/model.py:65-66) — nobody polls the deferred flag there."""
+    z, L = 10, 50
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-4)
+    train = batches(64, 32, L, z, seed=2)
+    Trainer(max_epochs=1, enable_checkpointing=False).fit(mod, train)
+    assert net.label_check == "sync" and mod.sync_every_step is True
+    x, lab = train[0]
+    bad = lab.clone()
+    bad[5] = 7
+    mod.eval()
+    with pytest.raises(IndexError):
+        mod((x.cuda(), bad.cuda()))
+    with pytest.raises(IndexError):
+        mod.embed((x.cuda(), bad.cuda()))
+    # a flag left pending on an engine is reported before configure_training drops that engine
+    net.label_check = "deferred"
+    mod((x.cuda(), bad.cuda()))
+    with pytest.raises(IndexError):
+        mod.set_gradient_clip(0.5)
+    net.label_check = "sync"

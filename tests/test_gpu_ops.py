@@ -679,149 +679,8 @@ def test_conv_eval_bn_epilogue_equals_conv_then_bn_apply(with_res, act):
     assert np.array_equal(view(gpu, out_f, np.float32, M * N), view(gpu, out_2, np.float32, M * N)), "fused != conv -> BN_APPLY"
 
 
-def test_chained_launch_equals_standalone_ops():
-    """A run of small ops executed by ONE launch of one workgroup (HP_FLAG_CHAIN_SHIFT) against the same records
-    launched one by one: same kernel bodies, so everything that does not pass through an atomic sum is bit-identical."""
-    from hippie_amd import planner
-    Bn, z, H = 300, 10, 5
-    ld = 2 * z + 2 * H
-
-    def build(img):
-        h = img.f32(Bn * 2 * z)
-        semb = img.f32(5 * H)
-        src = img.i64(img.rng.integers(0, 5, Bn))
-        c0 = img.f32(Bn * ld, zero=True)
-        w0, b0 = img.f32(2 * z * ld, 0.2), img.f32(2 * z)
-        u1, a1 = img.f32(Bn * 2 * z, zero=True), img.f32(Bn * 2 * z, zero=True)
-        st = img.f64(R(2 * z) * 4 * z)
-        gamma, beta, rm = img.f32(2 * z), img.f32(2 * z), img.f32(2 * z, 0.1)
-        rv = img._put(np.abs(img.rng.standard_normal(2 * z)).astype(np.float32) + 0.5)
-        save = img.f32(4 * z, zero=True)
-        w1, b1 = img.f32(2 * z * 2 * z, 0.2), img.f32(2 * z)
-        mulv = img.f32(Bn * 2 * z, zero=True)
-        eps, zz = img.f32(Bn * z), img.f32(Bn * z, zero=True)
-        loss = img.f64(4)
-        x, rec, drec = img.f32(Bn * 50), img.f32(Bn * 50), img.f32(Bn * 50, zero=True)
-        scal = img.f32(4, zero=True)
-        # backward-style members
-        dy = img.f32(Bn * 2 * z)
-        dw, db, dx = img.f32(2 * z * ld, zero=True), img.f32(2 * z, zero=True), img.f32(Bn * ld, zero=True)
-        dsemb = img.f32(5 * H, zero=True)
-        g, dr = img.f32(Bn * 2 * z, zero=True), img.f32(Bn * 2 * z, zero=True)
-        bs = img.f64(R(2 * z) * 4 * z)
-        dgam, dbet = img.f32(2 * z, zero=True), img.f32(2 * z, zero=True)
-        ol = P.OpList()
-        ol.begin("chain")
-        ol.add(P.CONCAT, 0, [Bn, 3, ld, 0, 0, 2 * z, 2 * z, 1, H, H, 2, H, 0, 0, 0, 0, 0, 5, 0], (), [c0, h, None, semb, src, None, None])
-        ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, ld, ld, 2 * z, 0, 1], [0.2], [c0, w0, b0, u1, st])
-        ol.add(P.BN_APPLY, 0, [Bn, 2 * z, 0, 1, 1], [0.2, 1e-5, 0.1], [u1, a1, st, gamma, beta, rm, rv, save])
-        ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, 2 * z, 2 * z, 2 * z, 0, 0], [0.2], [a1, w1, b1, mulv, None])
-        ol.add(P.REPARAM_KL_FWD, 0, [Bn, z], (), [mulv, eps, zz, loss])
-        ol.add(P.MSE_FWD_BWD, 0, [Bn * 50, 1], [1.0], [x, rec, drec, loss])
-        ol.add(P.LOSS_FINALIZE, 0, [Bn, Bn * 50, 0], [1.0, 1.0, 0.0], [loss, scal])
-        ol.add(P.BN_BWD_REDUCE, 0, [Bn, 2 * z, 0, 0], [0.2], [dy, None, a1, g, u1, save, bs])
-        ol.add(P.BN_BWD_APPLY, 0, [Bn, 2 * z], (), [g, u1, save, bs, gamma, dr, dgam, dbet])
-        ol.add(P.LINEAR_BWD_W, 0, [Bn, 2 * z, ld, 2 * z, ld], (), [dr, c0, dw, db])
-        ol.add(P.LINEAR_BWD_X, 0, [Bn, 2 * z, ld, 2 * z, ld, 0, 0, 0], [0.2], [dr, w0, dx, None])
-        ol.add(P.EMB_BWD, 0, [Bn, H, ld, 2 * z, 5], (), [dx, src, dsemb])
-        ol.end()
-        outs = dict(c0=(c0, Bn * ld), u1=(u1, Bn * 2 * z), a1=(a1, Bn * 2 * z), save=(save, 4 * z), rm=(rm, 2 * z), rv=(rv, 2 * z),
-                    mulv=(mulv, Bn * 2 * z), zz=(zz, Bn * z), drec=(drec, Bn * 50), scal=(scal, 4), g=(g, Bn * 2 * z), dr=(dr, Bn * 2 * z),
-                    dw=(dw, 2 * z * ld), dx=(dx, Bn * ld), dsemb=(dsemb, 5 * H), dgam=(dgam, 2 * z))
-        return ol, outs
-
-    img = Img(51)
-    ol, outs = build(img)
-    gpu_single, cpu = run_both(img, ol.array())             # one launch per record (hp_run_op ignores the chain field)
-    planner.apply_chains(ol, ("chain",))
-    recs = ol.array()
-    assert ((int(recs[-1]["flags"]) >> P.FLAG_CHAIN_SHIFT) & P.FLAG_CHAIN_MASK) == len(recs) - 1
-    assert all(int(r["flags"]) & P.FLAG_MEMBER for r in recs[:-1])
-    image = img.image()
-    dev = torch.from_numpy(image.copy()).cuda()
-    prog = P.DeviceProgram(recs, [dev.data_ptr()] + [dev.data_ptr()] * 5, [image.size] + [4] * 5)
-    prog.run(0, len(recs), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    gpu_chain = dev.cpu().numpy()
-    seg = prog.capture(0, len(recs))                          # and through a hipGraph
-    dev2 = torch.from_numpy(image.copy()).cuda()
-    dev.copy_(dev2)
-    prog.replay(seg, torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    gpu_graph = dev.cpu().numpy()
-    for name, (ref, n) in outs.items():
-        check(gpu_chain, cpu, ref, n, rel=3e-5, what="chain vs interpreter: " + name)
-        a, b, c_ = view(gpu_single, ref, np.float32, n), view(gpu_chain, ref, np.float32, n), view(gpu_graph, ref, np.float32, n)
-        # members downstream of an atomic sum (BatchNorm statistics, weight-gradient atomics) may differ in the last bits
-        tol = 0 if name in ("c0", "u1") else 2e-6
-        assert np.abs(a - b).max() <= tol * max(np.abs(a).max(), 1e-30), name
-        assert np.abs(b - c_).max() <= tol * max(np.abs(b).max(), 1e-30), name
-
-
-@pytest.mark.parametrize("variant", ["s1", "up", "phases"])
-def test_conv_in_dr_equals_bn_bwd_apply_then_conv(variant):
-    """HP_CONV_IN_DR: the input-gradient conv evaluates dr = bn_bwd_apply(g, raw) in its operand loader, writes it back
-    for the weight-gradient GEMM and (workgroup 0) the BatchNorm's dgamma / dbeta — bit-identical to HP_OP_BN_BWD_APPLY
-    followed by the plain conv (one coefficient derivation, one expression: hp_common.h bn_dr_coef / bn_dr)."""
-    Bn, K, N = 4, 128, 64
-    img = Img(71)
-    if variant == "s1":
-        L = 13
-        tms = [TapMap(Bn * L, N, K, L, L, L, 1, 0, [(1 - t, t) for t in range(3)])]
-        wb = [(1,)]
-        rows = Bn * L
-    elif variant == "up":       # transpose of nearest-x2 + conv: 6 taps over a source of 2*Lx rows
-        Lx = 7
-        tms = [TapMap(Bn * Lx, N, K, Lx, 2 * Lx, 2 * Lx, 2, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)])]
-        wb = [(1, 0)]
-        rows = Bn * 2 * Lx
-    else:                        # stride-2 phases: two sources, interleaved output rows
-        Lx, Ly = 13, 7
-        tms = [TapMap(Bn * 7, N, K, 7, Ly, Ly, 1, 0, [(0, 1, 0), (0, 0, 1)], out_Lfull=Lx, out_a=2, out_o=0),
-               TapMap(Bn * 6, N, K, 6, Ly, Ly, 1, 0, [(1, 0, 0), (0, 2, 0)], out_Lfull=Lx, out_a=2, out_o=1)]
-        wb = [(0, 1), ()]
-        rows = Bn * Ly
-    two = variant == "phases"
-    w, w2 = img.f32(3 * N * K, scale=0.1), img.f32(N * K, scale=0.1)
-    srcs = []
-    for s_ in range(2 if two else 1):
-        g, raw = img.f32(rows * K), img.f32(rows * K)
-        save = img._put(np.concatenate([img.rng.standard_normal(K) * 0.1, np.abs(img.rng.standard_normal(K)) + 0.5]).astype(np.float32))
-        gamma = img.f32(K)
-        bs = img.f64(R(K) * 2 * K)
-        _chunk_array(img, bs)[: 2 * K] = img.rng.standard_normal(2 * K) * rows * 0.1
-        srcs.append(dict(g=g, raw=raw, save=save, gamma=gamma, bs=bs,
-                         dr_a=img.f32(rows * K, zero=True), dr_b=img.f32(rows * K, zero=True),
-                         dga=img.f32(K, zero=True), dba=img.f32(K, zero=True), dgb=img.f32(K, zero=True), dbb=img.f32(K, zero=True)))
-    out_rows = tms[0].out_rows
-    out_a, out_b = img.f32(out_rows * N, zero=True), img.f32(out_rows * N, zero=True)
-    ol = P.OpList()
-    for sd in srcs:
-        ol.add(P.BN_BWD_APPLY, 0, [rows, K, 0], (), [sd["g"], sd["raw"], sd["save"], sd["bs"], sd["gamma"], sd["dr_a"], sd["dga"], sd["dba"]])
-    for tm in tms:
-        ol.add(P.CONV_TAPS, P.CONV_W_KN, tm.conv_ints(), (), [srcs[0]["dr_a"], w, out_a] + [None] * 7 + ([srcs[1]["dr_a"], w2] if two else []))
-    for tm, wbt in zip(tms, wb):
-        ii = tm.conv_ints() + [0] * (40 - len(tm.conv_ints()))
-        ii[33] = rows
-        ii[34] = rows if two else 0
-        ii[36] = sum(1 << j for j in wbt)
-        bufs = [None, w, out_b] + [None] * 7 + [None, w2 if two else None] + [None] * 12
-        for sd in srcs:
-            bufs += [sd["g"], sd["raw"], sd["save"], sd["bs"], sd["gamma"], sd["dgb"], sd["dbb"], sd["dr_b"]]
-        ol.add(P.CONV_TAPS, P.CONV_W_KN | P.CONV_IN_DR, ii, (), bufs)
-    gpu, cpu = run_both(img, ol.array())
-    check(gpu, cpu, out_b, out_rows * N, what="in-dr conv vs interpreter")
-    g_ = lambda ref, n: view(gpu, ref, np.float32, n)
-    np.testing.assert_array_equal(g_(out_a, out_rows * N), g_(out_b, out_rows * N))
-    for sd in srcs:
-        check(gpu, cpu, sd["dr_b"], rows * K, what="dr write-back vs interpreter")
-        np.testing.assert_array_equal(g_(sd["dr_a"], rows * K), g_(sd["dr_b"], rows * K))
-        np.testing.assert_array_equal(g_(sd["dga"], K), g_(sd["dgb"], K))
-        np.testing.assert_array_equal(g_(sd["dba"], K), g_(sd["dbb"], K))
-
-
 def test_parallel_group_of_small_weight_gradients_equals_standalone_launches():
-    """HP_FLAG_PARALLEL: independent small leaf ops (Linear weight / bias gradients of different layers, two embedding
+    """Small-leaf group (HP_FLAG_GROUP_SHIFT): independent small leaf ops (Linear weight / bias gradients of different layers, two embedding
     gradients into ONE table) run side by side in one launch — against the interpreter and against one launch per record."""
     Bn, H = 300, 5
     img = Img(61)
@@ -843,7 +702,7 @@ def test_parallel_group_of_small_weight_gradients_equals_standalone_launches():
     n = len(members)
     for j, (op, fl, i, f, buf) in enumerate(members):
         single.add(op, fl, i, f, buf)
-        group.add(op, fl | (P.FLAG_MEMBER if j < n - 1 else (((n - 1) << P.FLAG_CHAIN_SHIFT) | P.FLAG_PARALLEL)), i, f, buf)
+        group.add(op, fl | (P.FLAG_MEMBER if j < n - 1 else ((n - 1) << P.FLAG_GROUP_SHIFT)), i, f, buf)
     gpu_single, cpu = run_both(img, single.array())
     image = img.image()
     dev = torch.from_numpy(image.copy()).cuda()
@@ -863,85 +722,23 @@ def test_parallel_group_of_small_weight_gradients_equals_standalone_launches():
         P.DeviceProgram(bad, [dev.data_ptr()] * 6, [image.size] + [4] * 5)
 
 
-def test_rowwise_chain_equals_standalone_ops():
-    """HP_FLAG_ROWWISE: a run of row-local head ops as one launch in which every workgroup takes R rows through all members
-    (planner.apply_rowchains) — against the interpreter and against one launch per record, forward-style and backward-style
-    runs, a row count that is not a multiple of R."""
-    from hippie_amd import planner
-    Bn, z, H = 301, 10, 5
-    ld = 2 * z + 2 * H
-    img = Img(71)
-    # forward-style: BN_APPLY (complete statistics given) -> Linear -> reparameterise -> concat -> Linear+lrelu -> Linear+stats
-    u2 = img.f32(Bn * z)
-    st_in = img.f64(R(z) * 2 * z)
-    r = _chunk_array(img, u2).reshape(Bn, z).astype(np.float64)
-    _chunk_array(img, st_in)[:z] = r.sum(0)
-    _chunk_array(img, st_in)[z: 2 * z] = (r * r).sum(0)
-    gamma, beta, rm = img.f32(z), img.f32(z), img.f32(z, 0.1)
-    rv = img._put(np.abs(img.rng.standard_normal(z)).astype(np.float32) + 0.5)
-    save = img.f32(2 * z, zero=True)
-    encv = img.f32(Bn * z, zero=True)
-    wz, bz = img.f32(2 * z * z, 0.3), img.f32(2 * z)
-    mulv = img.f32(Bn * 2 * z, zero=True)
-    eps, zz = img.f32(Bn * z), img.f32(Bn * z, zero=True)
-    loss = img.f64(4)
-    semb = img.f32(5 * H)
-    src = img.i64(img.rng.integers(0, 5, Bn))
-    c1 = img.f32(Bn * (z + 2 * H), zero=True)
-    w0, b0 = img.f32(2 * z * (z + 2 * H), 0.3), img.f32(2 * z)
-    u3 = img.f32(Bn * 2 * z, zero=True)
-    w2, b2 = img.f32(2 * z * 2 * z, 0.3), img.f32(2 * z)
-    u4 = img.f32(Bn * 2 * z, zero=True)
-    st_out = img.f64(R(2 * z) * 4 * z)
-    # backward-style: BN_BWD_APPLY (complete sums given) -> Linear dX (masked) -> Linear dX -> BN_BWD_REDUCE
-    g, raw = img.f32(Bn * 2 * z), img.f32(Bn * 2 * z)
-    bsv = img.f64(R(2 * z) * 4 * z)
-    _chunk_array(img, bsv)[: 4 * z] = img.rng.standard_normal(4 * z)
-    save_b = img._put(np.concatenate([img.rng.standard_normal(2 * z) * 0.1, np.abs(img.rng.standard_normal(2 * z)) + 0.5]).astype(np.float32))
-    gam_b = img.f32(2 * z)
-    dr, dgam, dbet = img.f32(Bn * 2 * z, zero=True), img.f32(2 * z, zero=True), img.f32(2 * z, zero=True)
-    act = img.f32(Bn * 2 * z)
-    dx1 = img.f32(Bn * 2 * z, zero=True)
-    dx2 = img.f32(Bn * (z + 2 * H), zero=True)
-    raw_r, save_r = img.f32(Bn * (z + 2 * H)), img._put(np.concatenate([img.rng.standard_normal(z + 2 * H) * 0.1, np.abs(img.rng.standard_normal(z + 2 * H)) + 0.5]).astype(np.float32))
-    act_r = img.f32(Bn * (z + 2 * H))
-    gout_r = img.f32(Bn * (z + 2 * H), zero=True)
-    bs_r = img.f64(R(z + 2 * H) * 2 * (z + 2 * H))
-    ol = P.OpList()
-    ol.begin("fwd")
-    ol.add(P.BN_APPLY, 0, [Bn, z, 0, 1, 1], [0.2, 1e-5, 0.1], [u2, encv, st_in, gamma, beta, rm, rv, save])
-    ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, z, z, 2 * z, 0, 0], [0.2], [encv, wz, bz, mulv, None])
-    ol.add(P.REPARAM_KL_FWD, 0, [Bn, z], (), [mulv, eps, zz, loss])
-    ol.add(P.CONCAT, 0, [Bn, 3, z + 2 * H, 0, 0, z, z, 1, H, H, 2, H, 0, 0, 0, 0, 0, 5, 0], (), [c1, zz, None, semb, src, None, None])
-    ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, z + 2 * H, z + 2 * H, 2 * z, 1, 0], [0.2], [c1, w0, b0, u3, None])
-    ol.add(P.LINEAR_FWD, 0, [Bn, 2 * z, 2 * z, 2 * z, 2 * z, 0, 1], [0.2], [u3, w2, b2, u4, st_out])
-    ol.end()
-    ol.begin("bwd")
-    ol.add(P.BN_BWD_APPLY, 0, [Bn, 2 * z], (), [g, raw, save_b, bsv, gam_b, dr, dgam, dbet])
-    ol.add(P.LINEAR_BWD_X, 0, [Bn, 2 * z, 2 * z, 2 * z, 2 * z, 1, 2 * z, 0], [0.2], [dr, w2, dx1, act])
-    ol.add(P.LINEAR_BWD_X, 0, [Bn, 2 * z, z + 2 * H, 2 * z, z + 2 * H, 0, 0, 0], [0.2], [dx1, w0, dx2, None])
-    ol.add(P.BN_BWD_REDUCE, 0, [Bn, z + 2 * H, 0, 0], [0.2], [dx2, None, act_r, gout_r, raw_r, save_r, bs_r])
-    ol.end()
-    outs = dict(encv=(encv, Bn * z), save=(save, 2 * z), rm=(rm, z), rv=(rv, z), mulv=(mulv, Bn * 2 * z), zz=(zz, Bn * z), c1=(c1, Bn * (z + 2 * H)),
-                u3=(u3, Bn * 2 * z), u4=(u4, Bn * 2 * z), dr=(dr, Bn * 2 * z), dgam=(dgam, 2 * z), dbet=(dbet, 2 * z), dx1=(dx1, Bn * 2 * z),
-                dx2=(dx2, Bn * (z + 2 * H)), gout=(gout_r, Bn * (z + 2 * H)))
-    gpu_single, cpu = run_both(img, ol.array())
-    planner.apply_rowchains(ol, ("fwd", "bwd"), Bn)
-    recs = ol.array()
-    heads = [k for k, rr in enumerate(recs) if (int(rr["flags"]) >> P.FLAG_CHAIN_SHIFT) & P.FLAG_CHAIN_MASK]
-    assert heads == [5, 9] and all(int(recs[k]["flags"]) & P.FLAG_ROWWISE for k in heads)
+def test_ranges_that_cut_through_a_launch_unit_are_refused():
+    """hp_program_run / capture / profile reject a range that holds members without their closing record (they would be
+    silently skipped) or a closing record without its members (ops outside the range would run)."""
+    Bn = 64
+    img = Img(62)
+    group = P.OpList()
+    for j, (N, K) in enumerate([(20, 30), (10, 20), (20, 10)]):
+        dy, x = img.f32(Bn * N), img.f32(Bn * K)
+        dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
+        group.add(P.LINEAR_BWD_W, P.FLAG_MEMBER if j < 2 else (2 << P.FLAG_GROUP_SHIFT), [Bn, N, K, N, K], (), [dy, x, dw, db])
     image = img.image()
     dev = torch.from_numpy(image.copy()).cuda()
-    prog = P.DeviceProgram(recs, [dev.data_ptr()] * 6, [image.size] + [4] * 5)
-    seg = prog.capture(0, len(recs))
-    prog.replay(seg, torch.cuda.current_stream().cuda_stream)
+    prog = P.DeviceProgram(group.array(), [dev.data_ptr()] * 6, [image.size] + [4] * 5)
+    prog.run(0, 3)
     torch.cuda.synchronize()
-    gpu_chain = dev.cpu().numpy()
-    for name, (ref, n) in outs.items():
-        check(gpu_chain, cpu, ref, n, rel=3e-5, what="row-wise chain vs interpreter: " + name)
-        a, b = view(gpu_single, ref, np.float32, n), view(gpu_chain, ref, np.float32, n)
-        np.testing.assert_array_equal(a, b, err_msg=name)          # same bodies, same per-row arithmetic, no atomic sum upstream
-    check_stats(gpu_chain, cpu, st_out, 2 * z, what="row-wise chain: Linear statistics")
-    check_stats(gpu_chain, cpu, bs_r, z + 2 * H, what="row-wise chain: BatchNorm-backward sums")
-    lo = view(gpu_chain, loss, np.float64, 4)
-    np.testing.assert_allclose(lo, view(cpu, loss, np.float64, 4), rtol=1e-6)          # (device expf vs numpy)
+    for first, count in ((0, 2), (1, 2), (2, 1), (0, 1)):
+        with pytest.raises(P.HipEngineError):
+            prog.run(first, count)
+        with pytest.raises(P.HipEngineError):
+            prog.capture(first, count)

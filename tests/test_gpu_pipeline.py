@@ -191,11 +191,7 @@ def test_pipeline_numbers_match_the_oracle_walking_the_same_steps(tmp_path):
             "--pretrain-max-epochs", str(epochs), "--finetune-max-epochs", "2", "--z_dim", str(z), "--learning-rate", str(lr)]
     # ---- the product pipeline on the prescribed noise
     noise = _Noise()
-    Engine.eps_source = staticmethod(lambda eng: noise.draw(eng.B, eng.cfg.z_dim).to(eng.device))
-    try:
-        paths = pp.main(argv)
-    finally:
-        Engine.eps_source = None
+    paths = pp.main(argv, eps_source=lambda eng: noise.draw(eng.B, eng.cfg.z_dim).to(eng.device))
     n_forwards = noise.k
     # ---- the oracle, same steps
     torch.manual_seed(42)

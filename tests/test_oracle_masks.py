@@ -87,3 +87,33 @@ def test_wrong_mask_shape_is_rejected():
     masks["encoder.bn1"] = masks["encoder.bn1"][:, :, :-1]
     with pytest.raises(AssertionError):
         om.forward(batch, eps, True, masks=masks)
+
+
+def test_flip_budget_passes_for_the_interpreter_and_catches_a_mis_signed_band():
+    """helpers.assert_flip_budget — the unmasked anchor of the GPU gradient tests — on the numpy interpreter's forward:
+    no sign differs from the free-running float64 oracle; an implementation that took the wrong branch on a band of
+    clearly non-zero inputs (which the mask-injected oracle would FOLLOW) fails it, and so does one that exceeds the
+    count budget on values below the parity bar."""
+    plan, ops, A, om, batch, eps = _setup("unimodal", 10, 50, 8, None)
+    pres = H.pre_activations(plan, ops, lambda off, n: A.mem[P.WS][off: off + 4 * n].view(np.float32), plan.B)
+    taps = []
+    for dt in (torch.float32, torch.float64):
+        o = O.OracleModel("unimodal", 10, 50, salt=1, dtype=dt)
+        taps.append({})
+        b = tuple(t.to(dt) if (t is not None and t.is_floating_point()) else t for t in batch)
+        with torch.no_grad():
+            o.forward(b, eps.to(dt), True, taps=taps[-1])
+    flips, elems, _ = H.assert_flip_budget(pres, taps[0], taps[1], "interp")
+    assert flips == 0 and elems == sum(v.size for v in pres.values())
+    key = "encoder.layer2.0.bn1"
+    bad = {k: v.copy() for k, v in pres.items()}
+    big = np.abs(bad[key]) > 0.5 * np.abs(bad[key]).max()
+    bad[key][big] *= -1.0                                     # a mis-signed band of clearly non-zero activations
+    with pytest.raises(AssertionError):
+        H.assert_flip_budget(bad, taps[0], taps[1], "mis-signed")
+    tiny = {k: v.copy() for k, v in pres.items()}
+    small = np.abs(tiny[key]) < 1e-3 * np.abs(tiny[key]).max()
+    assert small.sum() > H.FLIP_BUDGET * elems
+    tiny[key][small] *= -1.0                                  # many flips of small values: over the count budget
+    with pytest.raises(AssertionError):
+        H.assert_flip_budget(tiny, taps[0], taps[1], "too many")

@@ -83,6 +83,10 @@ def test_shared_memory_only_between_disjoint_live_ranges():
                 at[k] = g
         elif int(r["op"]) == P.PAIR:
             at[int(r["i"][0])] = at[int(r["i"][1])] = g
+        ngroup = (int(r["flags"]) >> P.FLAG_GROUP_SHIFT) & P.FLAG_GROUP_MASK      # small-leaf group: members run at its last record
+        for k in range(g - ngroup, g):
+            at[k] = g
+    assert any((int(r["flags"]) >> P.FLAG_GROUP_SHIFT) & P.FLAG_GROUP_MASK for r in ru), "the default lowering groups its small leaves"
     span, mem = {}, {}
     for k, (u, p) in enumerate(zip(ru, rp)):
         for bu, bp in zip(u["buf"], p["buf"]):
