@@ -1,0 +1,259 @@
+// hp_model_*: a serialised lowered model (".hpm" file written by hippie_amd/export.py) loaded, bound to device arenas the
+// LIBRARY allocates, and stepped through the reference's verbs (forward / backward / optimizer step) — the part of the C ABI a
+// host WITHOUT Python uses.  hp_program_* (program.hip) stays the lower level: caller-owned arenas + op records.
+//
+// Reference interface this stands under: constructing hippieUnimodalCVAE / MultiModalCVAE (hippie/model.py:13-44,352-395) and
+// the Lightning automatic-optimisation loop around training_step (model.py:95-116): zero_grad -> training_step -> backward ->
+// [clip] -> optimizer.step().
+#include "hp_common.h"
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+constexpr int kHpmVersion = 1;
+
+struct HpmHeader {
+  char magic[8];
+  int32_t version, abi;
+  int32_t n_ops, n_segments, n_params, n_bufs, n_io, has_init;
+  int64_t arena_bytes[HP_NUM_SPACES];
+  int32_t config[16];      // kind(0 unimodal / 1 multimodal), z_dim, output_size, output_size2, class_hidden_dim, num_sources, num_classes, batch, with_class, n_active, 0...
+};
+static_assert(sizeof(HpmHeader) == 8 + 8 * 4 + 6 * 8 + 16 * 4, "HpmHeader layout");
+
+struct HpmSegment { char name[32]; int32_t first, count; };
+static_assert(sizeof(HpmSegment) == 40, "HpmSegment layout");
+static_assert(sizeof(HpTensorInfo) == 112 + 8 + 16 + 4 + 16 + 4, "HpTensorInfo layout");
+
+thread_local std::string g_merr;
+
+}  // namespace
+
+// hp_last_error() is defined in program.hip; model errors are routed through it
+namespace hp { int set_error(const std::string& msg); }
+
+struct HpModel {
+  HpmHeader hdr;
+  std::vector<HpOp> ops;
+  std::vector<HpmSegment> segments;
+  std::vector<HpTensorInfo> tensors[3];          // params, buffers, io slots
+  std::vector<float> init_param, init_buf;
+  void* arenas[HP_NUM_SPACES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  HpProgram* prog = nullptr;
+  std::map<std::string, int> graphs;             // segment name -> captured segment id
+  int64_t batches_tracked = 0;                   // BatchNorm num_batches_tracked (all layers advance together)
+  bool on_device = false;
+};
+
+namespace {
+
+int merr(const std::string& msg) { return hp::set_error(msg); }
+
+bool read_exact(FILE* f, void* dst, size_t n) { return n == 0 || fread(dst, 1, n, f) == n; }
+
+const HpmSegment* find_segment(const HpModel* m, const char* name) {
+  for (const auto& s : m->segments)
+    if (strncmp(s.name, name, sizeof s.name) == 0) return &s;
+  return nullptr;
+}
+
+int dtype_size(int dt) { return dt == 0 ? 4 : 8; }
+
+}  // namespace
+
+extern "C" {
+
+int hp_model_load(const char* path, int flags, HpModel** out) {
+  if (!path || !out) return merr("hp_model_load: null argument");
+  FILE* f = fopen(path, "rb");
+  if (!f) return merr(std::string("hp_model_load: cannot open ") + path);
+  HpModel* m = new HpModel();
+  auto bail = [&](const std::string& why) { fclose(f); hp_model_destroy(m); return merr("hp_model_load: " + why); };
+  if (!read_exact(f, &m->hdr, sizeof m->hdr)) return bail("short file (header)");
+  const HpmHeader& h = m->hdr;
+  if (memcmp(h.magic, "HPMODEL", 8) != 0) return bail("not an .hpm file (bad magic)");
+  if (h.version != kHpmVersion) return bail("unsupported file version " + std::to_string(h.version));
+  if (h.abi != HP_ABI_VERSION) return bail("lowered for ABI " + std::to_string(h.abi) + ", this library is ABI " + std::to_string(HP_ABI_VERSION));
+  if (h.n_ops <= 0 || h.n_ops > (1 << 20) || h.n_segments < 0 || h.n_segments > 4096 || h.n_params < 0 || h.n_params > (1 << 20) ||
+      h.n_bufs < 0 || h.n_bufs > (1 << 20) || h.n_io < 0 || h.n_io > 4096)
+    return bail("implausible table sizes");
+  for (int k = 0; k < HP_NUM_SPACES; ++k)
+    if (h.arena_bytes[k] <= 0 || (h.arena_bytes[k] & 3)) return bail("bad arena size");
+  m->ops.resize(h.n_ops);
+  m->segments.resize(h.n_segments);
+  if (!read_exact(f, m->ops.data(), sizeof(HpOp) * h.n_ops)) return bail("short file (ops)");
+  if (!read_exact(f, m->segments.data(), sizeof(HpmSegment) * h.n_segments)) return bail("short file (segments)");
+  const int counts[3] = {h.n_params, h.n_bufs, h.n_io};
+  for (int w = 0; w < 3; ++w) {
+    m->tensors[w].resize(counts[w]);
+    if (!read_exact(f, m->tensors[w].data(), sizeof(HpTensorInfo) * counts[w])) return bail("short file (tensor table)");
+    for (auto& t : m->tensors[w]) {
+      t.name[sizeof t.name - 1] = 0;
+      if (t.space < 0 || t.space >= HP_NUM_SPACES || t.offset_bytes < 0 || t.numel < 0 || t.dtype < 0 || t.dtype > 2 ||
+          t.offset_bytes + t.numel * dtype_size(t.dtype) > h.arena_bytes[t.space])
+        return bail(std::string("tensor '") + t.name + "' lies outside its arena");
+    }
+  }
+  if (h.has_init & 1) {
+    m->init_param.resize(h.arena_bytes[HP_SPACE_PARAM] / 4);
+    if (!read_exact(f, m->init_param.data(), h.arena_bytes[HP_SPACE_PARAM])) return bail("short file (parameter values)");
+  }
+  if (h.has_init & 2) {
+    m->init_buf.resize(h.arena_bytes[HP_SPACE_BUF] / 4);
+    if (!read_exact(f, m->init_buf.data(), h.arena_bytes[HP_SPACE_BUF])) return bail("short file (buffer values)");
+  }
+  fclose(f);
+  f = nullptr;
+  for (auto& s : m->segments) {
+    s.name[sizeof s.name - 1] = 0;
+    if (s.first < 0 || s.count < 0 || s.first + s.count > h.n_ops) { hp_model_destroy(m); return merr("hp_model_load: segment out of range"); }
+  }
+  if (flags & HP_MODEL_NO_DEVICE) {
+    // host-only: validate the records against the declared arena sizes (no allocation, no GPU)
+    void* fake[HP_NUM_SPACES];
+    for (int k = 0; k < HP_NUM_SPACES; ++k) fake[k] = nullptr;
+    if (hp_program_create(m->ops.data(), h.n_ops, fake, h.arena_bytes, &m->prog)) { hp_model_destroy(m); return 1; }
+    *out = m;
+    return 0;
+  }
+  for (int k = 0; k < HP_NUM_SPACES; ++k) {
+    hipError_t e = hipMalloc(&m->arenas[k], h.arena_bytes[k]);
+    if (e == hipSuccess) e = hipMemset(m->arenas[k], 0, h.arena_bytes[k]);
+    if (e != hipSuccess) { hp_model_destroy(m); return merr(std::string("hp_model_load: arena allocation: ") + hipGetErrorString(e)); }
+  }
+  m->on_device = true;
+  hipError_t e = hipSuccess;
+  if (!m->init_param.empty()) e = hipMemcpy(m->arenas[HP_SPACE_PARAM], m->init_param.data(), h.arena_bytes[HP_SPACE_PARAM], hipMemcpyHostToDevice);
+  if (e == hipSuccess && !m->init_buf.empty()) e = hipMemcpy(m->arenas[HP_SPACE_BUF], m->init_buf.data(), h.arena_bytes[HP_SPACE_BUF], hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hp_model_destroy(m); return merr(std::string("hp_model_load: upload: ") + hipGetErrorString(e)); }
+  if (hp_program_create(m->ops.data(), h.n_ops, m->arenas, h.arena_bytes, &m->prog)) { hp_model_destroy(m); return 1; }
+  *out = m;
+  return 0;
+}
+
+int hp_model_destroy(HpModel* m) {
+  if (!m) return 0;
+  if (m->prog) hp_program_destroy(m->prog);
+  for (int k = 0; k < HP_NUM_SPACES; ++k)
+    if (m->arenas[k]) hipFree(m->arenas[k]);
+  delete m;
+  return 0;
+}
+
+int hp_model_config(const HpModel* m, int32_t out[16]) {
+  if (!m || !out) return merr("hp_model_config: null argument");
+  memcpy(out, m->hdr.config, sizeof m->hdr.config);
+  return 0;
+}
+
+int hp_model_tensor_count(const HpModel* m, int which) {
+  if (!m || which < 0 || which > 2) return -1;
+  return (int)m->tensors[which].size();
+}
+
+int hp_model_tensor_info(const HpModel* m, int which, int index, HpTensorInfo* out) {
+  if (!m || !out || which < 0 || which > 2 || index < 0 || index >= (int)m->tensors[which].size()) return merr("hp_model_tensor_info: bad argument");
+  *out = m->tensors[which][index];
+  return 0;
+}
+
+int hp_model_find(const HpModel* m, const char* name, HpTensorInfo* out) {
+  if (!m || !name || !out) return merr("hp_model_find: null argument");
+  for (int w = 2; w >= 0; --w)      // io slots first: "x", "src", "eps", "scalars", ...
+    for (const auto& t : m->tensors[w])
+      if (strcmp(t.name, name) == 0) { *out = t; return 0; }
+  return merr(std::string("hp_model_find: no tensor named '") + name + "'");
+}
+
+void* hp_model_arena(const HpModel* m, int space, int64_t* nbytes) {
+  if (!m || space < 0 || space >= HP_NUM_SPACES) return nullptr;
+  if (nbytes) *nbytes = m->hdr.arena_bytes[space];
+  return m->arenas[space];
+}
+
+HpProgram* hp_model_program(HpModel* m) { return m ? m->prog : nullptr; }
+
+int hp_model_segment(const HpModel* m, const char* name, int* first, int* count) {
+  if (!m || !name) return merr("hp_model_segment: null argument");
+  const HpmSegment* s = find_segment(m, name);
+  if (!s) return merr(std::string("hp_model_segment: no segment named '") + name + "'");
+  if (first) *first = s->first;
+  if (count) *count = s->count;
+  return 0;
+}
+
+int hp_model_run(HpModel* m, const char* segment, int use_graph, void* stream) {
+  if (!m || !segment) return merr("hp_model_run: null argument");
+  if (!m->on_device) return merr("hp_model_run: the model was loaded with HP_MODEL_NO_DEVICE");
+  const HpmSegment* s = find_segment(m, segment);
+  if (!s) return merr(std::string("hp_model_run: no segment named '") + segment + "'");
+  if (s->count == 0) return 0;
+  if (!use_graph) return hp_program_run(m->prog, s->first, s->count, stream);
+  auto it = m->graphs.find(segment);
+  if (it == m->graphs.end()) {
+    int id = -1;
+    if (hp_program_capture(m->prog, s->first, s->count, &id)) return 1;
+    it = m->graphs.emplace(segment, id).first;
+  }
+  return hp_program_replay(m->prog, it->second, stream);
+}
+
+// ---- the reference's verbs -------------------------------------------------------------------------------------------
+int hp_model_forward(HpModel* m, int training, int use_graph, void* stream) {
+  const int rc = hp_model_run(m, training ? "fwd_train" : "fwd_eval", use_graph, stream);
+  if (rc == 0 && training) m->batches_tracked += 1;
+  return rc;
+}
+int hp_model_backward(HpModel* m, int use_graph, void* stream) { return hp_model_run(m, "bwd", use_graph, stream); }
+int hp_model_optimizer_step(HpModel* m, int use_graph, void* stream) { return hp_model_run(m, "opt", use_graph, stream); }
+int hp_model_train_step(HpModel* m, int use_graph, void* stream) {
+  if (m && find_segment(m, "step")) {
+    const int rc = hp_model_run(m, "step", use_graph, stream);
+    if (rc == 0) m->batches_tracked += 1;
+    return rc;
+  }
+  int rc = hp_model_forward(m, 1, use_graph, stream);
+  if (rc == 0) rc = hp_model_backward(m, use_graph, stream);
+  if (rc == 0) rc = hp_model_optimizer_step(m, use_graph, stream);
+  return rc;
+}
+int64_t hp_model_batches_tracked(const HpModel* m) { return m ? m->batches_tracked : -1; }
+
+int hp_model_write(HpModel* m, const char* name, const void* src, int64_t nbytes, int src_on_device, void* stream) {
+  HpTensorInfo t;
+  if (!m || !src) return merr("hp_model_write: null argument");
+  if (!m->on_device) return merr("hp_model_write: the model was loaded with HP_MODEL_NO_DEVICE");
+  if (hp_model_find(m, name, &t)) return 1;
+  if (nbytes != t.numel * dtype_size(t.dtype)) return merr(std::string("hp_model_write: '") + name + "' holds " + std::to_string(t.numel * dtype_size(t.dtype)) + " bytes, got " + std::to_string(nbytes));
+  hipError_t e = hipMemcpyAsync(static_cast<char*>(m->arenas[t.space]) + t.offset_bytes, src, nbytes,
+                                src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, (hipStream_t)stream);
+  if (e != hipSuccess) return merr(std::string("hp_model_write: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int hp_model_read(HpModel* m, const char* name, void* dst, int64_t nbytes, int dst_on_device, void* stream) {
+  HpTensorInfo t;
+  if (!m || !dst) return merr("hp_model_read: null argument");
+  if (!m->on_device) return merr("hp_model_read: the model was loaded with HP_MODEL_NO_DEVICE");
+  if (hp_model_find(m, name, &t)) return 1;
+  if (nbytes != t.numel * dtype_size(t.dtype)) return merr(std::string("hp_model_read: '") + name + "' holds " + std::to_string(t.numel * dtype_size(t.dtype)) + " bytes, asked for " + std::to_string(nbytes));
+  hipError_t e = hipMemcpyAsync(dst, static_cast<const char*>(m->arenas[t.space]) + t.offset_bytes, nbytes,
+                                dst_on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e == hipSuccess && !dst_on_device) e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return merr(std::string("hp_model_read: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int hp_model_synchronize(HpModel* m, void* stream) {
+  (void)m;
+  hipError_t e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return merr(std::string("hp_model_synchronize: ") + hipGetErrorString(e));
+  return 0;
+}
+
+}  // extern "C"

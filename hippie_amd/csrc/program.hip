@@ -25,6 +25,9 @@ int fail(const std::string& msg) {
   g_err = msg;
   return 1;
 }
+}  // namespace
+namespace hp { int set_error(const std::string& msg) { return fail(msg); } }      // (model.hip reports through hp_last_error too)
+namespace {
 int fail_hip(const char* what, hipError_t e) {
   g_err = std::string(what) + ": " + hipGetErrorString(e);
   return 1;

@@ -51,6 +51,10 @@ class _Net:
         # callable(engine) -> [B, z] reparameterisation noise for every forward of THIS network that is not handed one
         # (None: torch's device generator); handed down to the engines
         self.eps_source = None
+        # data parallel (set by Trainer.fit for the duration of a fit): replicas per process group, gradient mean between
+        # backward and optimizer.step (hippie_amd.parallel), optional sync-BatchNorm; and the MFMA operand precision
+        self.dp_world, self.dp_group, self.sync_batchnorm = 1, None, False
+        self.precision = "f32"
 
     # -- engine cache -----------------------------------------------------------------
     def engine(self, batch, with_class) -> Engine:
@@ -59,6 +63,7 @@ class _Net:
         if eng is None:
             eng = Engine(self.cfg, key[0], self._train_cfg, with_class=key[1], device=self.device, share_params_from=self._root)
             eng.eps_source = self.eps_source
+            eng.sync_group = self.dp_group
             if self._root is None:
                 self._root = eng
                 if self._pending_sd is not None:
@@ -80,6 +85,9 @@ class _Net:
         # in a fixed order (per-split slabs + ordered reduce) instead of with fp32 atomics — runs become bit-reproducible
         if (self.deterministic or torch.are_deterministic_algorithms_enabled()) and not train_cfg.deterministic_wgrad:
             train_cfg = replace(train_cfg, deterministic_wgrad=True)
+        # network-level settings survive every re-lowering of the optimiser constants
+        train_cfg = replace(train_cfg, mfma_dtype=self.precision,
+                            sync_bn_world=self.dp_world if (self.sync_batchnorm and self.dp_world > 1) else 0)
         self._train_cfg = train_cfg
         keep = self._root
         self.check_deferred_errors()          # a pending bad-label flag lives on the engines dropped below: report it first
@@ -87,11 +95,45 @@ class _Net:
         if keep is not None:
             eng = Engine(self.cfg, keep.B, train_cfg, with_class=keep.with_class, device=self.device, share_params_from=keep)
             eng.eps_source = self.eps_source
+            eng.sync_group = self.dp_group
             if reset_optimizer:
                 eng.reset_optimizer_state()
             self._root = eng
             self._engines[(keep.B, keep.with_class)] = eng
         self._generation += 1
+
+    def set_precision(self, precision):
+        """"f32": the reference's arithmetic (fp32 MFMA, the parity path).  "bf16": BASELINE config 2's reduced-precision mode —
+        conv / weight-gradient operands in bfloat16 on v_mfma_f32_32x32x16_bf16, fp32 accumulation, statistics, master weights
+        and AdamW (planner.TrainCfg.mfma_dtype; tolerance: tests/test_gpu_bf16.py).  Trainer(precision="bf16") calls this."""
+        if precision not in ("f32", "bf16"):
+            raise ValueError(f"precision must be 'f32' or 'bf16', not {precision!r}")
+        if precision != self.precision:
+            self.precision = precision
+            self.configure_training(self._train_cfg)
+
+    def set_parallel(self, world, group=None, sync_batchnorm=False):
+        """Data-parallel replicas of this network (one process per GPU, Lightning-DDP semantics): `_Loss.backward()` then
+        mean-all-reduces the gradient arena over `group` before optimizer.step(); sync_batchnorm=True re-lowers with
+        sync-BatchNorm markers (torch.nn.SyncBatchNorm semantics, Lightning's sync_batchnorm=True)."""
+        world = int(world)
+        changed = (bool(sync_batchnorm) and world > 1) != (self._train_cfg.sync_bn_world > 1) or \
+                  (bool(sync_batchnorm) and world > 1 and self._train_cfg.sync_bn_world != world)
+        self.dp_world, self.dp_group, self.sync_batchnorm = world, group, bool(sync_batchnorm)
+        if changed:
+            self.configure_training(self._train_cfg)
+        for eng in self._engines.values():
+            eng.sync_group = group
+
+    def broadcast_from_rank0(self):
+        """DDP start-up: parameters, BatchNorm buffers and optimiser state of every replica := rank 0's."""
+        from . import parallel
+        eng = self._any_engine()
+        parallel.broadcast_([eng.params, eng.bufs, eng.m, eng.v], 0, self.dp_group)
+        nbt = torch.tensor([eng.num_batches_tracked[k] for k in eng.plan.bn_keys], dtype=torch.int64, device=eng.device)
+        parallel.broadcast_([nbt], 0, self.dp_group)
+        for k, v in zip(eng.plan.bn_keys, nbt.tolist()):
+            eng.num_batches_tracked[k] = int(v)
 
     def set_eps_source(self, fn):
         """Prescribe the reparameterisation noise of this network's forwards (None = torch's device generator)."""
@@ -326,8 +368,9 @@ class MultiModalCVAE(_Net):
 class _Loss:
     """What training_step returns: a scalar handle with .item() / .backward() / float()."""
 
-    def __init__(self, eng: Engine, slot=0, use_graph=True):
+    def __init__(self, eng: Engine, slot=0, use_graph=True, dp_world=1, dp_group=None):
         self.eng, self.slot, self.use_graph = eng, slot, use_graph
+        self.dp_world, self.dp_group = dp_world, dp_group
         self._backward_done = False
         self.value = eng.io("scalars")[slot].clone()      # device scalar of THIS step (the slot is overwritten by the next one)
 
@@ -342,6 +385,11 @@ class _Loss:
     def backward(self):
         if not self._backward_done:
             self.eng.backward(self.use_graph)
+            if self.dp_world > 1:
+                # DDP: gradient MEAN over the replicas between backward and optimizer.step (Lightning's default strategy on a
+                # multi-GPU host, scripts/train_model_with_multimodal.py:200-207); RCCL over xGMI when the backend is "nccl"
+                from . import parallel
+                parallel.allreduce_mean_(self.eng.grads[: self.eng.plan.n_active], self.dp_group)
             self._backward_done = True
 
 
@@ -499,7 +547,7 @@ class hippieUnimodalEmbeddingModelCVAE(_TrainModule):
         self.log(prefix + "_loss", sc[0])
         self.log(prefix + "_mse_loss", sc[1])
         self.log(prefix + "_kl_loss", sc[3])
-        loss = _Loss(eng, use_graph=self.model.use_graph)
+        loss = _Loss(eng, use_graph=self.model.use_graph, dp_world=self.model.dp_world, dp_group=self.model.dp_group)
         self._record(store, loss)                 # loss.item() in the reference: one host sync per step
         self.optimizer.last_engine = eng
         return loss
@@ -543,7 +591,7 @@ class MultiModalCVAETrainModule(_TrainModule):
         self.log(prefix + "_mse_loss1", sc[1])
         self.log(prefix + "_mse_loss2", sc[2])
         self.log(prefix + "_kl_loss", sc[3])
-        loss = _Loss(eng, use_graph=self.model.use_graph)
+        loss = _Loss(eng, use_graph=self.model.use_graph, dp_world=self.model.dp_world, dp_group=self.model.dp_group)
         self._record(store, loss)
         self.optimizer.last_engine = eng
         return loss

@@ -147,7 +147,11 @@ LIB_PATH = debug_knob("HIPPIE_HIP_LIB") or os.path.join(os.path.dirname(os.path.
 
 EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",
            "hp_program_validate", "hp_program_run", "hp_program_capture", "hp_program_replay", "hp_program_profile",
-           "hp_run_op")
+           "hp_run_op",
+           "hp_model_load", "hp_model_destroy", "hp_model_config", "hp_model_tensor_count", "hp_model_tensor_info", "hp_model_find",
+           "hp_model_arena", "hp_model_program", "hp_model_segment", "hp_model_run", "hp_model_forward", "hp_model_backward",
+           "hp_model_optimizer_step", "hp_model_train_step", "hp_model_batches_tracked", "hp_model_write", "hp_model_read",
+           "hp_model_synchronize")
 
 
 class HipEngineError(RuntimeError):
@@ -181,6 +185,27 @@ def load_library():
     lib.hp_program_replay.argtypes = [vp, ctypes.c_int, vp]
     lib.hp_program_profile.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(ctypes.c_float)]
     lib.hp_run_op.argtypes = [vp, ctypes.POINTER(vp), vp]
+    cp, i64 = ctypes.c_char_p, ctypes.c_int64
+    lib.hp_model_load.argtypes = [cp, ctypes.c_int, ctypes.POINTER(vp)]
+    lib.hp_model_destroy.argtypes = [vp]
+    lib.hp_model_config.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
+    lib.hp_model_tensor_count.argtypes = [vp, ctypes.c_int]
+    lib.hp_model_tensor_info.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    lib.hp_model_find.argtypes = [vp, cp, vp]
+    lib.hp_model_arena.argtypes = [vp, ctypes.c_int, ctypes.POINTER(i64)]
+    lib.hp_model_arena.restype = vp
+    lib.hp_model_program.argtypes = [vp]
+    lib.hp_model_program.restype = vp
+    lib.hp_model_segment.argtypes = [vp, cp, ip, ip]
+    lib.hp_model_run.argtypes = [vp, cp, ctypes.c_int, vp]
+    lib.hp_model_forward.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
+    for fn in (lib.hp_model_backward, lib.hp_model_optimizer_step, lib.hp_model_train_step):
+        fn.argtypes = [vp, ctypes.c_int, vp]
+    lib.hp_model_batches_tracked.argtypes = [vp]
+    lib.hp_model_batches_tracked.restype = i64
+    lib.hp_model_write.argtypes = [vp, cp, vp, i64, ctypes.c_int, vp]
+    lib.hp_model_read.argtypes = [vp, cp, vp, i64, ctypes.c_int, vp]
+    lib.hp_model_synchronize.argtypes = [vp, vp]
     if lib.hp_abi_version() != ABI_VERSION:
         raise HipEngineError("libhippie_hip.so ABI version mismatch")
     _LIB = lib

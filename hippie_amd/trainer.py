@@ -2,7 +2,14 @@
 reference's scripts rely on (scripts/train_model_with_multimodal.py:186-230): automatic optimisation
 (training_step -> backward -> [clip] -> optimizer.step), two sanity validation batches, a validation
 pass per epoch, top-1 `val_loss` checkpointing (ModelCheckpoint(monitor="val_loss", mode="min")),
-EarlyStopping(patience), and `.ckpt` files holding {"state_dict", "optimizer_states", "epoch"}."""
+EarlyStopping(patience), and `.ckpt` files holding {"state_dict", "optimizer_states", "epoch"}.
+
+Data parallel.  The reference passes no `devices` / `strategy` (scripts/...:200-207), so on a multi-GPU host Lightning
+picks DDP by itself: one process per GPU, every DataLoader's sampler replaced by a DistributedSampler (per-rank batches
+of `batch_size`), parameters broadcast from rank 0, gradients mean-all-reduced between backward and optimizer.step,
+BatchNorm statistics local unless `sync_batchnorm=True`, checkpoints and logs written by rank 0.  `Trainer(strategy=
+"ddp")` — or simply running under an initialised torch.distributed with more than one rank (torchrun) — gives the same
+here, with RCCL ("nccl") as the collective backend; precision="bf16" (`bf16-mixed`) selects the bf16-MFMA lowering."""
 from __future__ import annotations
 
 import json
@@ -15,7 +22,8 @@ import torch
 class Trainer:
     def __init__(self, max_epochs=1, gradient_clip_val=None, default_root_dir="checkpoints", patience=30,
                  monitor="val_loss", logger_path=None, num_sanity_val_steps=2, device=None, enable_checkpointing=True,
-                 sync_every_step=False, deterministic=False):
+                 sync_every_step=False, deterministic=False, strategy="auto", devices="auto", sync_batchnorm=False,
+                 precision="32", process_group=None, seed=0):
         """sync_every_step: True reproduces the reference's per-step `loss.item()` host sync (hippie/model.py:114) and
         checks labels on the host every step; False (default) keeps the step asynchronous — hipGraph replays, per-step
         losses kept on the device and averaged at the epoch end, label range errors raised at the epoch end."""
@@ -30,20 +38,65 @@ class Trainer:
         self.best_model_path, self.best_score = "", float("inf")
         self.current_epoch, self.global_step = 0, 0
         self.history = []
+        # ---- data parallel (Lightning's DDP strategy) ----
+        if strategy not in ("auto", "ddp", None, "single_device"):
+            raise ValueError(f"strategy {strategy!r}: only 'auto', 'ddp' and 'single_device' exist here (the model is 8 M parameters: nothing to shard but the batch)")
+        if str(precision) not in ("32", "32-true", "bf16", "bf16-mixed"):
+            raise ValueError(f"precision {precision!r}: '32' (the reference's arithmetic) or 'bf16' / 'bf16-mixed'")
+        self.precision = "bf16" if str(precision).startswith("bf16") else "f32"
+        self.strategy, self.devices, self.sync_batchnorm = strategy, devices, sync_batchnorm
+        self.process_group, self.seed = process_group, seed
+        self.world_size, self.global_rank = 1, 0
+
+    # ---- data parallel plumbing ---------------------------------------------------------------------------------------
+    def _setup_distributed(self):
+        """world size / rank of this fit: >1 only when torch.distributed is initialised with more than one rank (the
+        launcher's job — torchrun, or bench.py's own spawn: one process per GPU) and the strategy allows it."""
+        import torch.distributed as dist
+        self.world_size, self.global_rank = 1, 0
+        if self.strategy in ("single_device", None) or not (dist.is_available() and dist.is_initialized()):
+            if self.strategy == "ddp" and not isinstance(self.devices, str) and int(self.devices) > 1:
+                raise RuntimeError("Trainer(strategy='ddp', devices>1): start one process per GPU (torchrun / "
+                                   "torch.distributed.run) and initialise torch.distributed first; this Trainer does not fork")
+            return
+        self.world_size = dist.get_world_size(self.process_group)
+        self.global_rank = dist.get_rank(self.process_group)
+
+    @property
+    def is_global_zero(self):
+        return self.global_rank == 0
+
+    def _shard(self, loader, epoch, shuffle_seed_offset=0):
+        """Lightning replaces a DataLoader's sampler by DistributedSampler under DDP.  Loaders that can re-shard
+        themselves (`.shard(rank, world, epoch, seed)`, e.g. scripts/pretrain_pipeline.py's HBM-table loaders) do;
+        any other iterable is passed through unchanged (every rank then sees all of it — also Lightning's behaviour for
+        iterables it cannot wrap)."""
+        if self.world_size > 1 and hasattr(loader, "shard"):
+            return loader.shard(self.global_rank, self.world_size, epoch, self.seed + shuffle_seed_offset)
+        return loader
+
+    def _reduce_mean(self, value, device):
+        """mean over ranks of a host scalar (val_loss: every rank must take the same checkpoint / early-stop decision)"""
+        if self.world_size == 1:
+            return value
+        import torch.distributed as dist
+        t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend(self.process_group) == "nccl" else "cpu")
+        dist.all_reduce(t, group=self.process_group)
+        return float(t.item()) / self.world_size
 
     def _to_device(self, batch, device):
         return tuple(t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
 
     def _log(self, rec):
         self.history.append(rec)
-        if self.logger_path:
+        if self.logger_path and self.is_global_zero:
             with open(self.logger_path, "a") as f:
                 f.write(json.dumps(rec) + "\n")
 
     def validate(self, module, loader, limit=None):
         module.eval()
         losses = []
-        for i, batch in enumerate(loader):
+        for i, batch in enumerate(self._shard(loader, 0)):
             if limit is not None and i >= limit:
                 break
             loss = module.validation_step(self._to_device(batch, self._dev(module)), i)
@@ -51,7 +104,8 @@ class Trainer:
         module.on_validation_epoch_end()
         module.model.check_deferred_errors()
         module.train()
-        return float(torch.stack(losses).double().mean()) if losses else 0.0
+        val = float(torch.stack(losses).double().mean()) if losses else 0.0
+        return self._reduce_mean(val, self._dev(module))
 
     def _dev(self, module):
         if self.device is not None:
@@ -59,17 +113,24 @@ class Trainer:
         return module.model._any_engine().device
 
     def save_checkpoint(self, module, path):
-        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-        torch.save({"state_dict": {k: v.cpu() for k, v in module.state_dict().items()},
-                    "optimizer_states": [module.optimizer.state_dict()],
-                    "epoch": self.current_epoch, "global_step": self.global_step}, path)
+        if self.is_global_zero:              # replicas are identical: rank 0 writes (its BatchNorm running statistics, as Lightning does)
+            os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+            torch.save({"state_dict": {k: v.cpu() for k, v in module.state_dict().items()},
+                        "optimizer_states": [module.optimizer.state_dict()],
+                        "epoch": self.current_epoch, "global_step": self.global_step}, path)
+        if self.world_size > 1:              # the other ranks may load the file right after fit()
+            import torch.distributed as dist
+            dist.barrier(group=self.process_group)
 
     def fit(self, module, train_dataloaders, val_dataloaders=None):
         module.trainer = self
+        self._setup_distributed()
         if self.deterministic and not module.model.deterministic:
             module.model.deterministic = True
             module._apply_cfg()
         module.set_gradient_clip(self.gradient_clip_val)
+        module.model.set_parallel(self.world_size, self.process_group, self.sync_batchnorm)
+        module.model.set_precision(self.precision)
         # The asynchronous mode (device-side label flag, per-step losses kept on the device) is a property of THIS loop,
         # which raises the deferred errors at every epoch end.  Outside it — `model(...)`, `get_embeddings` after fit() —
         # nobody would, so both settings are restored on the way out: labels are range-checked on the host again
@@ -81,10 +142,13 @@ class Trainer:
             return self._fit(module, train_dataloaders, val_dataloaders)
         finally:
             module.sync_every_step, module.model.label_check = saved
+            module.model.set_parallel(1, None, False)      # user-level calls after fit() are single-process again
             module.model.check_deferred_errors()
 
     def _fit(self, module, train_dataloaders, val_dataloaders):
         dev = self._dev(module)
+        if self.world_size > 1:
+            module.model.broadcast_from_rank0()            # DDP: every replica starts from rank 0's parameters / buffers / optimiser state
         if val_dataloaders is not None and self.num_sanity_val_steps:
             self.validate(module, val_dataloaders, self.num_sanity_val_steps)
         bad_epochs = 0
@@ -93,7 +157,7 @@ class Trainer:
             module.train()
             t0 = time.perf_counter()
             n = 0
-            for i, batch in enumerate(train_dataloaders):
+            for i, batch in enumerate(self._shard(train_dataloaders, epoch)):
                 batch = self._to_device(batch, dev)
                 module.optimizer.zero_grad()
                 loss = module.training_step(batch, i)
@@ -105,7 +169,7 @@ class Trainer:
             dt = time.perf_counter() - t0
             module.model.check_deferred_errors()
             module.on_train_epoch_end()
-            rec = {"epoch": epoch, "train_samples_per_s": n / dt}
+            rec = {"epoch": epoch, "train_samples_per_s": n * self.world_size / dt, "world_size": self.world_size}
             rec.update({k: float(v) for k, v in module.logged.items() if k.startswith("train")})
             if val_dataloaders is not None:
                 val = self.validate(module, val_dataloaders)

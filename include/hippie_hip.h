@@ -320,6 +320,64 @@ int hp_program_profile(HpProgram* p, int first, int count, void* stream, float* 
 /* Single-op launch without a program (unit tests, benchmarks). */
 int hp_run_op(const HpOp* op, void* const bases[HP_NUM_SPACES], void* stream);
 
+/* ---- serialised models: the level a host WITHOUT Python binds ----------------------------------------------------
+ * hp_program_* above executes op records somebody lowered.  The lowering itself (hippie_amd/planner.py) stands for
+ * constructing the reference's nn.Module graph — hippieUnimodalCVAE.__init__ / MultiModalCVAE.__init__
+ * (hippie/model.py:13-44,352-395) over ResNet18Enc / ResNet18Dec (hippie/backbones.py:74-126) — and is done ONCE per
+ * (model configuration, batch size):  `python -m hippie_amd.export ... -o model.hpm`  writes the records, the named
+ * segments, the six arena sizes, a table of every parameter / BatchNorm buffer under its reference state_dict key
+ * (shape, arena offset, layout) and of every named I/O slot, and optionally initial values.  hp_model_load reads such a
+ * file, allocates the arenas ITSELF (hipMalloc, freed by hp_model_destroy: nothing is handed to the caller to free),
+ * uploads the initial values and validates the program; the verbs below are what Lightning's automatic optimisation
+ * calls around training_step (hippie/model.py:95-116): forward, backward, optimizer.step.
+ *
+ * I/O slots (hp_model_write / hp_model_read by name):  "x" float[B][1][L] (multimodal: + "x2"), "src" / "cls" int64[B]
+ * (source / class labels), "eps" float[B][z] (reparameterisation noise, model.py:46-49), "scalars" float[4] =
+ * (loss, mse1, mse2, kl_mean) of the last forward, "enc_train" / "enc_eval" float[B][z] (the embedding), "mulv_*"
+ * float[B][2z] = (mu | logvar), "rec_*" / "rec2_*" reconstructions, "adam_step" int64[1].  Parameters are addressed by
+ * their reference keys ("encoder.conv1.weight", ...); layout 1 = conv weight stored tap-major [k][Cout][Cin].
+ * Segments: "fwd_train", "bwd", "opt", "step" (= the three, one graph), "fwd_eval", "enc_eval" (encoder half only). */
+typedef struct HpModel HpModel;
+typedef struct HpTensorInfo {
+  char name[112];           /* reference state_dict key, or I/O slot name */
+  int32_t space;            /* HP_SPACE_* */
+  int32_t layout;           /* 0 = as `shape` says; 1 = conv weight [Cout][Cin][k] stored as [k][Cout][Cin] */
+  int64_t offset_bytes;     /* into the arena */
+  int64_t numel;
+  int32_t ndim;
+  int32_t shape[4];
+  int32_t dtype;            /* 0 float32, 1 int64, 2 float64 */
+} HpTensorInfo;
+#define HP_MODEL_NO_DEVICE 1   /* hp_model_load flag: parse + validate only (no GPU, no allocation) */
+
+int hp_model_load(const char* path, int flags, HpModel** out);
+int hp_model_destroy(HpModel* m);
+/* out[0..9] = kind (0 unimodal, 1 multimodal), z_dim, output_size, output_size2, class_hidden_dim, num_sources, num_classes,
+ * batch, with_class, number of floats AdamW updates. */
+int hp_model_config(const HpModel* m, int32_t out[16]);
+/* which: 0 parameters, 1 BatchNorm buffers, 2 I/O slots.  hp_model_find searches slots, then buffers, then parameters. */
+int hp_model_tensor_count(const HpModel* m, int which);
+int hp_model_tensor_info(const HpModel* m, int which, int index, HpTensorInfo* out);
+int hp_model_find(const HpModel* m, const char* name, HpTensorInfo* out);
+/* Device base pointer and size of one arena (NULL under HP_MODEL_NO_DEVICE); owned by the model. */
+void* hp_model_arena(const HpModel* m, int space, int64_t* nbytes);
+HpProgram* hp_model_program(HpModel* m);
+int hp_model_segment(const HpModel* m, const char* name, int* first, int* count);
+/* Run a named segment on `stream`; use_graph != 0: captured into a hipGraph on first use, replayed afterwards. */
+int hp_model_run(HpModel* m, const char* segment, int use_graph, void* stream);
+/* The reference's verbs: model(batch) in train / eval mode; loss.backward(); optimizer.step(); all three. */
+int hp_model_forward(HpModel* m, int training, int use_graph, void* stream);
+int hp_model_backward(HpModel* m, int use_graph, void* stream);
+int hp_model_optimizer_step(HpModel* m, int use_graph, void* stream);
+int hp_model_train_step(HpModel* m, int use_graph, void* stream);
+/* BatchNorm num_batches_tracked (training forwards so far; the reference keeps it as an int64 buffer per layer). */
+int64_t hp_model_batches_tracked(const HpModel* m);
+/* Copy nbytes (must equal the tensor's size) into / out of a named tensor, stream-ordered; a host destination is
+ * complete when hp_model_read returns, a host SOURCE must stay valid until the stream has passed the copy. */
+int hp_model_write(HpModel* m, const char* name, const void* src, int64_t nbytes, int src_on_device, void* stream);
+int hp_model_read(HpModel* m, const char* name, void* dst, int64_t nbytes, int dst_on_device, void* stream);
+int hp_model_synchronize(HpModel* m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,12 @@ def build_parser():
     p.add_argument("--output-dir", type=str, default=".")
     p.add_argument("--supervised", action="store_true", help="run the supervised fine-tune + kNN stage (:349-616)")
     p.add_argument("--label-column", type=str, default="label", help='column of labels.csv (the reference reads "label")')
+    p.add_argument("--precision", type=str, default="32", choices=["32", "bf16"],
+                   help="Trainer(precision=...): 32 = the reference's fp32 arithmetic; bf16 = BASELINE config 2's reduced-precision mode "
+                        "(bf16 MFMA operands, fp32 accumulation / statistics / master weights)")
+    p.add_argument("--strategy", type=str, default="auto", choices=["auto", "ddp", "single_device"],
+                   help="as pl.Trainer(strategy=...): under torchrun with more than one rank 'auto' and 'ddp' train data-parallel")
+    p.add_argument("--sync-batchnorm", action="store_true", help="pl.Trainer(sync_batchnorm=True)")
     return p
 
 
@@ -104,16 +110,29 @@ class _Concat:
         """DataLoader(Subset(ConcatDataset, indices), batch_size, shuffle) of the reference (:155-166), with torch's own
         DataLoader producing the INDEX batches — so the global generator is consumed exactly as there (one base-seed
         draw per iterator, one more by RandomSampler when shuffling) — and the rows gathered from the HBM tables."""
-        index_loader = torch.utils.data.DataLoader(list(indices), batch_size=batch_size, shuffle=shuffle)
+        indices = list(indices)
+        index_loader = torch.utils.data.DataLoader(indices, batch_size=batch_size, shuffle=shuffle)
+        table = self
 
         class _L:
             def __iter__(s):
                 for j in index_loader:
-                    j = j.to(self.data.device)
-                    yield self.data.index_select(0, j).unsqueeze(1), self.labels.index_select(0, j)
+                    j = j.to(table.data.device)
+                    yield table.data.index_select(0, j).unsqueeze(1), table.labels.index_select(0, j)
 
             def __len__(s):
                 return len(index_loader)
+
+            def shard(s, rank, world, epoch, seed=0):
+                """What Lightning's DDP strategy does to this DataLoader: its sampler becomes DistributedSampler(dataset,
+                shuffle=<as given>, seed) with set_epoch(epoch) — a seeded permutation padded to a multiple of `world`,
+                rank r taking positions r::world — and batch_size stays PER RANK (hippie_amd.parallel.shard_indices)."""
+                from hippie_amd.parallel import shard_indices
+                pos = shard_indices(len(indices), rank, world, epoch=epoch, seed=seed, shuffle=shuffle)
+                mine = torch.as_tensor(indices, dtype=torch.int64)[pos].to(table.data.device)
+                for i in range(0, len(mine), batch_size):
+                    j = mine[i: i + batch_size]
+                    yield table.data.index_select(0, j).unsqueeze(1), table.labels.index_select(0, j)
         return _L()
 
 
@@ -125,6 +144,15 @@ def main(argv=None, eps_source=None):
         raise SystemExit("the reference's multimodal script branch builds EphysDatasetLabeled(mode='both'), which its own "
                          "dataset class rejects (dataloading.py:67); only the unimodal pipeline is reproduced")
     os.makedirs(args.output_dir, exist_ok=True)
+    # under a launcher (torchrun: one process per GPU) this is a DDP run, as Lightning would make it (scripts/...:200-207):
+    # RCCL ("nccl") over xGMI, rank r on GPU LOCAL_RANK; rank 0 writes checkpoints, logs and CSVs
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and args.strategy != "single_device" and not dist.is_initialized():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(os.environ.get("HIPPIE_DIST_BACKEND", "nccl"))
+    rank0 = not dist.is_initialized() or dist.get_rank() == 0
     torch.manual_seed(42)
     num_sources = max(DATASET_FILES.values()) + 1
     wave_parts, time_parts = [], []
@@ -145,7 +173,8 @@ def main(argv=None, eps_source=None):
     def fit(kind, module, train_loader, val_loader, epochs, clip, tag):
         tr = Trainer(max_epochs=epochs, gradient_clip_val=clip, patience=args.early_stopping_patience,
                      default_root_dir=os.path.join(args.output_dir, "checkpoints", f"{kind}_{tag}"),
-                     logger_path=os.path.join(args.output_dir, f"{kind}_{tag}_log.jsonl"))
+                     logger_path=os.path.join(args.output_dir, f"{kind}_{tag}_log.jsonl"),
+                     precision=args.precision, strategy=args.strategy, sync_batchnorm=args.sync_batchnorm)
         tr.fit(module, train_loader, val_loader)
         return tr
 
@@ -186,10 +215,12 @@ def main(argv=None, eps_source=None):
     paths = {}
     for name, emb in (("waveform", ew), ("isi", et), ("joint", joint)):
         path = os.path.join(args.output_dir, f"pretraining_{args.dataset}_{name}_embeddings.csv")
-        pd.DataFrame({"embeddings": list(emb)}).to_csv(path)
+        if rank0:
+            pd.DataFrame({"embeddings": list(emb)}).to_csv(path)
         paths[name] = path
-    with open(os.path.join(args.output_dir, "run_config.json"), "w") as f:
-        json.dump(vars(args), f)
+    if rank0:
+        with open(os.path.join(args.output_dir, "run_config.json"), "w") as f:
+            json.dump(vars(args), f)
     if args.supervised:
         paths.update(supervised_stage(args, num_sources, trw.best_model_path, trt.best_model_path, fit, eps_source))
     return paths

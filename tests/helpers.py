@@ -91,6 +91,7 @@ def assert_adam_close(actual, desired, lr, msg="", grad=None, steps=1, frac=2e-3
         assert not bad.any(), f"{msg}: {bad.sum()} of {bad.size} elements with significant gradient differ"
     else:
         assert bad.mean() <= frac, f"{msg}: {bad.sum()} of {bad.size} elements off by more than noise"
+    return float(bad.mean())
 
 
 def relerr(a, b):
@@ -151,18 +152,28 @@ def engine_pre_activations(eng):
     return pre_activations(eng.plan, eng.ops, lambda off, n: eng.ws[off: off + 4 * n].view(torch.float32).cpu().numpy(), eng.B)
 
 
-FLIP_BUDGET = 1e-5          # leaky-ReLU inputs whose sign may differ from the free-running float64 oracle's, as a fraction of all of them
+# leaky-ReLU inputs whose sign may differ from the free-running float64 oracle's, as a fraction of all of them.  Measured on
+# MI355X (profiles/r03_flip_budget.txt): 0.7-0.9e-6 at batch 512 (22 / 38 / 69 of 32 / 46 / 78 M), 0-4 per case at batch 8-16
+# — the same rate as torch-float32 on the same inputs (profiles/r03_flips_*_B512.txt): what float32 conv accumulation leaves
+# undecided.  Budget: 3e-6 (and never fewer than 4 elements), i.e. ~3.5x the measured rate.
+FLIP_BUDGET = 3e-6
+FLIP_FLOOR = 4
+FLIP_MAG = 2e-5             # |pre| of an element whose sign differs, relative to its tensor's max (measured <= 2e-6)
 
 
-def assert_flip_budget(pres, taps32, taps64, tag, budget=FLIP_BUDGET, rel=1e-4):
+def flip_allowance(total, budget=FLIP_BUDGET):
+    return max(FLIP_FLOOR, int(np.ceil(budget * total)))
+
+
+def assert_flip_budget(pres, taps32, taps64, tag, budget=FLIP_BUDGET, rel=1e-4, mag_rel=FLIP_MAG):
     """The UNMASKED anchor of the gradient tests.  `pres` = the implementation's leaky-ReLU inputs (pre_activations),
     taps32 / taps64 = the free-running float32 / float64 oracle's taps (Ctx.lrelu records `site#pre`).  Asserts
       1. every site's input tensor meets the parity criterion against the free-running float64 oracle (1e-4 of the
          tensor's max, or 3x the float32 reference path's own error): an implementation that took the wrong branch on
          clearly non-zero values upstream cannot pass, whatever masks the gradient comparison later injects;
-      2. the signs differ on at most `budget` of all elements (1e-5: ~10x what float32 rounding produces here);
-      3. every element whose sign differs is unresolvable at the parity bar: |pre64| <= rel * max|pre64| of its tensor
-         (implied by 1; asserted on its own so that the failure names the element).
+      2. the signs differ on at most `budget` of all elements (3e-6: ~3.5x what float32 rounding produces here);
+      3. every element whose sign differs is unresolvable in float32: |pre64| <= mag_rel * max|pre64| of its tensor
+         (2e-5: ten times the largest one measured; far inside the parity bar of 1).
     Returns (flips, elements, worst |pre64| / max|pre64| over the flipped elements)."""
     flips = total = 0
     worst = 0.0
@@ -177,9 +188,9 @@ def assert_flip_budget(pres, taps32, taps64, tag, budget=FLIP_BUDGET, rel=1e-4):
             flips += int(diff.sum())
             mag = np.abs(ref64[diff]).max() / np.abs(ref64).max()
             e32 = relerr(ref32, ref64)
-            assert mag <= max(rel, 3.0 * e32), f"{tag} {key}: an element with |pre| = {mag:.2e} of the tensor's max changed sign"
+            assert mag <= max(mag_rel, 3.0 * e32), f"{tag} {key}: an element with |pre| = {mag:.2e} of the tensor's max changed sign"
             worst = max(worst, mag)
-    allowed = int(np.ceil(budget * total))
+    allowed = flip_allowance(total, budget)
     assert flips <= allowed, f"{tag}: {flips} leaky-ReLU sign differences over {total} elements (budget {allowed})"
     return flips, total, worst
 

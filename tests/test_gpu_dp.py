@@ -169,3 +169,192 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and not r.stdout.strip()
+
+
+# ---- DDP through the class surface: Trainer(strategy="ddp") -----------------------------------------------------------
+class _ShardableLoader:
+    """The protocol Trainer._shard looks for (scripts/pretrain_pipeline.py's loaders implement it): DistributedSampler
+    semantics, per-rank batches of `batch`."""
+
+    def __init__(self, x, labels, batch):
+        self.x, self.labels, self.batch = x, labels, batch
+
+    def __iter__(self):
+        for i in range(0, len(self.x), self.batch):
+            yield self.x[i: i + self.batch], self.labels[i: i + self.batch]
+
+    def shard(self, rank, world, epoch, seed=0):
+        from hippie_amd.parallel import shard_indices
+        idx = shard_indices(len(self.x), rank, world, epoch=epoch, seed=seed)
+        for i in range(0, len(idx), self.batch):
+            j = idx[i: i + self.batch]
+            yield self.x[j], self.labels[j]
+
+
+def _eps_of(x, z):
+    """reparameterisation noise as a fixed function of the batch itself: the oracle in the parent process reproduces it"""
+    return torch.sin(997.0 * x.reshape(x.shape[0], -1)[:, :z].float().cpu()) * 1.3
+
+
+def _ddp_trainer_worker(rank, world, port, q, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
+    from hippie_amd.trainer import Trainer
+    from oracle import cvae_oracle as O
+    z, L, B, n = 10, 50, 8, 32
+    torch.manual_seed(100 + rank)                       # different initial weights per rank: the start-up broadcast must fix it
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    if rank == 0:
+        sd0 = {k: v.clone() for k, v in net._pending_sd.items()}
+    net.set_eps_source(lambda eng: _eps_of(eng.io("x"), z).to(eng.device))
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-5, weight_decay=0.01)
+    x, src, cls, _ = O.synth_inputs(n, L, z, salt=21)
+    loader = _ShardableLoader(x, src, B)
+    val = _ShardableLoader(x[:16], src[:16], B)
+    tr = Trainer(max_epochs=2, gradient_clip_val=1.0, strategy="ddp", default_root_dir=os.path.join(tmp, "ckpt"),
+                 logger_path=os.path.join(tmp, "log.jsonl"), num_sanity_val_steps=0, seed=3)
+    tr.fit(mod, loader, val)
+    assert tr.world_size == world and net.dp_world == 1          # restored after fit
+    eng = net._any_engine()
+    exists = os.path.exists(tr.best_model_path)
+    ck = torch.load(tr.best_model_path, weights_only=False) if exists else None
+    q.put((rank, eng.params.double().sum().item(), eng.params.double().abs().sum().item(), eng.adam_step, tr.best_model_path, exists,
+           {k: v.cpu() for k, v in net.state_dict().items()} if rank == 0 else None, sd0 if rank == 0 else None,
+           sorted(ck.keys()) if ck else None, [h["val_loss"] for h in tr.history]))
+    dist.destroy_process_group()
+
+
+def test_trainer_ddp_two_ranks_equals_two_single_rank_oracles(tmp_path):
+    """Trainer(strategy="ddp") under a 2-rank process group (gloo moving CUDA tensors; both ranks on the one GPU): start-up
+    broadcast, DistributedSampler sharding, per-rank BatchNorm statistics, gradient MEAN between loss.backward() and
+    optimizer.step(), rank-0 checkpoint that every rank can load — against two float64 oracles that each take their rank's
+    shard, average their gradients and apply the same AdamW step (what Lightning-DDP does to the reference's module)."""
+    import re
+    from hippie_amd.parallel import shard_indices
+    from oracle import cvae_oracle as O
+    from tests import helpers as H
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_trainer_worker, args=(r, world, port, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+    r0, r1 = res
+    assert r0[1] == r1[1] and r0[2] == r1[2], "replicas diverged"
+    z, L, B, n, lr = 10, 50, 8, 32, 1e-5
+    steps = 2 * (n // world // B)
+    assert r0[3] == r1[3] == steps
+    assert r0[4] == r1[4] and r0[5] and r1[5], "every rank must be able to load rank 0's checkpoint"
+    assert r0[8] == ["epoch", "global_step", "optimizer_states", "state_dict"]
+    assert r0[9] == r1[9], "ranks disagree on the monitored val_loss (checkpoint / early-stop decisions would diverge)"
+    assert len([f for f in os.listdir(tmp_path / "ckpt")]) >= 1 and os.path.exists(tmp_path / "log.jsonl")
+    # ---- two float64 oracles, one per rank, gradients averaged
+    x, src, cls, _ = O.synth_inputs(n, L, z, salt=21)
+    oms = [O.OracleModel("unimodal", z, L, dtype=torch.float64) for _ in range(world)]
+    for om in oms:
+        om.load({k: v for k, v in r0[7].items()})           # rank 0's constructor initialisation, broadcast to all
+    for epoch in range(2):
+        shards = [shard_indices(n, r, world, epoch=epoch, seed=3) for r in range(world)]
+        for i in range(0, n // world, B):
+            grads = []
+            for r, om in enumerate(oms):
+                j = shards[r][i: i + B]
+                xb = x[j]
+                for k in om.param_keys:
+                    om.state[k].grad = None
+                outs = om.forward((xb.double(), src[j], None), _eps_of(xb, z).double(), True)
+                om.losses((xb.double(), src[j], None), outs, 1.0)[0].backward()
+                grads.append(om.grads())
+            with torch.no_grad():
+                mean = {k: (None if grads[0][k] is None else (grads[0][k] + grads[1][k]) / 2) for k in grads[0]}
+                for om in oms:
+                    g = {k: (None if v is None else v.clone()) for k, v in mean.items()}
+                    O.clip_grad_norm(list(g.values()), 1.0)
+                    for k in om.param_keys:
+                        if g[k] is not None and k not in om.exp_avg:
+                            om.exp_avg[k] = torch.zeros_like(om.state[k])
+                            om.exp_avg_sq[k] = torch.zeros_like(om.state[k])
+                    om.step_count += 1
+                    O.adamw_step({k: om.state[k] for k in om.param_keys}, g, om.exp_avg, om.exp_avg_sq, om.step_count, lr, 0.01)
+    sd = r0[6]
+    for k in oms[0].param_keys:
+        if mean[k] is None:
+            continue
+        a, b = sd[k].numpy().astype(np.float64).reshape(-1), oms[0].state[k].detach().numpy().reshape(-1)
+        assert np.abs(a - b).max() <= 2.2 * lr * steps + 1e-7, k
+        if re.search(H.ZERO_GRAD_RE, k):
+            continue
+        gk = np.abs(mean[k].numpy().reshape(-1))
+        bad = (np.abs(a - b) > 1e-4 * np.abs(b) + 0.02 * lr) & (gk > 1e-2 * gk.max())
+        assert bad.mean() <= 2e-3, f"{k}: {bad.sum()} of {bad.size} elements with significant gradient differ"
+    for k, v in sd.items():          # rank 0's BatchNorm running statistics are the ones checkpointed: they follow rank 0's shards
+        if "running_" in k:
+            H.assert_close(v.numpy(), oms[0].state[k].detach().numpy(), 1e-4, k)
+
+
+# ---- the RCCL ("nccl") backend inside the suite: world size 1 -------------------------------------------------------------
+def _rccl_worker(port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HIPPIE_FORCE_DIST="1", GPU_MAX_HW_QUEUES="8")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from hippie_amd import parallel, planner
+    from hippie_amd.engine import Engine
+    from oracle import cvae_oracle as O
+    z, B, steps = 10, 32, 3
+    out = {}
+    for name, use_dp in (("plain", False), ("rccl", True)):
+        engs, streams = [], []
+        for k, (L, clip) in enumerate(((50, 0.0), (100, 1.0))):
+            e = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=clip, deterministic_wgrad=True))
+            om = O.OracleModel("unimodal", z, L, salt=30 + k)
+            e.load_state_dict({kk: v.detach() for kk, v in om.state.items()})
+            x, src, cls, eps = O.synth_inputs(B, L, z, salt=30 + k)
+            e.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+            engs.append(parallel.DataParallelEngine(e, dist.group.WORLD) if use_dp else e)
+            streams.append(torch.cuda.Stream(device=dev))
+        torch.cuda.synchronize()
+        cur = torch.cuda.current_stream(dev)
+        for s in streams:
+            s.wait_stream(cur)
+        # the bench's structure: the wave and the time model on two HIP streams, graph replay, ONE communicator
+        for _ in range(steps):
+            for e, s in zip(engs, streams):
+                with torch.cuda.stream(s):
+                    e.train_step(use_graph=True)
+        for s in streams:
+            cur.wait_stream(s)
+        torch.cuda.synchronize()
+        raw = [e.engine if use_dp else e for e in engs]
+        out[name] = [(e.params.cpu().numpy().copy(), e.grads.cpu().numpy().copy(), e.scalars(), e.adam_step) for e in raw]
+    q.put((out, dist.get_backend(), dist.get_world_size()))
+    dist.destroy_process_group()
+
+
+def test_rccl_world1_data_parallel_step_equals_plain_step_bit_for_bit():
+    """The first RCCL run inside the suite: DataParallelEngine.train_step (hipGraph replay of fwd / bwd / opt with
+    ncclAllReduce(AVG) of the gradient arena between bwd and opt) for the wave and the time model on two HIP streams over
+    ONE communicator, world size 1 — against the same engines stepping without torch.distributed.  The mean over one rank is
+    the identity and deterministic_wgrad orders every sum, so parameters, gradients and losses must agree BIT FOR BIT."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out, backend, world = q.get(timeout=600)
+    p.join(60)
+    assert backend == "nccl" and world == 1
+    for k in range(2):
+        pa, ga, sa, ta = out["plain"][k]
+        pb, gb, sb, tb = out["rccl"][k]
+        assert ta == tb == 3
+        np.testing.assert_array_equal(ga, gb, err_msg=f"model {k}: gradients differ")
+        np.testing.assert_array_equal(pa, pb, err_msg=f"model {k}: parameters differ")
+        assert sa == sb, (sa, sb)

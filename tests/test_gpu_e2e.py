@@ -88,8 +88,8 @@ def masked_oracle_step(eng, oms, batch, batch64, eps, c, tag):
     pres = H.engine_pre_activations(eng)
     masks = {k: torch.from_numpy(v > 0) for k, v in pres.items()}
     # The UNMASKED anchor: against the FREE-RUNNING oracles (throw-away copies: a training forward mutates the running
-    # statistics) every leaky-ReLU input tensor of the engine meets the parity criterion, at most 1e-5 of the signs differ,
-    # and every element whose sign differs is closer to zero than the parity bar resolves (helpers.assert_flip_budget).
+    # statistics) every leaky-ReLU input tensor of the engine meets the parity criterion, at most 3e-6 of the signs differ,
+    # and every element whose sign differs is closer to zero than float32 resolves (helpers.assert_flip_budget).
     # Only then are both oracles re-evaluated on the engine's branches for the gradient comparison.
     taps_free = []
     for dt, b_, e_ in ((torch.float32, batch, eps), (torch.float64, batch64, eps.double())):
@@ -99,7 +99,7 @@ def masked_oracle_step(eng, oms, batch, batch64, eps, c, tag):
             free.forward(b_, e_, True, taps=taps_free[-1])
     flips, elems, worst = H.assert_flip_budget(pres, taps_free[0], taps_free[1], tag)
     print(f"[{tag}] leaky-ReLU inputs whose sign differs from the free-running f64 oracle: {flips} of {elems} "
-          f"(budget {int(np.ceil(H.FLIP_BUDGET * elems))}); largest |pre| among them {worst:.2e} of its tensor's max")
+          f"(budget {H.flip_allowance(elems)}); largest |pre| among them {worst:.2e} of its tensor's max")
     outs32 = oms[0].forward(batch, eps, True, masks=masks)
     ls32 = oms[0].losses(batch, outs32, c["beta"], c.get("w1", 1.0), c.get("w2", 1.0))
     ls32[0].backward()
@@ -194,18 +194,24 @@ def test_training_trajectory_vs_reference_golden(name, use_graph):
         got.append([sc[0], sc[1], sc[3]])
     got = np.array(got)
     dev = np.abs(got - g["scalars_traj"]) / np.abs(g["scalars_traj"])
-    print(f"[traj {name} graph={use_graph}] max rel deviation per step: {dev.max(1)}")
+    print(f"[traj {name} graph={use_graph}] max rel deviation per step: " + " ".join(f"{v:.2e}" for v in dev.max(1)))
     np.testing.assert_allclose(got[0], g["scalars_traj"][0], rtol=1e-4)
-    # later steps inherit the few-per-cent gradient perturbation of leaky-ReLU mask flips (helpers.grad_parity)
-    np.testing.assert_allclose(got, g["scalars_traj"], rtol=2e-3)
-    # the optimiser's effect: cumulative loss decrements agree with the reference's to 5 %
+    # Later steps: UNMASKED, against what the reference itself logged.  Measured (MI355X, round 3): <= 4.4e-4 over the six
+    # steps — at batch 32 at most one leaky-ReLU sign differs from the oracle's (helpers.assert_flip_budget), and what is left is
+    # Adam's +-lr move of elements whose gradient is rounding noise in ANY float32 implementation, the reference's included
+    # (test_masked_trajectory_is_tight holds the same steps to 5e-5 against the float64 oracle).  Bound: 1e-3 (round 2: 2e-3).
+    np.testing.assert_allclose(got, g["scalars_traj"], rtol=1e-3)
+    # the optimiser's effect: cumulative loss decrements agree with the reference's to 2 % (measured <= 0.5 %; round 2: 5 %)
     d_mine, d_ref = got[0, 0] - got[1:, 0], g["scalars_traj"][0, 0] - g["scalars_traj"][1:, 0]
-    np.testing.assert_allclose(d_mine, d_ref, rtol=5e-2)
+    print(f"[traj {name} graph={use_graph}] loss decrements vs reference: max rel deviation {np.abs(d_mine / d_ref - 1).max():.2e}")
+    np.testing.assert_allclose(d_mine, d_ref, rtol=2e-2)
     assert eng.adam_step == 6
     sd = eng.state_dict()
+    worst_frac = 0.0
     for k in g:
         if k.startswith("param_step6.") and not re.search(H.ZERO_GRAD_RE, k):
-            H.assert_adam_close(n(sd[k.split(".", 1)[1]]), g[k], c["lr"], k, steps=6, frac=5e-2)
+            worst_frac = max(worst_frac, H.assert_adam_close(n(sd[k.split(".", 1)[1]]), g[k], c["lr"], k, steps=6, frac=5e-2))
+    print(f"[traj {name} graph={use_graph}] parameters after 6 steps: worst fraction of elements beyond noise {worst_frac:.2e}")
     for k, v in sd.items():
         if k.endswith("num_batches_tracked"):
             assert int(v) == 6

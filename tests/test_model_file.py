@@ -1,0 +1,145 @@
+"""Serialised lowered models (.hpm, hippie_amd/export.py) and the hp_model_* level of the C ABI (hippie_amd/csrc/model.hip).
+
+CPU: the file round-trips, hp_model_load(HP_MODEL_NO_DEVICE) parses and validates it without a GPU and reports the same
+tables as the planner; damaged files are refused.  GPU: a plain-C host (tests/c_host/host_step.c — no Python, no torch, no HIP
+headers) loads the file, takes optimisation steps through hp_model_forward / backward / optimizer_step / train_step, and lands
+on the Python engine's and the oracle's numbers."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from hippie_amd import export, planner, program as P
+from oracle import cvae_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class TensorInfo(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 112), ("space", ctypes.c_int32), ("layout", ctypes.c_int32), ("offset_bytes", ctypes.c_int64),
+                ("numel", ctypes.c_int64), ("ndim", ctypes.c_int32), ("shape", ctypes.c_int32 * 4), ("dtype", ctypes.c_int32)]
+
+
+assert ctypes.sizeof(TensorInfo) == export.TENSOR_DT.itemsize == 160
+
+
+def _export(tmp_path, kind="unimodal", z=10, L=50, B=16, L2=100, salt=0, clip=0.0, lr=1e-3):
+    cfg = planner.ModelCfg(kind, z, L, L2)
+    plan = planner.lower(cfg, B, planner.TrainCfg(lr=lr, clip=clip))
+    om = O.OracleModel(kind, z, L, output_size2=L2 if kind == "multimodal" else None, salt=salt)
+    pv, bv = export.arena_values(plan, {k: v.detach() for k, v in om.state.items()})
+    path = str(tmp_path / f"{kind}.hpm")
+    export.save_model(plan, path, pv, bv)
+    return plan, om, path, pv, bv
+
+
+@pytest.mark.parametrize("kind", ["unimodal", "multimodal"])
+def test_file_round_trip_and_host_only_load(tmp_path, kind):
+    plan, om, path, pv, bv = _export(tmp_path, kind, B=6)
+    d = export.read_model(path)
+    assert d["abi"] == P.ABI_VERSION and d["arena_bytes"] == export.arena_sizes(plan)
+    assert np.array_equal(d["ops"], plan.ops.array()) and d["segments"] == dict(plan.ops.segments)
+    assert [t["name"].decode() for t in d["params"]] == list(plan.params)
+    assert np.array_equal(d["param_values"], pv) and np.array_equal(d["buf_values"], bv)
+    lib = P.load_library()
+    m = ctypes.c_void_p()
+    assert lib.hp_model_load(path.encode(), export.NO_DEVICE, ctypes.byref(m)) == 0, lib.hp_last_error()
+    cfg = (ctypes.c_int32 * 16)()
+    assert lib.hp_model_config(m, cfg) == 0
+    assert list(cfg[:9]) == [1 if kind == "multimodal" else 0, 10, 50, 100, 5, 5, 5, 6, 0] and cfg[9] == plan.n_active
+    assert lib.hp_model_tensor_count(m, 0) == len(plan.params) and lib.hp_model_tensor_count(m, 1) == len(plan.bufs)
+    assert lib.hp_model_tensor_count(m, 2) == len(plan.io)
+    t = TensorInfo()
+    for i, (k, info) in enumerate(plan.params.items()):
+        assert lib.hp_model_tensor_info(m, 0, i, ctypes.byref(t)) == 0
+        assert t.name.decode() == k and t.offset_bytes == info.offset * 4 and t.numel == info.numel
+        assert list(t.shape[: t.ndim]) == list(info.shape) and t.layout == (1 if info.layout == "tnc" else 0)
+    assert lib.hp_model_find(m, b"scalars", ctypes.byref(t)) == 0 and t.numel == 4 and t.space == P.WS
+    assert lib.hp_model_find(m, b"no_such_tensor", ctypes.byref(t)) != 0 and b"no_such_tensor" in lib.hp_last_error()
+    first, count = ctypes.c_int(), ctypes.c_int()
+    for seg, (f, c) in plan.ops.segments.items():
+        assert lib.hp_model_segment(m, seg.encode(), ctypes.byref(first), ctypes.byref(count)) == 0
+        assert (first.value, count.value) == (f, c)
+    assert lib.hp_model_run(m, b"fwd_train", 0, None) != 0            # host-only load: running is refused, not crashed
+    assert lib.hp_model_destroy(m) == 0
+
+
+def test_damaged_files_are_refused(tmp_path):
+    plan, om, path, pv, bv = _export(tmp_path, B=4)
+    raw = open(path, "rb").read()
+    lib = P.load_library()
+    m = ctypes.c_void_p()
+
+    def load(data):
+        bad = str(tmp_path / "bad.hpm")
+        with open(bad, "wb") as f:
+            f.write(data)
+        return lib.hp_model_load(bad.encode(), export.NO_DEVICE, ctypes.byref(m))
+
+    assert load(b"NOTMODEL" + raw[8:]) != 0 and b"magic" in lib.hp_last_error()
+    assert load(raw[: len(raw) // 2]) != 0 and b"short file" in lib.hp_last_error()
+    wrong_abi = bytearray(raw)
+    wrong_abi[12:16] = (P.ABI_VERSION + 1).to_bytes(4, "little")
+    assert load(bytes(wrong_abi)) != 0 and b"ABI" in lib.hp_last_error()
+    # an op whose buffer reference points outside its arena: caught by the same validation as hp_program_create
+    d = export.read_model(path)
+    ops = d["ops"].copy()
+    k = next(i for i, r in enumerate(ops) if int(r["op"]) == P.CONV_TAPS)
+    ops[k]["buf"][2] = (P.WS << 56) | (d["arena_bytes"][P.WS] - 64)
+    off = 152
+    assert load(raw[:off] + ops.tobytes() + raw[off + ops.nbytes:]) != 0 and b"out of range" in lib.hp_last_error()
+    assert lib.hp_model_load(str(tmp_path / "missing.hpm").encode(), 0, ctypes.byref(m)) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,use_graph", [("unimodal", 1), ("unimodal", 0), ("multimodal", 1)])
+def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph):
+    """tests/c_host/host_step.c — C99, only include/hippie_hip.h — against the Python engine on the same file and inputs."""
+    from hippie_amd.engine import Engine
+    z, L, L2, B, lr, clip = 10, 50, 100, 16, 1e-4, 1.0
+    plan, om, path, pv, bv = _export(tmp_path, kind, z, L, B, L2, salt=4, clip=clip, lr=lr)
+    x, src, cls, eps = O.synth_inputs(B, L, z, salt=4, name="x1" if kind == "multimodal" else "x")
+    parts = [x.numpy().astype(np.float32).tobytes()]
+    x2 = None
+    if kind == "multimodal":
+        x2 = O.synth_inputs(B, L2, z, salt=4, name="x2")[0]
+        parts.append(x2.numpy().astype(np.float32).tobytes())
+    parts += [src.numpy().astype(np.int64).tobytes(), eps.numpy().astype(np.float32).tobytes()]
+    inputs = str(tmp_path / "inputs.bin")
+    with open(inputs, "wb") as f:
+        f.write(b"".join(parts))
+    exe = str(tmp_path / "host_step")
+    libdir = os.path.join(ROOT, "hippie_amd")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_host", "host_step.c"), "-o", exe, "-L", libdir, "-lhippie_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    steps = 3
+    out = subprocess.run([exe, path, inputs, str(steps), str(use_graph)], check=True, capture_output=True, text=True, timeout=300).stdout
+    lines = out.strip().splitlines()
+    got = np.array([[float(v) for v in ln.split()[2:]] for ln in lines if ln.startswith("step ")])
+    assert got.shape == (steps, 4), out
+    # the Python engine on the same program and inputs
+    eng = Engine(planner.ModelCfg(kind, z, L, L2), B, planner.TrainCfg(lr=lr, clip=clip))
+    eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda(), x2=x2.cuda() if x2 is not None else None)
+    want = []
+    for _ in range(steps):
+        eng.train_step(use_graph=False)
+        want.append(eng.scalars())
+    np.testing.assert_allclose(got, np.array(want), rtol=2e-6)        # same kernels; only the order of atomic sums differs
+    enc = eng.io("enc_train").double()
+    tail = dict(ln.split(" sum ") for ln in lines if " sum " in ln)
+    s, s2 = (float(v) for v in tail["enc_train"].replace("sumsq ", "").split())
+    np.testing.assert_allclose([s, s2], [float(enc.sum()), float((enc * enc).sum())], rtol=1e-5, atol=1e-6)
+    key = ("encoder_mod1." if kind == "multimodal" else "encoder.") + "conv1.weight"
+    wsum, rest = tail[key].split(" numel ")
+    np.testing.assert_allclose(float(wsum), float(eng.state_dict()[key].double().sum()), rtol=1e-5, atol=1e-6)
+    assert rest.split() == ["192", "batches_tracked", str(steps)]
+    # and the oracle: the first step's scalars (before any parameter moved)
+    outs = om.forward((x, src, None) if kind == "unimodal" else (x, x2, src, None), eps, True)
+    ls = [float(v) for v in om.losses((x, src, None) if kind == "unimodal" else (x, x2, src, None), outs, 1.0)]
+    mine = [got[0][0], got[0][1], got[0][3]] if kind == "unimodal" else list(got[0])
+    np.testing.assert_allclose(mine, ls, rtol=1e-4)

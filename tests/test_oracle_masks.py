@@ -113,7 +113,7 @@ def test_flip_budget_passes_for_the_interpreter_and_catches_a_mis_signed_band():
         H.assert_flip_budget(bad, taps[0], taps[1], "mis-signed")
     tiny = {k: v.copy() for k, v in pres.items()}
     small = np.abs(tiny[key]) < 1e-3 * np.abs(tiny[key]).max()
-    assert small.sum() > H.FLIP_BUDGET * elems
+    assert small.sum() > H.flip_allowance(elems)
     tiny[key][small] *= -1.0                                  # many flips of small values: over the count budget
     with pytest.raises(AssertionError):
         H.assert_flip_budget(tiny, taps[0], taps[1], "too many")
