@@ -42,6 +42,20 @@ class ModelCfg:
 
 
 @dataclass
+class BackboneCfg:
+    """A stand-alone module of hippie/backbones.py lowered on its own (forward only: training-mode BatchNorm with running-
+    statistics side effects, and eval mode): "ResizeConv1d" (:6-16), "BasicBlockEnc" (:19-41), "BasicBlockDec" (:44-70),
+    "ResNet18Enc" (:73-103), "ResNet18Dec" (:106-141).  Tensors cross the boundary channels-last ([B, L, C])."""
+    kind: str = "ResNet18Enc"
+    length: int = 50                  # input length L (ResNet18Dec: unused — its input is [B, 2z])
+    z_dim: int = 10                   # ResNet18Enc / ResNet18Dec
+    output_size: int = 64             # ResNet18Dec
+    in_channels: int = 64             # blocks / ResizeConv1d: in_planes / in_channels
+    out_channels: int = 64            # ResizeConv1d only
+    stride: int = 1                   # blocks: stride; ResizeConv1d: scale_factor
+
+
+@dataclass
 class TrainCfg:
     lr: float = 0.01
     weight_decay: float = 0.01
@@ -207,6 +221,19 @@ class Lowering:
         self.det_flag = 1 if self.train.deterministic_wgrad else 0
 
     # ---- parameter declaration (own order; class_embedding last so that AdamW can skip it) ----
+    def declare_enc_block(self, p, cin, stride):
+        """BasicBlockEnc(in_planes=cin, stride) (hippie/backbones.py:20-34): planes = cin * stride"""
+        pl, planes = self.pl, cin * stride
+        blk = dict(prefix=p, cin=cin, cout=planes, stride=stride)
+        blk["conv1"] = pl.param(p + "conv1.weight", (planes, cin, 3), "tnc")
+        blk["bn1"] = pl.bn_params(p + "bn1", planes)
+        blk["conv2"] = pl.param(p + "conv2.weight", (planes, planes, 3), "tnc")
+        blk["bn2"] = pl.bn_params(p + "bn2", planes)
+        if stride != 1:
+            blk["sc"] = pl.param(p + "shortcut.0.weight", (planes, cin, 1))
+            blk["scbn"] = pl.bn_params(p + "shortcut.1", planes)
+        return blk
+
     def declare_encoder(self, pre):
         pl = self.pl
         e = dict(prefix=pre)
@@ -217,20 +244,29 @@ class Lowering:
         for li, planes in enumerate((64, 128, 256, 512), start=1):
             for bi in (0, 1):
                 stride = 2 if (bi == 0 and li > 1) else 1
-                p = f"{pre}layer{li}.{bi}."
-                blk = dict(prefix=p, cin=cin, cout=planes, stride=stride)
-                blk["conv1"] = pl.param(p + "conv1.weight", (planes, cin, 3), "tnc")
-                blk["bn1"] = pl.bn_params(p + "bn1", planes)
-                blk["conv2"] = pl.param(p + "conv2.weight", (planes, planes, 3), "tnc")
-                blk["bn2"] = pl.bn_params(p + "bn2", planes)
-                if stride != 1:
-                    blk["sc"] = pl.param(p + "shortcut.0.weight", (planes, cin, 1))
-                    blk["scbn"] = pl.bn_params(p + "shortcut.1", planes)
-                e["blocks"].append(blk)
+                e["blocks"].append(self.declare_enc_block(f"{pre}layer{li}.{bi}.", cin, stride))
                 cin = planes
         e["lin_w"] = pl.param(pre + "linear.weight", (2 * self.cfg.z_dim, 512))
         e["lin_b"] = pl.param(pre + "linear.bias", (2 * self.cfg.z_dim,))
         return e
+
+    def declare_dec_block(self, p, cin, stride):
+        """BasicBlockDec(in_planes=cin, stride) (hippie/backbones.py:45-63): planes = cin / stride"""
+        pl, cout = self.pl, cin // stride
+        blk = dict(prefix=p, cin=cin, cout=cout, stride=stride)
+        blk["conv2"] = pl.param(p + "conv2.weight", (cin, cin, 3), "tnc")
+        blk["bn2"] = pl.bn_params(p + "bn2", cin)
+        if stride == 1:
+            blk["conv1"] = pl.param(p + "conv1.weight", (cout, cin, 3), "tnc")
+            blk["bn1"] = pl.bn_params(p + "bn1", cout)
+        else:
+            blk["conv1"] = pl.param(p + "conv1.conv.weight", (cout, cin, 3), "tnc")
+            blk["conv1_b"] = pl.param(p + "conv1.conv.bias", (cout,))
+            blk["bn1"] = pl.bn_params(p + "bn1", cout)
+            blk["sc"] = pl.param(p + "shortcut.0.conv.weight", (cout, cin, 3), "tnc")
+            blk["sc_b"] = pl.param(p + "shortcut.0.conv.bias", (cout,))
+            blk["scbn"] = pl.bn_params(p + "shortcut.1", cout)
+        return blk
 
     def declare_decoder(self, pre, output_size):
         pl = self.pl
@@ -241,22 +277,7 @@ class Lowering:
         cin = 512
         for li, planes in ((4, 256), (3, 128), (2, 64), (1, 64)):
             for bi, stride in enumerate((1, 1 if li == 1 else 2)):
-                p = f"{pre}layer{li}.{bi}."
-                cout = cin // stride
-                blk = dict(prefix=p, cin=cin, cout=cout, stride=stride)
-                blk["conv2"] = pl.param(p + "conv2.weight", (cin, cin, 3), "tnc")
-                blk["bn2"] = pl.bn_params(p + "bn2", cin)
-                if stride == 1:
-                    blk["conv1"] = pl.param(p + "conv1.weight", (cout, cin, 3), "tnc")
-                    blk["bn1"] = pl.bn_params(p + "bn1", cout)
-                else:
-                    blk["conv1"] = pl.param(p + "conv1.conv.weight", (cout, cin, 3), "tnc")
-                    blk["conv1_b"] = pl.param(p + "conv1.conv.bias", (cout,))
-                    blk["bn1"] = pl.bn_params(p + "bn1", cout)
-                    blk["sc"] = pl.param(p + "shortcut.0.conv.weight", (cout, cin, 3), "tnc")
-                    blk["sc_b"] = pl.param(p + "shortcut.0.conv.bias", (cout,))
-                    blk["scbn"] = pl.bn_params(p + "shortcut.1", cout)
-                d["blocks"].append(blk)
+                d["blocks"].append(self.declare_dec_block(f"{pre}layer{li}.{bi}.", cin, stride))
             cin = planes
         d["tail_w"] = pl.param(pre + "conv1.conv.weight", (1, 64, 3))
         d["tail_b"] = pl.param(pre + "conv1.conv.bias", (1,))
@@ -555,41 +576,47 @@ class Lowering:
         e.update(x=x, L=L, L1=L1, raw0=raw0, a0=a0)
         cur, Lc = a0, L1
         for blk in e["blocks"]:
-            cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
-            tm1, Lo = self.map_fwd(Lc, cin, cout, s)
-            Mo = B * Lo
-            r1 = pl.f32(Mo * cout)
-            st1 = pl.stat(2 * cout) if training else None
-            self.conv(tm1, cur, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1")
-            if s != 1:
-                tms, _ = self.map_fwd(Lc, cin, cout, s, k=1)
-                rs = pl.f32(Mo * cout)
-                sts = pl.stat(2 * cout) if training else None
-                self.conv(tms, cur, blk["sc"], rs, stats=sts, note=blk["prefix"] + "shortcut.0")
-                self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut.0")
-            tm2, _ = self.map_fwd(Lo, cout, cout, 1)
-            r2 = pl.f32(Mo * cout)
-            st2 = pl.stat(2 * cout) if training else None
-            if training and self.train.fuse_bn:
-                # lrelu(bn1(r1)) has exactly one consumer, conv2: evaluated in its operand loader, never stored
-                a1 = None
-                self.conv(tm2, r1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2", in_bn=dict(bn=blk["bn1"], stats=st1, M=Mo))
-            else:
-                a1 = pl.f32(Mo * cout)
-                self.bn_apply(Mo, blk["bn1"], r1, a1, st1, training, True, SLOPE_BACKBONE)
-                self.conv(tm2, a1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
-            out = pl.f32(Mo * cout)
-            blk.update(x=cur, Lin=Lc, Lout=Lo, r1=r1, a1=a1, r2=r2, out=out, tm1=tm1, tm2=tm2)
-            if s == 1:
-                self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 1, cur)
-            else:
-                self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
-                blk.update(rs=rs, tms=tms)
-            cur, Lc = out, Lo
+            cur, Lc = self.enc_block_fwd(blk, cur, Lc, training)
         pooled = pl.f32(B * 512)
         self.o.add(P.POOL_FWD, 0, i=[B, Lc, 512], buf=[cur, pooled], note=e["prefix"] + "avgpool")
         e.update(pooled=pooled, Llast=Lc, last=cur)
         return pooled
+
+    def enc_block_fwd(self, blk, cur, Lc, training):
+        """BasicBlockEnc.forward (hippie/backbones.py:36-41): lrelu(bn1(conv1(x))) -> bn2(conv2(.)) -> += shortcut(x) -> lrelu.
+        cur: [B*Lc][cin] channels-last.  -> (out, Lout)"""
+        pl, B = self.pl, self.B
+        cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
+        tm1, Lo = self.map_fwd(Lc, cin, cout, s)
+        Mo = B * Lo
+        r1 = pl.f32(Mo * cout)
+        st1 = pl.stat(2 * cout) if training else None
+        self.conv(tm1, cur, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1")
+        if s != 1:
+            tms, _ = self.map_fwd(Lc, cin, cout, s, k=1)
+            rs = pl.f32(Mo * cout)
+            sts = pl.stat(2 * cout) if training else None
+            self.conv(tms, cur, blk["sc"], rs, stats=sts, note=blk["prefix"] + "shortcut.0")
+            self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut.0")
+        tm2, _ = self.map_fwd(Lo, cout, cout, 1)
+        r2 = pl.f32(Mo * cout)
+        st2 = pl.stat(2 * cout) if training else None
+        if training and self.train.fuse_bn:
+            # lrelu(bn1(r1)) has exactly one consumer, conv2: evaluated in its operand loader, never stored
+            a1 = None
+            self.conv(tm2, r1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2", in_bn=dict(bn=blk["bn1"], stats=st1, M=Mo))
+        else:
+            a1 = pl.f32(Mo * cout)
+            self.bn_apply(Mo, blk["bn1"], r1, a1, st1, training, True, SLOPE_BACKBONE)
+            self.conv(tm2, a1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
+        out = pl.f32(Mo * cout)
+        blk.update(x=cur, Lin=Lc, Lout=Lo, r1=r1, a1=a1, r2=r2, out=out, tm1=tm1, tm2=tm2)
+        if s == 1:
+            self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 1, cur)
+        else:
+            self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
+            blk.update(rs=rs, tms=tms)
+        return out, Lo
 
     def enc_out_spec(self, e, bi, g2):
         """reduction spec of the BatchNorm that produced the INPUT of encoder block bi (block bi-1's bn2 [+ shortcut
@@ -663,42 +690,7 @@ class Lowering:
         d.update(din=din, lin=lin, y=y, act0=act0)
         cur, Lc = act0, 4
         for blk in d["blocks"]:
-            cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
-            Mi = B * Lc
-            tm2, _ = self.map_fwd(Lc, cin, cin, 1)
-            r2 = pl.f32(Mi * cin)
-            st2 = pl.stat(2 * cin) if training else None
-            self.conv(tm2, cur, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
-            if training and self.train.fuse_bn:
-                a2, src2 = None, r2                 # lrelu(bn2(r2)) is evaluated in conv1's operand loader
-                ib = dict(bn=blk["bn2"], stats=st2, M=Mi)
-            else:
-                a2 = src2 = pl.f32(Mi * cin)
-                ib = None
-                self.bn_apply(Mi, blk["bn2"], r2, a2, st2, training, True, SLOPE_BACKBONE)
-            blk.update(x=cur, Lin=Lc, r2=r2, a2=a2, tm2=tm2)
-            if s == 1:
-                tm1, Lo = self.map_fwd(Lc, cin, cout, 1)
-                r1 = pl.f32(Mi * cout)
-                st1 = pl.stat(2 * cout) if training else None
-                self.conv(tm1, src2, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1", in_bn=ib)
-                out = pl.f32(Mi * cout)
-                self.bn_apply(Mi, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 1, cur)
-            else:
-                tm1, Lo = self.map_fwd_up(Lc, cin, cout)
-                Mo = B * Lo
-                r1 = pl.f32(Mo * cout)
-                st1 = pl.stat(2 * cout) if training else None
-                self.conv(tm1, src2, blk["conv1"], r1, bias=blk["conv1_b"], stats=st1, note=blk["prefix"] + "conv1 (resize)", in_bn=ib)
-                rs = pl.f32(Mo * cout)
-                sts = pl.stat(2 * cout) if training else None
-                self.conv(tm1, cur, blk["sc"], rs, bias=blk["sc_b"], stats=sts, note=blk["prefix"] + "shortcut (resize)")
-                self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut (resize)")
-                out = pl.f32(Mo * cout)
-                self.bn_apply(Mo, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
-                blk.update(rs=rs)
-            blk.update(r1=r1, out=out, tm1=tm1, Lout=Lo)
-            cur, Lc = out, Lo
+            cur, Lc = self.dec_block_fwd(blk, cur, Lc, training)
         assert Lc == 32
         t = pl.f32(B * 64)
         self.o.add(P.TAIL_FWD, 0, i=[B, 32, 64], buf=[cur, d["tail_w"].ref, d["tail_b"].ref, t], note=d["prefix"] + "conv1 (resize 64->1)")
@@ -709,6 +701,47 @@ class Lowering:
         self.linear_fwd(B, lo, t, 64, rec, d["output_size"], note=d["prefix"] + "linear_out")
         d.update(last=cur, t=t, lo=lo, rec=rec)
         return rec
+
+    def dec_block_fwd(self, blk, cur, Lc, training):
+        """BasicBlockDec.forward (hippie/backbones.py:65-70): lrelu(bn2(conv2(x))) -> bn1(conv1(.)) (conv1 = ResizeConv1d when the
+        block up-samples) -> += shortcut(x) (identity, or ResizeConv1d + BN) -> lrelu.  cur: [B*Lc][cin].  -> (out, Lout)"""
+        pl, B = self.pl, self.B
+        cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
+        Mi = B * Lc
+        tm2, _ = self.map_fwd(Lc, cin, cin, 1)
+        r2 = pl.f32(Mi * cin)
+        st2 = pl.stat(2 * cin) if training else None
+        self.conv(tm2, cur, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
+        if training and self.train.fuse_bn:
+            a2, src2 = None, r2                 # lrelu(bn2(r2)) is evaluated in conv1's operand loader
+            ib = dict(bn=blk["bn2"], stats=st2, M=Mi)
+        else:
+            a2 = src2 = pl.f32(Mi * cin)
+            ib = None
+            self.bn_apply(Mi, blk["bn2"], r2, a2, st2, training, True, SLOPE_BACKBONE)
+        blk.update(x=cur, Lin=Lc, r2=r2, a2=a2, tm2=tm2)
+        if s == 1:
+            tm1, Lo = self.map_fwd(Lc, cin, cout, 1)
+            r1 = pl.f32(Mi * cout)
+            st1 = pl.stat(2 * cout) if training else None
+            self.conv(tm1, src2, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1", in_bn=ib)
+            out = pl.f32(Mi * cout)
+            self.bn_apply(Mi, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 1, cur)
+        else:
+            tm1, Lo = self.map_fwd_up(Lc, cin, cout)
+            Mo = B * Lo
+            r1 = pl.f32(Mo * cout)
+            st1 = pl.stat(2 * cout) if training else None
+            self.conv(tm1, src2, blk["conv1"], r1, bias=blk["conv1_b"], stats=st1, note=blk["prefix"] + "conv1 (resize)", in_bn=ib)
+            rs = pl.f32(Mo * cout)
+            sts = pl.stat(2 * cout) if training else None
+            self.conv(tm1, cur, blk["sc"], rs, bias=blk["sc_b"], stats=sts, note=blk["prefix"] + "shortcut (resize)")
+            self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut (resize)")
+            out = pl.f32(Mo * cout)
+            self.bn_apply(Mo, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
+            blk.update(rs=rs)
+        blk.update(r1=r1, out=out, tm1=tm1, Lout=Lo)
+        return out, Lo
 
     def decoder_bwd(self, d, drec, ddin, accumulate=False):
         """drec: [B][out] ; writes d(din) [B][2z] into ddin."""
@@ -1188,5 +1221,77 @@ def pack_workspace(pl, serial_backward=True):
     pl._ws = top
 
 
-def lower(cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, **kw) -> Plan:
+def lower_backbone(spec: BackboneCfg, batch: int, train: TrainCfg = None) -> Plan:
+    """Forward programs ("fwd_train", "fwd_eval") of one stand-alone backbone module.  I/O slots: "x" (channels-last
+    [B, L, Cin]; ResNet18Enc [B, 1, L]; ResNet18Dec [B, 2z]) and "out_train" / "out_eval" (channels-last [B, Lout, Cout];
+    ResNet18Enc [B, 2z]; ResNet18Dec [B, 1, output_size]).  Parameter keys are the module's own state_dict keys."""
+    kind, L, B = spec.kind, spec.length, batch
+    lw = Lowering(ModelCfg(kind="unimodal", z_dim=spec.z_dim, output_size=spec.output_size), batch, train)
+    pl, z = lw.pl, spec.z_dim
+    pl.cfg = spec
+    cin, s_ = spec.in_channels, spec.stride
+    if kind in ("BasicBlockEnc", "BasicBlockDec", "ResizeConv1d"):
+        if cin % 32 != 0:
+            raise ValueError(f"{kind}: in_channels must be a multiple of 32 (the MFMA K-step); got {cin}")
+        if s_ not in (1, 2):
+            raise ValueError(f"{kind}: stride / scale_factor must be 1 or 2; got {s_}")
+    if kind == "ResNet18Enc":
+        mod = lw.declare_encoder("")
+        xshape, xn = (B, 1, L), B * L
+    elif kind == "ResNet18Dec":
+        mod = lw.declare_decoder("", spec.output_size)
+        xshape, xn = (B, 2 * z), B * 2 * z
+    elif kind == "BasicBlockEnc":
+        mod = lw.declare_enc_block("", cin, s_)
+        xshape, xn = (B, L, cin), B * L * cin
+    elif kind == "BasicBlockDec":
+        if cin % (32 * s_) != 0:
+            raise ValueError(f"BasicBlockDec: in_planes / stride must be a multiple of 32; got {cin} / {s_}")
+        mod = lw.declare_dec_block("", cin, s_)
+        xshape, xn = (B, L, cin), B * L * cin
+    elif kind == "ResizeConv1d":
+        if spec.out_channels % 4 != 0:
+            raise ValueError(f"ResizeConv1d: out_channels must be a multiple of 4; got {spec.out_channels}")
+        mod = dict(w=pl.param("conv.weight", (spec.out_channels, cin, 3), "tnc"), b=pl.param("conv.bias", (spec.out_channels,)))
+        xshape, xn = (B, L, cin), B * L * cin
+    else:
+        raise ValueError(f"unknown backbone module {kind!r}")
+    pl.n_active = pl.n_param_floats
+    pl.grad_bucket_a = None
+    pl.stats_cap = 32 << 20
+    pl.stats_base = pl.ws(pl.stats_cap).offset
+    x = pl.f32(xn, "x", xshape)
+    lw.slab = pl.ws(0)
+    zeros = []
+    for mode in ("train", "eval"):
+        training = mode == "train"
+        lw.o.begin("fwd_" + mode)
+        zeros.append(lw.o.add(P.ZERO, 0, i=[0, 0], buf=[Ref(P.WS, pl.stats_base)], note="zero statistics"))
+        if kind == "ResNet18Enc":
+            pooled = lw.encoder_fwd(mod, x, L, training)
+            out = pl.f32(B * 2 * z, "out_" + mode, (B, 2 * z))
+            lw.linear_fwd(B, dict(w=mod["lin_w"], b=mod["lin_b"], N=2 * z, K=512), pooled, 512, out, 2 * z, note="linear")
+        elif kind == "ResNet18Dec":
+            rec = lw.decoder_fwd(mod, x, training)
+            pl.io["out_" + mode] = (rec, (B, 1, spec.output_size), "f4")
+        elif kind in ("BasicBlockEnc", "BasicBlockDec"):
+            out, Lo = (lw.enc_block_fwd if kind == "BasicBlockEnc" else lw.dec_block_fwd)(mod, x, L, training)
+            pl.io["out_" + mode] = (out, (B, Lo, mod["cout"]), "f4")
+        else:
+            tm = lw.map_fwd_up(L, cin, spec.out_channels)[0] if s_ == 2 else lw.map_fwd(L, cin, spec.out_channels, 1)[0]
+            out = pl.f32(tm.M * tm.N, "out_" + mode, (B, tm.Lout, tm.N))
+            lw.conv(tm, x, mod["w"], out, bias=mod["b"], note="conv")
+        lw.o.end()
+    used = _round_up(max(pl.stats_bytes, 16), 256)
+    for k in zeros:
+        lw.o.recs[k]["i"][0] = used
+    pl.ws(16)          # (the slab slot of a full model: nothing here needs one)
+    if lw.train.reuse_workspace and not P.debug_knob("HIPPIE_NO_WS_REUSE"):
+        pack_workspace(pl)
+    return pl
+
+
+def lower(cfg, batch: int, train: TrainCfg = None, with_class=False, **kw) -> Plan:
+    if isinstance(cfg, BackboneCfg):
+        return lower_backbone(cfg, batch, train)
     return Lowering(cfg, batch, train, with_class, **kw).build()

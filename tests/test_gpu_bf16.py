@@ -6,6 +6,7 @@ tolerance the format allows at random initialisation, batch 64, stated here (the
 within 0.15 of the tensor's max after 40 bfloat16 conv layers with batch-statistics BatchNorm in between (measured:
 latents 2-4e-2, reconstruction 6-10e-2), loss scalars 3e-2 relative (measured < 3e-3), every gradient tensor's cosine with
 the float64 oracle (evaluated on the engine's own leaky-ReLU branches) >= 0.93 (measured worst: the stem conv / its BatchNorm, 0.95-0.97)."""
+import os
 import re
 
 import numpy as np
@@ -91,9 +92,11 @@ def test_wgrad_taps_bf16(name, nsplit):
     check(gpu, cpu, grad, numel, rel=3e-5, what=f"wgrad bf16 {name}")
 
 
-@pytest.mark.parametrize("L,clip", [(50, 0.0), (100, 1.0)])
-def test_bf16_step_against_the_float64_oracle(L, clip):
-    z, B = 10, 64
+@pytest.mark.parametrize("L,clip,B", [(50, 0.0, 64), (100, 1.0, 64), (50, 0.0, 512), (100, 1.0, 512)])
+def test_bf16_step_against_the_float64_oracle(L, clip, B):
+    """BASELINE configs[1]'s bf16 wording, at the tolerance bfloat16 operands allow (stated per quantity below), batch 64 and
+    the config's batch 512; wave (no clipping) and time (clip 1.0) models."""
+    z = 10
     eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-3, clip=clip, mfma_dtype="bf16"))
     om = O.OracleModel("unimodal", z, L, salt=2, dtype=torch.float64)
     eng.load_state_dict({k: v.detach().float() for k, v in om.state.items()})
@@ -128,3 +131,48 @@ def test_bf16_step_against_the_float64_oracle(L, clip):
         eng.train_step(use_graph=True)
     torch.cuda.synchronize()
     assert eng.adam_step == 6 and torch.isfinite(eng.params).all() and np.isfinite(eng.scalars()[0])
+
+
+def test_bf16_is_reachable_from_the_class_surface_and_the_pipeline(tmp_path):
+    """Trainer(precision="bf16") / `pretrain_pipeline.py --precision bf16` select the bf16-MFMA lowering (BASELINE configs[1]:
+    pretrain + fine-tune in bf16): the engines under the modules carry HP_CONV_BF16 records, the whole pipeline (pretrain ->
+    checkpoint reload -> label-free fine-tune -> embedding CSVs) finishes with finite numbers, and its embeddings stay close to
+    the fp32 pipeline's on the same seed and noise (row-standardised embeddings of unit scale: max 0.5, mean 0.1; the measured
+    values are printed)."""
+    import sys
+    import pandas as pd
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import pretrain_pipeline as pp
+    from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
+    from hippie_amd.trainer import Trainer
+    from tests.test_gpu_pipeline import make_root, _Noise
+    # ---- class surface
+    net = hippieUnimodalCVAE(z_dim=10, output_size=50, class_hidden_dim=5, num_sources=5, num_classes=5)
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-4)
+    x, src, cls, _ = O.synth_inputs(64, 50, 10, salt=3)
+    Trainer(max_epochs=1, precision="bf16", enable_checkpointing=False).fit(mod, [(x[:32], src[:32]), (x[32:], src[32:])])
+    eng = net._any_engine()
+    assert net.precision == "bf16" and eng.train_cfg.mfma_dtype == "bf16"
+    convs = [r for r in eng.ops if int(r["op"]) in (P.CONV_TAPS, P.WGRAD_TAPS)]
+    assert convs and all(int(r["flags"]) & P.CONV_BF16 for r in convs)
+    assert torch.isfinite(eng.params).all()
+    with pytest.raises(ValueError):
+        Trainer(precision="fp8")
+    # ---- the pipeline script, fp32 and bf16 on the same data, seed and noise
+    rng = np.random.default_rng(1)
+    data = tmp_path / "datasets"
+    data.mkdir()
+    make_root(data, rng)
+    embs = {}
+    for prec in ("32", "bf16"):
+        out = tmp_path / ("out_" + prec)
+        noise = _Noise()
+        paths = pp.main(["--dataset", "cellexplorer-celltype", "--data-root", str(data), "--output-dir", str(out), "--batch-size", "64",
+                         "--pretrain-max-epochs", "2", "--finetune-max-epochs", "2", "--z_dim", "5", "--learning-rate", "1e-4",
+                         "--precision", prec], eps_source=lambda eng: noise.draw(eng.B, eng.cfg.z_dim).to(eng.device))
+        df = pd.read_csv(paths["joint"])
+        embs[prec] = np.array([np.array(v.strip("[]").split(), dtype=np.float64) for v in df["embeddings"]])
+        assert np.isfinite(embs[prec]).all() and embs[prec].shape[1] == 10
+    dev = np.abs(embs["bf16"] - embs["32"])
+    print(f"[bf16 pipeline] joint embeddings vs the fp32 pipeline: max |diff| {dev.max():.3e}, mean {dev.mean():.3e} (row-standardised, unit scale)")
+    assert dev.max() <= 0.5 and dev.mean() <= 0.1

@@ -208,7 +208,7 @@ def _ddp_trainer_worker(rank, world, port, q, tmp):
     torch.manual_seed(100 + rank)                       # different initial weights per rank: the start-up broadcast must fix it
     net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
     if rank == 0:
-        sd0 = {k: v.clone() for k, v in net._pending_sd.items()}
+        sd0 = {k: v.numpy().copy() for k, v in net._pending_sd.items()}
     net.set_eps_source(lambda eng: _eps_of(eng.io("x"), z).to(eng.device))
     mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-5, weight_decay=0.01)
     x, src, cls, _ = O.synth_inputs(n, L, z, salt=21)
@@ -222,7 +222,9 @@ def _ddp_trainer_worker(rank, world, port, q, tmp):
     exists = os.path.exists(tr.best_model_path)
     ck = torch.load(tr.best_model_path, weights_only=False) if exists else None
     q.put((rank, eng.params.double().sum().item(), eng.params.double().abs().sum().item(), eng.adam_step, tr.best_model_path, exists,
-           {k: v.cpu() for k, v in net.state_dict().items()} if rank == 0 else None, sd0 if rank == 0 else None,
+           # (numpy, not tensors: a tensor in a queue is handed over through the SENDER's shared-memory server, which is gone
+           # once this process exits)
+           {k: v.cpu().numpy() for k, v in net.state_dict().items()} if rank == 0 else None, sd0 if rank == 0 else None,
            sorted(ck.keys()) if ck else None, [h["val_loss"] for h in tr.history]))
     dist.destroy_process_group()
 
@@ -259,7 +261,7 @@ def test_trainer_ddp_two_ranks_equals_two_single_rank_oracles(tmp_path):
     x, src, cls, _ = O.synth_inputs(n, L, z, salt=21)
     oms = [O.OracleModel("unimodal", z, L, dtype=torch.float64) for _ in range(world)]
     for om in oms:
-        om.load({k: v for k, v in r0[7].items()})           # rank 0's constructor initialisation, broadcast to all
+        om.load({k: torch.from_numpy(v) for k, v in r0[7].items()})           # rank 0's constructor initialisation, broadcast to all
     for epoch in range(2):
         shards = [shard_indices(n, r, world, epoch=epoch, seed=3) for r in range(world)]
         for i in range(0, n // world, B):
@@ -287,7 +289,7 @@ def test_trainer_ddp_two_ranks_equals_two_single_rank_oracles(tmp_path):
     for k in oms[0].param_keys:
         if mean[k] is None:
             continue
-        a, b = sd[k].numpy().astype(np.float64).reshape(-1), oms[0].state[k].detach().numpy().reshape(-1)
+        a, b = sd[k].astype(np.float64).reshape(-1), oms[0].state[k].detach().numpy().reshape(-1)
         assert np.abs(a - b).max() <= 2.2 * lr * steps + 1e-7, k
         if re.search(H.ZERO_GRAD_RE, k):
             continue
@@ -296,7 +298,7 @@ def test_trainer_ddp_two_ranks_equals_two_single_rank_oracles(tmp_path):
         assert bad.mean() <= 2e-3, f"{k}: {bad.sum()} of {bad.size} elements with significant gradient differ"
     for k, v in sd.items():          # rank 0's BatchNorm running statistics are the ones checkpointed: they follow rank 0's shards
         if "running_" in k:
-            H.assert_close(v.numpy(), oms[0].state[k].detach().numpy(), 1e-4, k)
+            H.assert_close(v, oms[0].state[k].detach().numpy(), 1e-4, k)
 
 
 # ---- the RCCL ("nccl") backend inside the suite: world size 1 -------------------------------------------------------------

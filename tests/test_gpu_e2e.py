@@ -196,21 +196,22 @@ def test_training_trajectory_vs_reference_golden(name, use_graph):
     dev = np.abs(got - g["scalars_traj"]) / np.abs(g["scalars_traj"])
     print(f"[traj {name} graph={use_graph}] max rel deviation per step: " + " ".join(f"{v:.2e}" for v in dev.max(1)))
     np.testing.assert_allclose(got[0], g["scalars_traj"][0], rtol=1e-4)
-    # Later steps: UNMASKED, against what the reference itself logged.  Measured (MI355X, round 3): <= 4.4e-4 over the six
+    # Later steps: UNMASKED, against what the reference itself logged.  Measured (MI355X, round 3): <= 9.8e-4 over the six
     # steps — at batch 32 at most one leaky-ReLU sign differs from the oracle's (helpers.assert_flip_budget), and what is left is
     # Adam's +-lr move of elements whose gradient is rounding noise in ANY float32 implementation, the reference's included
-    # (test_masked_trajectory_is_tight holds the same steps to 5e-5 against the float64 oracle).  Bound: 1e-3 (round 2: 2e-3).
-    np.testing.assert_allclose(got, g["scalars_traj"], rtol=1e-3)
-    # the optimiser's effect: cumulative loss decrements agree with the reference's to 2 % (measured <= 0.5 %; round 2: 5 %)
+    # (test_masked_trajectory_is_tight holds the same steps to 5e-5 against the float64 oracle).  Bound: 1.5e-3 (round 2: 2e-3).
+    np.testing.assert_allclose(got, g["scalars_traj"], rtol=1.5e-3)
+    # the optimiser's effect: cumulative loss decrements agree with the reference's to 1 % (measured <= 0.22 %; round 2: 5 %)
     d_mine, d_ref = got[0, 0] - got[1:, 0], g["scalars_traj"][0, 0] - g["scalars_traj"][1:, 0]
     print(f"[traj {name} graph={use_graph}] loss decrements vs reference: max rel deviation {np.abs(d_mine / d_ref - 1).max():.2e}")
-    np.testing.assert_allclose(d_mine, d_ref, rtol=2e-2)
+    np.testing.assert_allclose(d_mine, d_ref, rtol=1e-2)
     assert eng.adam_step == 6
     sd = eng.state_dict()
     worst_frac = 0.0
     for k in g:
         if k.startswith("param_step6.") and not re.search(H.ZERO_GRAD_RE, k):
-            worst_frac = max(worst_frac, H.assert_adam_close(n(sd[k.split(".", 1)[1]]), g[k], c["lr"], k, steps=6, frac=5e-2))
+            # fraction of a tensor's elements further from the reference's than Adam noise explains: measured <= 7.2e-3; bound 2e-2 (round 2: 5e-2)
+            worst_frac = max(worst_frac, H.assert_adam_close(n(sd[k.split(".", 1)[1]]), g[k], c["lr"], k, steps=6, frac=2e-2))
     print(f"[traj {name} graph={use_graph}] parameters after 6 steps: worst fraction of elements beyond noise {worst_frac:.2e}")
     for k, v in sd.items():
         if k.endswith("num_batches_tracked"):
