@@ -325,36 +325,54 @@ class HbmLoader:
     def __len__(self):
         return -(-self.x.shape[0] // self.batch)
 
-    def __iter__(self):
-        perm = torch.randperm(self.x.shape[0], generator=self.gen).to(self.x.device)
+    def _batches(self, perm):
         for i in range(0, len(perm), self.batch):
             j = perm[i: i + self.batch]
             yield self.x.index_select(0, j).unsqueeze(1), self.labels.index_select(0, j)
 
+    def __iter__(self):
+        return self._batches(torch.randperm(self.x.shape[0], generator=self.gen).to(self.x.device))
+
+    def frozen(self):
+        """one pass with its shuffle drawn now (hippie_amd.trainer.fit_concurrently)"""
+        perm = torch.randperm(self.x.shape[0], generator=self.gen).to(self.x.device)
+        loader = self
+
+        class _Pass:
+            def __iter__(p):
+                return loader._batches(perm)
+
+            def __len__(p):
+                return len(loader)
+        return _Pass()
+
 
 def trainer_rate(device, data, epochs=2):
-    """Throughput of the REFERENCE-API path (what the scripts call): hippieUnimodalCVAE + hippieUnimodalEmbeddingModelCVAE
-    driven by Trainer.fit over the synthetic pretrain pool at batch 512, the wave model (no clipping) and then the time
-    model (clip 1.0) one after the other exactly as scripts/train_model_with_multimodal.py:200-224 trains them — no
-    cross-model overlap, a ragged last batch per epoch, per-epoch shuffling by index.  samples/s = N * epochs / (t_wave + t_time)."""
+    """Throughput of the REFERENCE-API path (what scripts/pretrain_pipeline.py runs): hippieUnimodalCVAE +
+    hippieUnimodalEmbeddingModelCVAE driven by Trainer.fit over the synthetic pretrain pool at batch 512 — the wave model (no
+    clipping) and the time model (clip 1.0) of scripts/train_model_with_multimodal.py:200-224, fitted CONCURRENTLY on two HIP
+    streams by hippie_amd.trainer.fit_concurrently (same random draws and numbers as one after the other; round 2 ran them
+    sequentially: 90 k samples/s).  A ragged last batch per epoch, per-epoch shuffling by index.
+    samples/s = N * epochs / wall time of the concurrent fits."""
     from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
-    from hippie_amd.trainer import Trainer
+    from hippie_amd.trainer import Trainer, fit_concurrently
     N = data[0].shape[0]
-    times = []
+    jobs = []
     for k, (L, clip) in enumerate(((data[0].shape[1], None), (data[1].shape[1], 1.0))):
         net = hippieUnimodalCVAE(z_dim=Z_DIM, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5, device=device)
         mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3, weight_decay=0.01)
         loader = HbmLoader(data[k], data[2], BATCH, seed=7 + k)
         Trainer(max_epochs=1, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0).fit(mod, loader)   # warm-up: lowers + captures
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        Trainer(max_epochs=epochs, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0).fit(mod, loader)
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    return {"value": N * epochs / sum(times), "unit": "samples/s", "epochs": epochs, "units_per_epoch": N,
-            "wave_s": times[0], "time_s": times[1],
+        jobs.append((Trainer(max_epochs=epochs, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0), mod, loader, None))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fit_concurrently(jobs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": N * epochs / dt, "unit": "samples/s", "epochs": epochs, "units_per_epoch": N, "wall_s": dt,
             "path": "hippie_amd.model.hippieUnimodalEmbeddingModelCVAE.training_step / optimizer.step via hippie_amd.trainer.Trainer.fit "
-                    "(hipGraph replay, per-step losses kept on the device), wave then time model sequentially"}
+                    "(hipGraph replay, per-step losses kept on the device); wave and time fits concurrently on two streams "
+                    "(hippie_amd.trainer.fit_concurrently), as scripts/pretrain_pipeline.py runs them"}
 
 
 def cpu_baseline(steps=20, warm=3):

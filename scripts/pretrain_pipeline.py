@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 from hippie_amd.dataloading import EphysDatasetLabeled                     # noqa: E402
 from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE   # noqa: E402
-from hippie_amd.trainer import Trainer                                       # noqa: E402
+from hippie_amd.trainer import Trainer, fit_concurrently                    # noqa: E402
 from hippie_amd.utils import get_embeddings                                 # noqa: E402
 
 DATASET_FILES = {
@@ -85,6 +85,9 @@ def build_parser():
     p.add_argument("--strategy", type=str, default="auto", choices=["auto", "ddp", "single_device"],
                    help="as pl.Trainer(strategy=...): under torchrun with more than one rank 'auto' and 'ddp' train data-parallel")
     p.add_argument("--sync-batchnorm", action="store_true", help="pl.Trainer(sync_batchnorm=True)")
+    p.add_argument("--sequential-fits", action="store_true",
+                   help="fit the wave model, then the time model, as the reference does (default: both at once on two HIP streams, "
+                        "with the same random draws and therefore the same numbers)")
     return p
 
 
@@ -122,6 +125,22 @@ class _Concat:
 
             def __len__(s):
                 return len(index_loader)
+
+            def frozen(s):
+                """one pass with its index draws made now (hippie_amd.trainer.fit_concurrently): the torch DataLoader iterator
+                over the index list is created and exhausted here — consuming the global generator exactly as iter(self)
+                would — and the rows are gathered later, on the consumer's stream"""
+                batches = [j for j in index_loader]
+
+                class _Pass:
+                    def __iter__(p):
+                        for j in batches:
+                            j = j.to(table.data.device, non_blocking=True)
+                            yield table.data.index_select(0, j).unsqueeze(1), table.labels.index_select(0, j)
+
+                    def __len__(p):
+                        return len(batches)
+                return _Pass()
 
             def shard(s, rank, world, epoch, seed=0):
                 """What Lightning's DDP strategy does to this DataLoader: its sampler becomes DistributedSampler(dataset,
@@ -170,13 +189,29 @@ def main(argv=None, eps_source=None):
     train_idx, test_idx = random_split(list(range(n)), [int(prop * n), n - int(prop * n)])
     bs = args.batch_size
 
+    def trainer(kind, epochs, clip, tag):
+        return Trainer(max_epochs=epochs, gradient_clip_val=clip, patience=args.early_stopping_patience,
+                       default_root_dir=os.path.join(args.output_dir, "checkpoints", f"{kind}_{tag}"),
+                       logger_path=os.path.join(args.output_dir, f"{kind}_{tag}_log.jsonl"),
+                       precision=args.precision, strategy=args.strategy, sync_batchnorm=args.sync_batchnorm)
+
     def fit(kind, module, train_loader, val_loader, epochs, clip, tag):
-        tr = Trainer(max_epochs=epochs, gradient_clip_val=clip, patience=args.early_stopping_patience,
-                     default_root_dir=os.path.join(args.output_dir, "checkpoints", f"{kind}_{tag}"),
-                     logger_path=os.path.join(args.output_dir, f"{kind}_{tag}_log.jsonl"),
-                     precision=args.precision, strategy=args.strategy, sync_batchnorm=args.sync_batchnorm)
+        tr = trainer(kind, epochs, clip, tag)
         tr.fit(module, train_loader, val_loader)
         return tr
+
+    def fit_both(wave_job, time_job, epochs, tag):
+        """the wave fit (no clipping) and the time fit (gradient clipping) of one stage (scripts/...:200-224, :290-309): the
+        reference runs them one after the other; here concurrently on two streams with the same random draws, unless
+        --sequential-fits (or a multi-rank run, whose collectives must be issued in one order on every rank)"""
+        trw, trt = trainer("wave", epochs, None, tag), trainer("time", epochs, args.gradient_clip_val, tag)
+        jobs = [(trw,) + wave_job, (trt,) + time_job]
+        if args.sequential_fits or world > 1:
+            for tr, mod, tl, vl in jobs:
+                tr.fit(mod, tl, vl)
+        else:
+            fit_concurrently(jobs)
+        return trw, trt
 
     wave_net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=50, class_hidden_dim=5, num_sources=num_sources, num_classes=5)
     time_net = hippieUnimodalCVAE(z_dim=args.z_dim, output_size=100, class_hidden_dim=5, num_sources=num_sources, num_classes=5)
@@ -185,8 +220,9 @@ def main(argv=None, eps_source=None):
     # the unimodal branch builds its modules WITHOUT beta= (scripts/...:178-183), so --beta is ignored here too
     wave_mod = hippieUnimodalEmbeddingModelCVAE(wave_net, learning_rate=args.learning_rate, weight_decay=args.weight_decay)
     time_mod = hippieUnimodalEmbeddingModelCVAE(time_net, learning_rate=args.learning_rate, weight_decay=args.weight_decay)
-    trw = fit("wave", wave_mod, all_wave.loader(train_idx, bs, True), all_wave.loader(test_idx, bs, False), args.pretrain_max_epochs, None, "pretrain")
-    trt = fit("time", time_mod, all_time.loader(train_idx, bs, True), all_time.loader(test_idx, bs, False), args.pretrain_max_epochs, args.gradient_clip_val, "pretrain")
+    trw, trt = fit_both((wave_mod, all_wave.loader(train_idx, bs, True), all_wave.loader(test_idx, bs, False)),
+                        (time_mod, all_time.loader(train_idx, bs, True), all_time.loader(test_idx, bs, False)),
+                        args.pretrain_max_epochs, "pretrain")
     if trw.best_model_path:
         wave_mod.load_state_dict(torch.load(trw.best_model_path, weights_only=False)["state_dict"])
     if trt.best_model_path:
@@ -205,8 +241,8 @@ def main(argv=None, eps_source=None):
         wave_mod = hippieUnimodalEmbeddingModelCVAE(wave_mod.model, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay)
         time_mod = hippieUnimodalEmbeddingModelCVAE(time_mod.model, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay)
         lw, lt = ft_wave.loader(tr_i, bs, False), ft_time.loader(tr_i, bs, False)
-        fit("wave", wave_mod, lw, ft_wave.loader(te_i, bs, False), args.finetune_max_epochs, None, "finetune")
-        fit("time", time_mod, lt, ft_time.loader(te_i, bs, False), args.finetune_max_epochs, args.gradient_clip_val, "finetune")
+        fit_both((wave_mod, lw, ft_wave.loader(te_i, bs, False)), (time_mod, lt, ft_time.loader(te_i, bs, False)),
+                 args.finetune_max_epochs, "finetune")
     else:
         lw, lt = ft_wave.loader(range(m), bs, False), ft_time.loader(range(m), bs, False)
     wave_mod.eval()

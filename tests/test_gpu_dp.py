@@ -293,9 +293,12 @@ def test_trainer_ddp_two_ranks_equals_two_single_rank_oracles(tmp_path):
         assert np.abs(a - b).max() <= 2.2 * lr * steps + 1e-7, k
         if re.search(H.ZERO_GRAD_RE, k):
             continue
+        # UNMASKED comparison at 8 rows per rank: besides Adam's +-lr on noise-level gradients, a leaky-ReLU sign that differs
+        # from the float64 oracle's changes upstream gradients by a few per cent, i.e. the Adam update by a few per cent of lr
+        # per step.  A wrong shard, synced statistics or a missing all-reduce would move MOST elements by ~lr per step.
         gk = np.abs(mean[k].numpy().reshape(-1))
-        bad = (np.abs(a - b) > 1e-4 * np.abs(b) + 0.02 * lr) & (gk > 1e-2 * gk.max())
-        assert bad.mean() <= 2e-3, f"{k}: {bad.sum()} of {bad.size} elements with significant gradient differ"
+        bad = (np.abs(a - b) > 1e-4 * np.abs(b) + 0.25 * lr) & (gk > 1e-2 * gk.max())
+        assert bad.mean() <= 2e-2, f"{k}: {bad.sum()} of {bad.size} elements with significant gradient differ by more than a quarter step"
     for k, v in sd.items():          # rank 0's BatchNorm running statistics are the ones checkpointed: they follow rank 0's shards
         if "running_" in k:
             H.assert_close(v, oms[0].state[k].detach().numpy(), 1e-4, k)

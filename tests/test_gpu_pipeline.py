@@ -128,16 +128,24 @@ def test_inference_script_roundtrip(tmp_path):
 # training steps with validation + top-1 checkpoint reload, label-free fine-tune with a fresh AdamW at lr/10,
 # row-standardised `enc` embeddings — on a prescribed reparameterisation-noise sequence.
 class _Noise:
-    """closed-form noise for the k-th forward of a run (same values on both sides)"""
+    """closed-form noise for the k-th forward of one MODEL of a run (same values on both sides).  One stream per model: the
+    pipeline fits the wave and the time model concurrently (hippie_amd.trainer.fit_concurrently), so a stream shared by both
+    would be consumed in a scheduling-dependent order."""
 
-    def __init__(self):
-        self.k = 0
+    def __init__(self, name=""):
+        self.k, self.name = 0, name
 
     def draw(self, B, z):
         from oracle import cvae_oracle as O
-        e = sum(O.unit_noise(f"pipe.eps{i}", B * z, salt=self.k) for i in range(4)) * (3.0 / 4.0) ** 0.5
+        e = sum(O.unit_noise(f"pipe.{self.name}.eps{i}", B * z, salt=self.k) for i in range(4)) * (3.0 / 4.0) ** 0.5
         self.k += 1
         return torch.from_numpy(e.reshape(B, z)).float()
+
+
+def keyed_noise():
+    """({"wave": _Noise, "time": _Noise}, eps_source for pretrain_pipeline.main): the engine's input length tells the model"""
+    noise = {"wave": _Noise("wave"), "time": _Noise("time")}
+    return noise, (lambda eng: noise["wave" if eng.cfg.output_size == 50 else "time"].draw(eng.B, eng.cfg.z_dim).to(eng.device))
 
 
 def _oracle_fit(om, noise, train_batches, val_batches, epochs, lr, clip):
@@ -190,9 +198,9 @@ def test_pipeline_numbers_match_the_oracle_walking_the_same_steps(tmp_path):
     argv = ["--dataset", "cellexplorer-celltype", "--data-root", str(data), "--output-dir", str(out), "--batch-size", str(bs),
             "--pretrain-max-epochs", str(epochs), "--finetune-max-epochs", "2", "--z_dim", str(z), "--learning-rate", str(lr)]
     # ---- the product pipeline on the prescribed noise
-    noise = _Noise()
-    paths = pp.main(argv, eps_source=lambda eng: noise.draw(eng.B, eng.cfg.z_dim).to(eng.device))
-    n_forwards = noise.k
+    noise, eps_source = keyed_noise()
+    paths = pp.main(argv, eps_source=eps_source)
+    n_forwards = {k: v.k for k, v in noise.items()}
     # ---- the oracle, same steps
     torch.manual_seed(42)
     pool = pp.pretrain_pool("cellexplorer-celltype")
@@ -218,7 +226,7 @@ def test_pipeline_numbers_match_the_oracle_walking_the_same_steps(tmp_path):
             elif k.endswith("num_batches_tracked"):
                 om.state[k].zero_()
         oms[kind] = om
-    noise2 = _Noise()
+    noise2 = {"wave": _Noise("wave"), "time": _Noise("time")}
 
     def batches_of(tab, idx, shuffle):
         loader = DataLoader(list(idx), batch_size=bs, shuffle=shuffle)
@@ -226,7 +234,7 @@ def test_pipeline_numbers_match_the_oracle_walking_the_same_steps(tmp_path):
 
     lab_of = lab
     for kind, clip in (("wave", None), ("time", 1.0)):
-        best = _oracle_fit(oms[kind], noise2, batches_of(tabs[kind], tr_idx, True), batches_of(tabs[kind], te_idx, False), epochs, lr, clip)
+        best = _oracle_fit(oms[kind], noise2[kind], batches_of(tabs[kind], tr_idx, True), batches_of(tabs[kind], te_idx, False), epochs, lr, clip)
         oms[kind].load(best)
         for k in ("num_batches_tracked",):
             pass
@@ -241,9 +249,9 @@ def test_pipeline_numbers_match_the_oracle_walking_the_same_steps(tmp_path):
     for kind, clip in (("wave", None), ("time", 1.0)):
         om = oms[kind]
         om.exp_avg, om.exp_avg_sq, om.step_count = {}, {}, 0
-        _oracle_fit(om, noise2, batches_of(ft[kind], ft_tr, False), batches_of(ft[kind], ft_te, False), 2, lr / 10, clip)
+        _oracle_fit(om, noise2[kind], batches_of(ft[kind], ft_tr, False), batches_of(ft[kind], ft_te, False), 2, lr / 10, clip)
         # (the pipeline does NOT reload a checkpoint after fine-tuning: the embeddings come from the final weights)
-    assert noise2.k == n_forwards, "the oracle walked a different number of forwards than the pipeline"
+    assert {k: v.k for k, v in noise2.items()} == n_forwards, "the oracle walked a different number of forwards than the pipeline"
     embs = {}
     for kind in ("wave", "time"):
         rows = []

@@ -99,7 +99,7 @@ def test_damaged_files_are_refused(tmp_path):
 def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph):
     """tests/c_host/host_step.c — C99, only include/hippie_hip.h — against the Python engine on the same file and inputs."""
     from hippie_amd.engine import Engine
-    z, L, L2, B, lr, clip = 10, 50, 100, 16, 1e-4, 1.0
+    z, L, L2, B, lr, clip = 10, 50, 100, 16, 1e-6, 1.0      # (a small lr: Adam turns last-bit gradient differences — atomic sums — into +-lr moves)
     plan, om, path, pv, bv = _export(tmp_path, kind, z, L, B, L2, salt=4, clip=clip, lr=lr)
     x, src, cls, eps = O.synth_inputs(B, L, z, salt=4, name="x1" if kind == "multimodal" else "x")
     parts = [x.numpy().astype(np.float32).tobytes()]
@@ -129,7 +129,7 @@ def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph):
     for _ in range(steps):
         eng.train_step(use_graph=False)
         want.append(eng.scalars())
-    np.testing.assert_allclose(got, np.array(want), rtol=2e-6)        # same kernels; only the order of atomic sums differs
+    np.testing.assert_allclose(got, np.array(want), rtol=1e-5)        # same kernels; only the order of atomic sums differs
     enc = eng.io("enc_train").double()
     tail = dict(ln.split(" sum ") for ln in lines if " sum " in ln)
     s, s2 = (float(v) for v in tail["enc_train"].replace("sumsq ", "").split())
