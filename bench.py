@@ -68,42 +68,51 @@ class Pair:
     models' kernels).  (A zipped two-model program on one stream was built in round 2 and measured slower — 98.3 k vs
     113.8 k samples/s: nothing hides the launch floors on a single stream — and removed in round 3)"""
 
-    def __init__(self, device, world, lr=1e-3, lens=(50, 100), overlap=False, lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True):
-        self.device, self.world, self.overlap, self.lockstep = device, world, overlap, lockstep
+    def __init__(self, device, world, lr=1e-3, lens=(50, 100), lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True,
+                 model_type="unimodal"):
+        self.device, self.world, self.lockstep = device, world, lockstep
         self.only = None          # --only-model: step one of the two models (how much of the pair step is overlap?)
-        cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
-        tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws),
-               planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, split_backward=overlap, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws)]
+        self.multimodal = model_type == "multimodal"
+        if self.multimodal:
+            # MultiModalCVAE + MultiModalCVAETrainModule (hippie/model.py:350-533): ONE model with two encoder / decoder towers, one
+            # optimisation step per batch; the script's multimodal trainer clips gradients (scripts/...:701)
+            cfgs = [planner.ModelCfg(kind="multimodal", z_dim=Z_DIM, output_size=lens[0], output_size2=lens[1])]
+            tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws)]
+        else:
+            cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
+            tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws),
+                   planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws)]
         self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
         self.groups = None
         if world > 1 or os.environ.get("HIPPIE_FORCE_DIST"):
-            import torch.distributed as dist
-            # one communicator: the two models' all-reduces are issued in the same order on every rank and
-            # serialise on its stream (the wave model's backward finishes first anyway)
-            self.groups = [dist.group.WORLD for _ in self.eng]
+            self.use_world_group()
         self.init_params()
 
+    def use_world_group(self):
+        """gradient mean-all-reduce between bwd and opt over the default process group.  One communicator: the two models'
+        all-reduces are issued in the same order on every rank and serialise on its stream (the wave model's backward
+        finishes first anyway); each one overlaps the OTHER model's kernels, which run on their own stream."""
+        import torch.distributed as dist
+        self.groups = [dist.group.WORLD for _ in self.eng]
+
+    def stage(self, k, e, data, idx):
+        """gather the batch by index from the HBM-resident tables into the engine's input slots; draw eps"""
+        if self.multimodal:
+            e.io("x").copy_(data[0].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
+            e.io("x2").copy_(data[1].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
+        else:
+            e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
+        e.io("src").copy_(data[2].index_select(0, idx), non_blocking=True)
+        e.io("eps").normal_()
+
     def init_params(self):
-        """torch default init (kaiming-uniform bound 1/sqrt(fan_in); BN weight 1 / bias 0; Embedding N(0,1))."""
+        """the reference constructors' initialisation (hippie_amd.model.reference_init_state: kaiming-uniform(a=sqrt 5) weights,
+        U(+-1/sqrt(fan_in)) biases, BatchNorm 1 / 0, Embedding N(0,1)) from a fixed seed"""
+        from hippie_amd.model import reference_init_state
         g = torch.Generator(device="cpu").manual_seed(42)
         for e in self.eng:
-            sd = {}
-            for k, info in e.plan.params.items():
-                shp = info.shape
-                if k.endswith("embedding.weight"):
-                    v = torch.randn(shp, generator=g)
-                elif len(shp) == 1 and any(s in k for s in (".bn1.", ".bn2.", "shortcut.1.", "_fc.1.", "_fc.3.", "_fc.4.")):
-                    v = torch.ones(shp) if k.endswith("weight") else torch.zeros(shp)
-                else:
-                    fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else None
-                    if fan_in is None:                      # bias of the layer declared just before
-                        wkey = k[:-4] + "weight"
-                        fan_in = int(np.prod(e.plan.params[wkey].shape[1:]))
-                    bound = 1.0 / np.sqrt(fan_in)
-                    v = (torch.rand(shp, generator=g) * 2 - 1) * bound
-                sd[k] = v
-            e.load_state_dict(sd, strict=False)
+            e.load_state_dict(reference_init_state(e.cfg, g), strict=False)
 
     def fork(self):
         """The model streams start after whatever is queued on the current stream."""
@@ -127,17 +136,12 @@ class Pair:
             if self.only is not None and k != self.only:
                 continue
             with torch.cuda.stream(s):
-                e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1), non_blocking=True)
-                e.io("src").copy_(data[2].index_select(0, idx), non_blocking=True)
-                e.io("eps").normal_()
-                if self.groups is None and not self.overlap:
+                self.stage(k, e, data, idx)
+                if self.groups is None:
                     e.train_step(use_graph)              # one process: nothing sits between bwd and opt -> one graph per step
                     continue
                 e.forward(True, use_graph)
-                if self.groups is not None:
-                    parallel.backward_allreduce(e, self.groups[k], use_graph, self.overlap)
-                else:
-                    e.backward(use_graph, overlap=self.overlap)
+                parallel.backward_allreduce(e, self.groups[k], use_graph)
                 e.optimizer_step(use_graph)
         if self.lockstep:
             self.join()
@@ -179,9 +183,7 @@ def profile_ops(pair, data, idx, reps=5):
     rows = []
     progs = []
     for k, e in enumerate(pair.eng):
-        e.io("x").copy_(data[k].index_select(0, idx).view(BATCH, 1, -1))
-        e.io("src").copy_(data[2].index_select(0, idx))
-        e.io("eps").normal_()
+        pair.stage(k, e, data, idx)
         progs.append((k, e.ops, e.plan.ops.segments, e.plan.ops.notes,
                       (lambda seg, e=e: e.prog.profile(*e.plan.ops.segments[seg], torch.cuda.current_stream().cuda_stream))))
     for model, ops, segments, notes, prof in progs:
@@ -444,7 +446,6 @@ def main():
     ap.add_argument("--no-trainer", action="store_true", help="skip the secondary reference-API (Trainer.fit) throughput measurement")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-reuse-ws", action="store_true", help="every workspace tensor in memory of its own (A/B against the liveness-packed arena)")
-    ap.add_argument("--overlap", action="store_true", help="decoder-side wgrad + first gradient bucket on a side stream (measured slower on ROCm 7: DESIGN.md 5.3)")
     ap.add_argument("--only-model", type=int, choices=(0, 1), default=None, help="diagnostic: step only the wave (0) or the time (1) model; the line is then NOT the headline metric")
     ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
@@ -459,6 +460,11 @@ def main():
     ap.add_argument("--wave-len", type=int, default=50)
     ap.add_argument("--time-len", type=int, default=100)
     ap.add_argument("--units", type=int, default=15631)
+    ap.add_argument("--model-type", choices=["unimodal", "multimodal"], default="unimodal",
+                    help="unimodal (default, the headline): the wave + time cVAE pair.  multimodal: ONE MultiModalCVAE step per batch "
+                         "(BASELINE configs[4]'s per-rank shape: --model-type multimodal --batch 8192 --z-dim 64 --wave-len 256 --time-len 32): "
+                         "a NON-DEFAULT, separately labelled line")
+    ap.add_argument("--no-dp-probe", action="store_true", help="skip the 1-rank RCCL data-parallel overhead probe (N=1 only)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one child process per GPU BEFORE anything in this
@@ -497,8 +503,8 @@ def main():
     n_ranks_seen = dist.get_world_size() if (world > 1 or force_dist) else 1      # what the communicator says, not the flag
     dist_backend = dist.get_backend() if (world > 1 or force_dist) else None
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
-    pair = Pair(device, world, lens=(args.wave_len, args.time_len), overlap=args.overlap, lockstep=args.lockstep,
-                fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws)
+    pair = Pair(device, world, lens=(args.wave_len, args.time_len), lockstep=args.lockstep,
+                fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type)
     pair.only = args.only_model
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
@@ -533,8 +539,43 @@ def main():
         dt = float(tt.item())
     loss = [e.scalars()[0] for e in pair.eng]
 
+    def timed(n):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        pair.fork()
+        for i in range(n):
+            pair.step(data, batch_idx(args.warmup + i), use_graph)
+        pair.join()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
+
+    dp_probe = None
+    if world == 1 and not force_dist and not args.no_dp_probe and not args.no_profile and pair.only is None:
+        # What the data-parallel structure costs BEFORE any wire time: the same step with a 1-rank RCCL communicator in place —
+        # three graphs per model-step instead of one, ncclAllReduce(AVG) of the gradient arena between bwd and opt on the
+        # communicator's stream (a copy onto itself at one rank).  N > 1 adds only the transfer time on top of this.
+        try:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ["HIPPIE_FORCE_DIST"] = "1"
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            pair.use_world_group()
+            timed(args.warmup)
+            dt_dp = timed(args.steps)
+            dp_probe = {"ms_per_step": dt_dp / args.steps * 1e3, "value": BATCH * args.steps / dt_dp, "ratio_to_value": dt / dt_dp,
+                        "how": "same step with a 1-rank RCCL (nccl) all-reduce of each model's gradient arena between bwd and opt (3 graph "
+                               "replays per model-step); N > 1 adds the xGMI transfer on the communicator's stream, overlapped with the other model"}
+            dist.destroy_process_group()
+        except Exception as ex:                 # never lose the line over a secondary figure
+            dp_probe = {"error": repr(ex)[:200]}
+        finally:
+            os.environ.pop("HIPPIE_FORCE_DIST", None)
+            pair.groups = None
+
+    METRIC = "pretrain samples/sec (waveform+time cVAE, batch 512) at 1/2/4/8 MI355X"
     if rank == 0 and args.no_profile:
-        out = {"metric": "pretrain samples/sec (waveform+time cVAE, batch 512) at 1/2/4/8 MI355X", "value": BATCH * world * args.steps / dt,
+        out = {"metric": METRIC, "value": BATCH * world * args.steps / dt,
                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "note": "--no-profile run (counter collection): no roofline fields"}
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
@@ -566,7 +607,7 @@ def main():
         except Exception as ex:          # never lose the line over the secondary figure
             b2b = {"error": repr(ex)[:200]}
         out = {
-            "metric": "pretrain samples/sec (waveform+time cVAE, batch 512) at 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": BATCH * world * args.steps / dt,
             "unit": "samples/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
@@ -577,10 +618,14 @@ def main():
                                    ("BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
                                     "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "
                                     "fp32 arithmetic on f32 MFMA (the reference's arithmetic type; the config's bf16 wording is a separate, labelled mode)")
-                       if (args.batch, args.z_dim, args.wave_len, args.time_len) == (512, 10, 50, 100) else
-                       f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units",
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "wgrad_overlap": pair.overlap, "lockstep": pair.lockstep,
-                       "final_loss_wave": loss[0], "final_loss_time": loss[1],
+                       if (args.batch, args.z_dim, args.wave_len, args.time_len, args.model_type) == (512, 10, 50, 100, "unimodal") else
+                       (f"NON-DEFAULT (NOT the headline): ONE MultiModalCVAE (hippie/model.py:350-432) step per batch of {args.batch} units — wave L={args.wave_len} + "
+                        f"time L={args.time_len} towers, z_dim={args.z_dim}, clip 1.0, {N_UNITS} synthetic units; BASELINE configs[4]'s per-rank shape "
+                        "when --batch 8192 --z-dim 64 --wave-len 256 --time-len 32" if args.model_type == "multimodal" else
+                        f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units"),
+                       "model_type": args.model_type,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "lockstep": pair.lockstep,
+                       "final_loss_wave": loss[0], "final_loss_time": loss[-1],
                        # every HIPPIE_* variable of this run (measurement knobs act only under HIPPIE_DEBUG_KNOBS=1): {} = the product defaults
                        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("HIPPIE_")}},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
@@ -602,11 +647,12 @@ def main():
                          # whole-step view: samples/s x 3 x forward FLOPs per unit, all kernels and gaps included
                          "whole_step_tflops_per_gpu": BATCH * args.steps / dt * 3.0 * sum(e.plan.flops_fwd for e in pair.eng) / BATCH / 1e12},
         }
-        if world == 1 and not args.no_trainer:
+        out["dp_overhead_1rank"] = dp_probe
+        if world == 1 and not args.no_trainer and args.model_type == "unimodal":
             tr = trainer_rate(device, data) if args.dtype == "f32" else None
             out["trainer_samples_per_s"] = tr["value"] if tr else None
             out["trainer_path"] = tr
-        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only (the other ranks would sit in the barrier)
+        if not args.no_cpu_baseline and world == 1 and args.model_type == "unimodal":       # reported at N=1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if world > 1 or force_dist:

@@ -27,7 +27,6 @@ class Engine:
         self.cfg, self.B, self.with_class = cfg, batch, with_class
         self.train_cfg = train or planner.TrainCfg()
         self._graphs = {}
-        self._side = None
         self._sync_cache = {}
         self.sync_group = None          # process group of the sync-BatchNorm collectives (None = WORLD)
         # Provider of the reparameterisation noise when set_inputs() is not handed one: None = torch's device generator
@@ -261,36 +260,10 @@ class Engine:
         mulv = self.io("mulv_eval")
         return self.io("enc_eval"), mulv[:, :z], mulv[:, z:]
 
-    def backward(self, use_graph=False, overlap=False, after_first_half=None):
+    def backward(self, use_graph=False):
         """Backward pass.  Exactly one per training forward: its BatchNorm reductions accumulate into the fp64
-        statistic slots that the forward's first op zeroes, so a second backward would double them.
-        overlap=True runs the decoder-side weight-gradient GEMMs ("wg_a") on a second HIP
-        stream underneath the encoder-side chain ("bwd_b"): the chain is latency-bound (one small launch after
-        another), the grouped GEMM fills the CUs it leaves idle.  `after_first_half(side_stream)` is called
-        with the side stream current once "wg_a" is enqueued (data parallel: all-reduce that gradient bucket
-        there, see Plan.grad_bucket_a); the main stream joins the side stream before this returns."""
-        if not overlap:
-            self.run("bwd", use_graph)
-            if after_first_half is not None:
-                after_first_half(torch.cuda.current_stream(self.device))
-            return
-        if not self.train_cfg.split_backward:
-            raise HipEngineError("backward(overlap=True) needs TrainCfg(split_backward=True)")
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
-            self._ev = (torch.cuda.Event(), torch.cuda.Event())
-        cur = torch.cuda.current_stream(self.device)
-        self.run("bwd_a", use_graph)
-        self._ev[0].record(cur)
-        self._side.wait_event(self._ev[0])
-        with torch.cuda.stream(self._side):
-            self.run("wg_a", use_graph)
-            if after_first_half is not None:
-                after_first_half(self._side)
-            self._ev[1].record(self._side)
-        self.run("bwd_b", use_graph)
-        self.run("wg_b", use_graph)
-        cur.wait_event(self._ev[1])
+        statistic slots that the forward's first op zeroes, so a second backward would double them."""
+        self.run("bwd", use_graph)
 
     def optimizer_step(self, use_graph=False):
         self.run("opt", use_graph)

@@ -61,34 +61,28 @@ def broadcast_(tensors, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
-def backward_allreduce(engine, group=None, use_graph=True, overlap=False):
-    """Backward + gradient mean over ranks.  Default: the whole active arena in one collective after the
-    backward pass.  overlap=True uses two buckets: the decoder-side one (Plan.grad_bucket_a, about half of the
-    32 MB arena) is final after the first half of the backward pass and is all-reduced on the engine's side
-    stream while the encoder-side chain still runs; the rest follows on the main stream (same order on every
-    rank).  On ROCm 7 the extra stream costs more than the overlap gains at N=1, hence opt-in."""
+def backward_allreduce(engine, group=None, use_graph=True):
+    """Backward + gradient mean over ranks: the whole active arena in one collective after the backward pass, on the
+    communicator's stream.  What overlaps it is the OTHER model: the wave and the time cVAE step on two HIP streams, so one
+    model's all-reduce runs under the other's kernels (north_star: "overlapped with the backward encoder GEMM").  Round 2
+    also had a two-bucket form that reduced the decoder-side half of ONE model's gradients on a side stream under that model's
+    encoder-side chain; the side stream's grid-filling weight-gradient launch stalls every small kernel of the chain behind
+    its workgroups (linear_bwd_x 6 -> 32 us, profiles/r03_overlap_timeline.txt): 90.7 k vs 115.7 k samples/s.  Removed."""
     e = engine
-    if not overlap or not e.train_cfg.split_backward:
-        e.backward(use_graph)
-        allreduce_mean_(e.grads[: e.plan.n_active], group)
-        return
-    lo, hi = e.plan.grad_bucket_a
-    e.backward(use_graph, overlap=overlap, after_first_half=lambda _s: allreduce_mean_(e.grads[lo:hi], group))
-    allreduce_mean_(e.grads[:lo], group)
-    if e.plan.n_active > hi:
-        allreduce_mean_(e.grads[hi: e.plan.n_active], group)       # class_embedding rows
+    e.backward(use_graph)
+    allreduce_mean_(e.grads[: e.plan.n_active], group)
 
 
 class DataParallelEngine:
-    """Wraps an Engine: train_step = forward + backward (+ overlapped all-reduce(mean)) + AdamW."""
+    """Wraps an Engine: train_step = forward + backward + all-reduce(mean) + AdamW."""
 
-    def __init__(self, engine, group=None, overlap=False):
-        self.engine, self.group, self.overlap = engine, group, overlap
+    def __init__(self, engine, group=None):
+        self.engine, self.group = engine, group
         broadcast_([engine.params, engine.bufs, engine.m, engine.v], 0, group)
 
     def train_step(self, use_graph=True):
         e = self.engine
         e.forward(True, use_graph)
-        backward_allreduce(e, self.group, use_graph, self.overlap)
+        backward_allreduce(e, self.group, use_graph)
         e.optimizer_step(use_graph)
         return e.io("scalars")

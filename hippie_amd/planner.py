@@ -75,8 +75,6 @@ class TrainCfg:
                                         # reduction runs in the epilogue of the input-gradient conv that produces its operand
                                         # (HP_CONV_EPI_BNRED).  False: one launch per BatchNorm pass (HP_OP_BN_APPLY / BN_BWD_REDUCE)
     sync_bn_world: int = 0              # > 1: sync-BatchNorm over that many data-parallel ranks (HP_OP_STATS_SYNC markers)
-    split_backward: bool = False        # emit the deferred wgrad GEMMs in two groups (decoder | encoder side) so that
-                                        # Engine.backward(overlap=True) can run the first under the encoder-side chain
     mfma_dtype: str = "f32"             # "f32": the reference's arithmetic (parity path, v_mfma_f32_32x32x2_f32).  "bf16": BASELINE config 2's
                                         # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
                                         # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
@@ -844,11 +842,10 @@ class Lowering:
         else:
             self.o.add(op, flags, i=i, f=f, buf=buf, note=note)
 
-    def flush_wgrads(self, seg, only_if=True):
-        """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, in their own segment
-        (an empty segment, with the GEMMs left pending, when only_if is False)."""
-        self.o.begin(seg)
-        for ntaps in (3, 1) if only_if else ():
+    def flush_wgrads(self):
+        """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, then the deferred small leaves as one
+        small-leaf group (inside the open segment)."""
+        for ntaps in (3, 1):
             mem = [w_ for w_ in self.pending_wgrads if len(w_[0].taps) == ntaps]
             if not mem:
                 continue
@@ -857,7 +854,7 @@ class Lowering:
                 self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag, i=tm.ints() + [nsplit, rps, w.numel],
                            f=[SLOPE_BACKBONE], buf=[dy, x, w.gref, coef], note=note)
             self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
-        if only_if and self.pending_small:
+        if self.pending_small:
             n = len(self.pending_small)
             for j, (op, flags, i, f, buf, note) in enumerate(self.pending_small):
                 if n > 1:
@@ -865,9 +862,7 @@ class Lowering:
                     note += " [grouped]" if j < n - 1 else f" [group of {n} small weight gradients]"
                 self.o.add(op, flags, i=i, f=f, buf=buf, note=note)
             self.pending_small = []
-        if only_if:
-            self.pending_wgrads = []
-        self.o.end()
+        self.pending_wgrads = []
 
     # ---- whole model ---------------------------------------------------------------
     def build(self):
@@ -899,10 +894,6 @@ class Lowering:
             decs.append(self.declare_decoder(dpre, osz))
         self.cemb = pl.param("class_embedding.weight", (cfg.num_classes, H))    # LAST: skipped by AdamW without class labels
         pl.n_active = pl.n_param_floats if self.with_class else _round_up(self.cemb.offset, 4)
-        # gradient range that is final once "bwd_a" + "wg_a" have run (decoder heads + decoder); the embeddings
-        # and everything in front of it are finished by "bwd_b" + "wg_b"
-        first_dec = names[0][0] + ".0.weight"
-        pl.grad_bucket_a = (pl.params[first_dec].offset, self.cemb.offset) if self.train.split_backward else None
         # the floats between n_active and cemb.offset (alignment gap) are zero padding
 
         # ---------------- workspace: persistent + I/O ----------------
@@ -1005,10 +996,10 @@ class Lowering:
             segs["train_zero"] = zero_idx
 
             # ---------------- backward ----------------
-            # Two halves, each followed by its deferred weight-gradient GEMMs, so that a caller may run "wg_a"
-            # (decoder side) on a second stream underneath "bwd_b" (encoder side): bwd_a, wg_a, bwd_b, wg_b.
-            # "bwd" names the whole range; running it serially is equivalent.
-            self.o.begin("bwd_a")
+            # decoder side first, then heads and encoder(s); the weight-gradient GEMMs and the small leaf reductions are deferred
+            # to the end of the segment (flush_wgrads): one grouped launch each.  (Round 2 could split the pass in two halves and run
+            # the decoder-side group on a second stream under the encoder-side chain — measured slower, removed: DESIGN.md.)
+            self.o.begin("bwd")
             nb = pl.n_param_floats * 4
             self.o.add(P.ZERO, 0, i=[nb & 0xFFFFFFFF, nb >> 32], buf=[Ref(P.GRAD, 0)], note="zero gradients")
             dc1 = pl.f32(B * ncat1)
@@ -1019,9 +1010,6 @@ class Lowering:
                 du3 = pl.f32(B * 2 * z)
                 self.linear_bwd(B, fc["f2"], du4, 2 * z, hd["u3"], 2 * z, du3, 2 * z, mask=hd["u3"], ldmask=2 * z, note="decoder_fc.2")
                 self.linear_bwd(B, fc["f0"], du3, 2 * z, c1, ncat1, dc1, ncat1, accumulate=(k > 0), note="decoder_fc.0")
-            self.o.end()
-            self.flush_wgrads("wg_a", only_if=self.train.split_backward)
-            self.o.begin("bwd_b")
             self.emb_bwd(dc1, ncat1, z)
             dmulv = pl.f32(B * 2 * z)
             self.o.add(P.REPARAM_KL_BWD, 0, i=[B, z, ncat1], f=[self.train.beta], buf=[mulv, eps, dc1, dmulv], note="reparameterize + KL bwd")
@@ -1043,10 +1031,8 @@ class Lowering:
                 dh = dc0 + 4 * (2 * z * k)      # column window of dc0, leading dimension ncat
                 self.linear_bwd(B, lin, dh, ncat, e["pooled"], 512, dpooled, 512, note=e["prefix"] + "linear")
                 self.encoder_bwd(e, dpooled)
+            self.flush_wgrads()
             self.o.end()
-            self.flush_wgrads("wg_b")
-            first_bwd = self.o.segments["bwd_a"][0]
-            self.o.segments["bwd"] = (first_bwd, len(self.o.recs) - first_bwd)      # the four sub-segments in program order
 
             # ---------------- optimiser ----------------
             self.o.begin("opt")
@@ -1098,11 +1084,11 @@ class Lowering:
             elif int(r["op"]) == P.SLAB_REDUCE:
                 r["buf"][0] = slab.encode()
         if self.train.reuse_workspace and not P.debug_knob("HIPPIE_NO_WS_REUSE"):     # (the knob: A/B runs of unmodified callers)
-            pack_workspace(pl, serial_backward=not self.train.split_backward)
+            pack_workspace(pl)
         return pl
 
 
-def pack_workspace(pl, serial_backward=True):
+def pack_workspace(pl):
     """Liveness-based reuse of the workspace arena (arena colouring over op intervals).
 
     Two classes of allocations are packed, each into a region of its own: those that only records of the backward pass
@@ -1112,8 +1098,7 @@ def pack_workspace(pl, serial_backward=True):
     the end of the backward pass — and two allocations share memory only when one is dead strictly before the other is
     born.  Everything else (training-forward tensors, which the backward pass reads; named I/O slots; the statistics
     region; the slabs) keeps memory of its own, so training and eval passes may be interleaved in any order.
-    `serial_backward=False` (the decoder-side weight gradients may run on a second stream under the encoder-side chain)
-    leaves the backward class alone.  Rewrites the records, plan.io and plan.act_sites."""
+    Rewrites the records, plan.io and plan.act_sites."""
     import bisect
     recs = pl.ops.recs
     segs = pl.ops.segments
@@ -1171,7 +1156,7 @@ def pack_workspace(pl, serial_backward=True):
         if pinned[j] or len(users[j]) != 1:
             continue
         (u,) = users[j]
-        if u == "fwd_eval" or (u == "bwd" and serial_backward):
+        if u in ("fwd_eval", "bwd"):
             classes[u].append(j)
 
     new_off = {}
@@ -1257,7 +1242,6 @@ def lower_backbone(spec: BackboneCfg, batch: int, train: TrainCfg = None) -> Pla
     else:
         raise ValueError(f"unknown backbone module {kind!r}")
     pl.n_active = pl.n_param_floats
-    pl.grad_bucket_a = None
     pl.stats_cap = 32 << 20
     pl.stats_base = pl.ws(pl.stats_cap).offset
     x = pl.f32(xn, "x", xshape)

@@ -87,14 +87,10 @@ def test_planner_programs_validate_without_gpu(kind):
     rc, msg = _create(bad, sizes)
     assert rc != 0 and "required" in msg
     segs = plan.ops.segments
-    assert set(segs) == {"fwd_train", "bwd", "bwd_a", "wg_a", "bwd_b", "wg_b", "opt", "fwd_eval", "enc_eval", "step"}
-    assert sum(c for k, (_, c) in segs.items() if k not in ("bwd", "enc_eval", "step")) == len(ops)
+    assert set(segs) == {"fwd_train", "bwd", "opt", "fwd_eval", "enc_eval", "step"}
+    assert sum(c for k, (_, c) in segs.items() if k not in ("enc_eval", "step")) == len(ops)
     assert segs["step"] == (segs["fwd_train"][0], segs["fwd_train"][1] + segs["bwd"][1] + segs["opt"][1])      # alias: the whole step
     assert segs["enc_eval"][0] == segs["fwd_eval"][0] and 0 < segs["enc_eval"][1] < segs["fwd_eval"][1]
-    # "bwd" is exactly the four sub-segments in program order
-    parts = [segs[k] for k in ("bwd_a", "wg_a", "bwd_b", "wg_b")]
-    assert parts[0][0] == segs["bwd"][0] and sum(c for _, c in parts) == segs["bwd"][1]
-    assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(3))
 
 
 def test_product_path_fails_loudly_without_gpu():

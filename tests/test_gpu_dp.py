@@ -30,10 +30,10 @@ def _worker(rank, world, port, q):
     from hippie_amd.engine import Engine
     from oracle import cvae_oracle as O
     z, L, B = 10, 50, 16
-    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=1.0, split_backward=True))
+    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=1.0))
     om = O.OracleModel("unimodal", z, L, salt=rank)          # different init per rank: broadcast must fix it
     eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
-    dp = parallel.DataParallelEngine(eng, overlap=True)
+    dp = parallel.DataParallelEngine(eng)
     n = 64
     x, src, cls, eps = O.synth_inputs(n, L, z, salt=5)
     ok_grad = True
@@ -48,10 +48,10 @@ def _worker(rank, world, port, q):
         parallel.allreduce_mean_(eng.grads[: eng.plan.n_active], None, 2)
         want = (gathered[0] + gathered[1]) / 2
         ok_grad &= bool(torch.allclose(eng.grads[: eng.plan.n_active], want[: eng.plan.n_active], rtol=1e-6, atol=1e-8))
-        # the overlapped, two-bucket path (side stream + all-reduce under the encoder-side chain) gives the same
-        # mean up to the summation order of the fp32 atomics in the weight-gradient GEMMs
+        # backward_allreduce (what DataParallelEngine and bench.py call) gives the same mean up to the summation order of
+        # the fp32 atomics in the weight-gradient GEMMs
         eng.forward(True, True)              # one backward per forward (the BN-backward statistic slots are zeroed by the forward): run it again
-        parallel.backward_allreduce(eng, None, True, overlap=True)
+        parallel.backward_allreduce(eng, None, True)
         torch.cuda.synchronize()
         got, ref = eng.grads[: eng.plan.n_active], want[: eng.plan.n_active]
         ok_grad &= bool((got - ref).abs().max() <= 2e-5 * ref.abs().max())
@@ -262,6 +262,11 @@ def test_trainer_ddp_two_ranks_equals_two_single_rank_oracles(tmp_path):
     oms = [O.OracleModel("unimodal", z, L, dtype=torch.float64) for _ in range(world)]
     for om in oms:
         om.load({k: torch.from_numpy(v) for k, v in r0[7].items()})           # rank 0's constructor initialisation, broadcast to all
+        for k in om.state:                                                     # BatchNorm buffers of a fresh module
+            if k.endswith("running_mean") or k.endswith("num_batches_tracked"):
+                om.state[k].zero_()
+            elif k.endswith("running_var"):
+                om.state[k].fill_(1.0)
     for epoch in range(2):
         shards = [shard_indices(n, r, world, epoch=epoch, seed=3) for r in range(world)]
         for i in range(0, n // world, B):

@@ -21,9 +21,9 @@ def n(t):
     return t.detach().cpu().numpy()
 
 
-def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, split=False, fuse_bn=True):
+def build(kind, z, L, B, with_class, beta, clip, lr, salt, L2=None, w1=1.0, w2=1.0, fuse_bn=True):
     cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=L, output_size2=L2 or 100)
-    tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2, split_backward=split,
+    tc = planner.TrainCfg(lr=lr, weight_decay=0.01, beta=beta, clip=clip or 0.0, w1=w1, w2=w2,
                           fuse_bn=fuse_bn)
     eng = Engine(cfg, B, tc, with_class=with_class)
     oms = []
@@ -362,30 +362,6 @@ def test_ragged_batches_and_lengths(B, L):
     sd = eng.state_dict()
     assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
     assert eng.adam_step == 1
-
-
-def test_overlapped_backward_equals_serial():
-    """Engine.backward(overlap=True): decoder-side wgrad on a side stream under the encoder-side chain."""
-    eng, oms, batch, batch64, eps = build("unimodal", 10, 100, 64, True, 1.0, 1.0, 1e-3, 3, split=True)
-    plain = build("unimodal", 10, 100, 64, True, 1.0, 1.0, 1e-3, 3)[0]
-    with pytest.raises(Exception, match="split_backward"):
-        plain.backward(overlap=True)
-    for use_graph in (False, True):
-        eng.forward(True, use_graph)
-        eng.backward(use_graph)
-        torch.cuda.synchronize()
-        want = eng.grads.clone()
-        eng.forward(True, use_graph)          # one backward per forward (the BN-backward statistic slots are zeroed by the forward)
-        eng.backward(use_graph, overlap=True)
-        torch.cuda.synchronize()
-        scale = want.abs().max()
-        assert (eng.grads - want).abs().max() <= 2e-5 * scale      # fp32 atomics order only
-        lo, hi = eng.plan.grad_bucket_a
-        seen = []
-        eng.forward(True, use_graph)
-        eng.backward(use_graph, overlap=True, after_first_half=lambda s: seen.append(eng.grads[lo:hi].clone()))
-        torch.cuda.synchronize()
-        assert (seen[0] - want[lo:hi]).abs().max() <= 2e-5 * scale, "bucket A not final after the first half"
 
 
 def test_eval_rows_are_independent_of_batch_composition_at_config3_size():

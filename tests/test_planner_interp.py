@@ -141,48 +141,6 @@ def test_forward_flop_count_matches_survey_probe():
         assert pl.flops_fwd // 4 == want, (L, z, pl.flops_fwd // 4)
 
 
-@pytest.mark.parametrize("kind", ["unimodal", "multimodal"])
-def test_backward_halves_commute_and_first_bucket_is_final(kind):
-    """The overlapped schedule (Engine.backward(overlap=True)) runs wg_a beside bwd_b + wg_b: any interleaving
-    must give the serial result, and the gradient bucket [grad_bucket_a) must be final after bwd_a + wg_a."""
-    B, z = 4, 10
-    cfg = planner.ModelCfg(kind=kind, z_dim=z, output_size=50, output_size2=100)
-    plan = planner.lower(cfg, B, planner.TrainCfg(clip=1.0, split_backward=True), with_class=True)
-    ops = plan.ops.array()
-    om = O.OracleModel(kind, z, 50, output_size2=100 if kind == "multimodal" else None, salt=2)
-    x, src, cls, eps = O.synth_inputs(B, 50, z, salt=2, name="x1")
-    x2 = O.synth_inputs(B, 100, z, salt=2, name="x2")[0]
-
-    def fresh():
-        A = H.make_arenas(plan)
-        H.load_state(plan, A, om.state)
-        H.set_io(plan, A, "x", x.numpy())
-        if kind == "multimodal":
-            H.set_io(plan, A, "x2", x2.numpy())
-        for nm, v in (("src", src), ("cls", cls), ("eps", eps)):
-            H.set_io(plan, A, nm, v.numpy())
-        interp.run(ops, A, *plan.ops.segments["fwd_train"])
-        return A
-    serial = fresh()
-    interp.run(ops, serial, *plan.ops.segments["bwd"])
-    want = serial.mem[P.GRAD].view(np.float32).copy()
-    A = fresh()
-    interp.run(ops, A, *plan.ops.segments["bwd_a"])
-    interp.run(ops, A, *plan.ops.segments["bwd_b"])
-    interp.run(ops, A, *plan.ops.segments["wg_b"])
-    interp.run(ops, A, *plan.ops.segments["wg_a"])
-    np.testing.assert_array_equal(A.mem[P.GRAD].view(np.float32), want)
-    A = fresh()
-    interp.run(ops, A, *plan.ops.segments["bwd_a"])
-    interp.run(ops, A, *plan.ops.segments["wg_a"])
-    lo, hi = plan.grad_bucket_a
-    assert 0 < lo < hi <= plan.n_active and np.abs(want[lo:hi]).max() > 0
-    np.testing.assert_array_equal(A.mem[P.GRAD].view(np.float32)[lo:hi], want[lo:hi])
-    # ... and nothing in front of the bucket has been touched by the first half except embeddings' rows
-    first_dec = [k for k in plan.params if k.startswith("decoder_fc")][0]
-    assert plan.params[first_dec].offset == lo
-
-
 def run_lockstep(plan, ops, arenas, seg):
     """Data-parallel ranks in lock step on the interpreter: at every HP_OP_STATS_SYNC marker the slot is summed
     over the ranks' arenas — what Engine.run does with an all-reduce in sync-BatchNorm mode."""

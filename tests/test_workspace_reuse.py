@@ -109,12 +109,3 @@ def test_shared_memory_only_between_disjoint_live_ranges():
             shared += 1
             assert sa[1] < sb[0] or sb[1] < sa[0], f"[{lo},{hi}) records {sa} and [{lo2},{hi2}) records {sb} overlap in memory and in time"
     assert shared > 0, "nothing is shared: the pass did not run"
-
-
-def test_overlapped_backward_keeps_the_backward_class_unpacked():
-    """split_backward: the decoder-side weight gradients may run on a second stream under the encoder-side chain, so
-    program order is not execution order for the backward pass; only the eval forward is packed."""
-    cfg, B, _ = CASES["wave"]
-    a = planner.lower(cfg, B, planner.TrainCfg(split_backward=True))
-    b = planner.lower(cfg, B, planner.TrainCfg(split_backward=False))
-    assert b.ws_bytes < a.ws_bytes < a.ws_unpacked
