@@ -69,19 +69,24 @@ class Pair:
     113.8 k samples/s: nothing hides the launch floors on a single stream — and removed in round 3)"""
 
     def __init__(self, device, world, lr=1e-3, lens=(50, 100), lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True,
-                 model_type="unimodal"):
+                 model_type="unimodal", staged=True, rank=0):
         self.device, self.world, self.lockstep = device, world, lockstep
+        # staged: the synthetic tables are RESIDENT in each engine's workspace and every step's batch gather + eps draw is the first
+        # launch of the step's graph (HP_OP_STAGE_BATCH): one graph replay per model-step, no torch kernel inside the timed region.
+        # False (--no-staged, A/B): torch index_select / copy_ / normal_ in front of every step, as in rounds 1-2.
+        self.staged = staged
+        res = dict(resident_units=N_UNITS, dp_world=world, dp_rank=rank) if staged else {}
         self.only = None          # --only-model: step one of the two models (how much of the pair step is overlap?)
         self.multimodal = model_type == "multimodal"
         if self.multimodal:
             # MultiModalCVAE + MultiModalCVAETrainModule (hippie/model.py:350-533): ONE model with two encoder / decoder towers, one
             # optimisation step per batch; the script's multimodal trainer clips gradients (scripts/...:701)
             cfgs = [planner.ModelCfg(kind="multimodal", z_dim=Z_DIM, output_size=lens[0], output_size2=lens[1])]
-            tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws)]
+            tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws, **res)]
         else:
             cfgs = [planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[0]), planner.ModelCfg(kind="unimodal", z_dim=Z_DIM, output_size=lens[1])]
-            tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws),
-                   planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws)]
+            tcs = [planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws, **res),
+                   planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws, **res)]
         self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
         self.groups = None
@@ -95,6 +100,14 @@ class Pair:
         finishes first anyway); each one overlaps the OTHER model's kernels, which run on their own stream."""
         import torch.distributed as dist
         self.groups = [dist.group.WORLD for _ in self.eng]
+
+    def load_tables(self, data, perm):
+        """staged mode: the tables, the shuffle and a noise seed into every engine's workspace (once, before the timed region)"""
+        for k, e in enumerate(self.eng):
+            if self.multimodal:
+                e.load_dataset(data[0], data[2], x2=data[1], perm=perm, seed=1234)
+            else:
+                e.load_dataset(data[k], data[2], perm=perm, seed=1234 + k)
 
     def stage(self, k, e, data, idx):
         """gather the batch by index from the HBM-resident tables into the engine's input slots; draw eps"""
@@ -136,11 +149,17 @@ class Pair:
             if self.only is not None and k != self.only:
                 continue
             with torch.cuda.stream(s):
-                self.stage(k, e, data, idx)
-                if self.groups is None:
-                    e.train_step(use_graph)              # one process: nothing sits between bwd and opt -> one graph per step
-                    continue
-                e.forward(True, use_graph)
+                if self.staged:
+                    if self.groups is None:
+                        e.train_step_staged(use_graph)   # gather + eps + fwd + bwd + opt: ONE graph replay, nothing else on the stream
+                        continue
+                    e.staged_forward(use_graph)
+                else:
+                    self.stage(k, e, data, idx)
+                    if self.groups is None:
+                        e.train_step(use_graph)          # one process: nothing sits between bwd and opt -> one graph per step
+                        continue
+                    e.forward(True, use_graph)
                 parallel.backward_allreduce(e, self.groups[k], use_graph)
                 e.optimizer_step(use_graph)
         if self.lockstep:
@@ -187,7 +206,9 @@ def profile_ops(pair, data, idx, reps=5):
         progs.append((k, e.ops, e.plan.ops.segments, e.plan.ops.notes,
                       (lambda seg, e=e: e.prog.profile(*e.plan.ops.segments[seg], torch.cuda.current_stream().cuda_stream))))
     for model, ops, segments, notes, prof in progs:
-        for seg in ("fwd_train", "bwd", "opt"):
+        for seg in ("stage", "fwd_train", "bwd", "opt"):
+            if seg not in segments:
+                continue
             first, count = segments[seg]
             prof(seg)                                   # untimed: first eager launches load code objects / build tables
             acc = np.median(np.stack([prof(seg) for _ in range(reps)]), axis=0).astype(np.float64)      # median: robust against a stray slow launch
@@ -464,6 +485,8 @@ def main():
                     help="unimodal (default, the headline): the wave + time cVAE pair.  multimodal: ONE MultiModalCVAE step per batch "
                          "(BASELINE configs[4]'s per-rank shape: --model-type multimodal --batch 8192 --z-dim 64 --wave-len 256 --time-len 32): "
                          "a NON-DEFAULT, separately labelled line")
+    ap.add_argument("--no-staged", action="store_true", help="A/B: stage every batch with torch kernels (index_select / copy_ / normal_) instead of the "
+                    "in-graph HP_OP_STAGE_BATCH over workspace-resident tables")
     ap.add_argument("--no-dp-probe", action="store_true", help="skip the 1-rank RCCL data-parallel overhead probe (N=1 only)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -504,7 +527,8 @@ def main():
     dist_backend = dist.get_backend() if (world > 1 or force_dist) else None
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
     pair = Pair(device, world, lens=(args.wave_len, args.time_len), lockstep=args.lockstep,
-                fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type)
+                fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type,
+                staged=not args.no_staged, rank=rank)
     pair.only = args.only_model
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
@@ -515,6 +539,8 @@ def main():
         return perm[j * BATCH:(j + 1) * BATCH]
 
     use_graph = not args.no_graph
+    if pair.staged:
+        pair.load_tables(data, perm)
     pair.fork()
     for i in range(args.warmup):
         pair.step(data, batch_idx(i), use_graph)
@@ -624,7 +650,7 @@ def main():
                         "when --batch 8192 --z-dim 64 --wave-len 256 --time-len 32" if args.model_type == "multimodal" else
                         f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units"),
                        "model_type": args.model_type,
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "lockstep": pair.lockstep,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "staged_in_graph": pair.staged, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "lockstep": pair.lockstep,
                        "final_loss_wave": loss[0], "final_loss_time": loss[-1],
                        # every HIPPIE_* variable of this run (measurement knobs act only under HIPPIE_DEBUG_KNOBS=1): {} = the product defaults
                        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("HIPPIE_")}},

@@ -1224,6 +1224,65 @@ __global__ __launch_bounds__(256) void zero_kernel(uint4* p16, size_t n16, uint8
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p16[i] = z;
   if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
 }
+// ---- HP_OP_STAGE_BATCH: index gather from HBM-resident tables + Philox reparameterisation noise --------------------------
+struct StageArgs {
+  const float* table; const float* table2; const int64_t* labels; const int64_t* perm; const int64_t* cursor; const int64_t* seed;
+  float* x; float* x2; int64_t* src; float* eps;
+  int B, L, L2, z, spe, world, rank, N;
+};
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so a step's noise is a pure function of (seed, cursor, element)
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+__global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs p) {
+  const long id = (long)blockIdx.x * 256 + threadIdx.x;
+  const uint64_t cur = (uint64_t)p.cursor[0];
+  const long j = (long)(cur % (uint64_t)p.spe) * p.world + p.rank;
+  const long nx = (long)p.B * p.L, nx2 = (long)p.B * p.L2;
+  auto row_of = [&](int b) -> long {
+    const int64_t r = p.perm[j * p.B + b];
+    return (r >= 0 && r < (int64_t)p.N) ? (long)r : 0;
+  };
+  if (id < nx) {
+    const int b = (int)(id / p.L), c = (int)(id - (long)b * p.L);
+    p.x[id] = p.table[row_of(b) * p.L + c];
+    return;
+  }
+  long q = id - nx;
+  if (q < nx2) {
+    const int b = (int)(q / p.L2), c = (int)(q - (long)b * p.L2);
+    p.x2[q] = p.table2[row_of(b) * p.L2 + c];
+    return;
+  }
+  q -= nx2;
+  if (q < p.B) {
+    p.src[q] = p.labels[row_of((int)q)];
+    return;
+  }
+  q -= p.B;
+  const long ne = (long)p.B * p.z;
+  if (q * 4 < ne) {
+    const uint64_t sd = (uint64_t)p.seed[0];
+    const uint4 v = philox4x32_10(make_uint4((uint32_t)cur, (uint32_t)(cur >> 32), (uint32_t)q, 0u), make_uint2((uint32_t)sd, (uint32_t)(sd >> 32)));
+    const float r0 = sqrtf(-2.f * logf(u01(v.x))), r1 = sqrtf(-2.f * logf(u01(v.z)));
+    float s0, c0, s1, c1;
+    sincosf(6.28318530717958647692f * u01(v.y), &s0, &c0);
+    sincosf(6.28318530717958647692f * u01(v.w), &s1, &c1);
+    const float n4[4] = {r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (q * 4 + t < ne) p.eps[q * 4 + t] = n4[t];
+  }
+}
+
 __global__ void step_inc_kernel(int64_t* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1; }
 
 inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / per); }
@@ -1596,6 +1655,16 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     case HP_OP_STEP_INC:
       hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, ptr<int64_t>(op, 0, bases));
       break;
+    case HP_OP_STAGE_BATCH: {
+      StageArgs a;
+      a.table = ptr<const float>(op, 0, bases); a.table2 = ptr<const float>(op, 1, bases); a.labels = ptr<const int64_t>(op, 2, bases);
+      a.perm = ptr<const int64_t>(op, 3, bases); a.cursor = ptr<const int64_t>(op, 4, bases); a.x = ptr<float>(op, 5, bases);
+      a.x2 = ptr<float>(op, 6, bases); a.src = ptr<int64_t>(op, 7, bases); a.eps = ptr<float>(op, 8, bases); a.seed = ptr<const int64_t>(op, 9, bases);
+      a.B = I[0]; a.L = I[1]; a.L2 = a.table2 != nullptr ? I[2] : 0; a.z = I[3]; a.spe = I[4]; a.world = I[5]; a.rank = I[6]; a.N = I[7];
+      const int64_t items = (int64_t)a.B * a.L + (int64_t)a.B * a.L2 + a.B + ((int64_t)a.B * a.z + 3) / 4;
+      hipLaunchKernelGGL(stage_batch_kernel, dim3(blocks_for(items)), dim3(256), 0, s, a);
+      break;
+    }
     case HP_OP_ZERO: {
       uint8_t* dst = ptr<uint8_t>(op, 0, bases);
       const size_t nbytes = (size_t)(uint32_t)I[0] + ((size_t)(uint32_t)I[1] << 32);

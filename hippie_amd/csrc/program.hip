@@ -254,6 +254,14 @@ int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
     case HP_OP_ZERO: need[0] = (int64_t)(uint32_t)I[0] + ((int64_t)(uint32_t)I[1] << 32); break;
     case HP_OP_RESAMPLE_LINEAR: need[0] = (int64_t)I[0] * I[1] * f4; need[1] = (int64_t)I[0] * I[2] * f4; break;
     case HP_OP_STATS_SYNC: need[0] = (int64_t)I[0] * f8; break;
+    case HP_OP_STAGE_BATCH: {
+      const int64_t B = I[0], L = I[1], L2 = I[2], z = I[3], N = I[7];
+      need[0] = N * L * f4; if (L2 > 0) need[1] = N * L2 * f4;
+      need[2] = N * f8; need[3] = (int64_t)I[4] * I[5] * B * f8; need[4] = f8;
+      need[5] = B * L * f4; if (L2 > 0) need[6] = B * L2 * f4;
+      need[7] = B * f8; need[8] = B * z * f4; need[9] = f8;
+      break;
+    }
     default: break;
   }
   return 0;
@@ -306,6 +314,13 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
       why = buf;
       return 1;
     }
+  }
+  if (op.op == HP_OP_STAGE_BATCH && (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] < 0 || op.i[3] <= 0 || op.i[4] <= 0 || op.i[5] <= 0 || op.i[6] < 0 ||
+                                     op.i[6] >= op.i[5] || op.i[7] <= 0)) {
+    snprintf(buf, sizeof buf, "op %d: bad STAGE_BATCH shape (B=%d L=%d L2=%d z=%d batches=%d world=%d rank=%d N=%d)", index, op.i[0], op.i[1], op.i[2],
+             op.i[3], op.i[4], op.i[5], op.i[6], op.i[7]);
+    why = buf;
+    return 1;
   }
   if (op.op == HP_OP_WGRAD_GROUP && (op.i[0] < 0 || op.i[1] <= 0 || op.i[0] + op.i[1] > index || (op.i[2] != 1 && op.i[2] != 3))) {
     snprintf(buf, sizeof buf, "op %d: bad wgrad group range [%d, +%d) taps %d", index, op.i[0], op.i[1], op.i[2]);

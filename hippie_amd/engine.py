@@ -239,6 +239,15 @@ class Engine:
         else:
             self.prog.run(first, count, self._stream())
 
+    def capture_segments(self, names=("fwd_train", "bwd", "opt", "fwd_eval", "enc_eval")):
+        """Capture the named segments into hipGraphs now (they are otherwise captured on first use)."""
+        for seg in names:
+            if seg in self.plan.ops.segments and seg not in self._graphs and self.plan.ops.segments[seg][1] > 0:
+                first, count = self.plan.ops.segments[seg]
+                if self.train_cfg.sync_bn_world > 1 and self._sync_points(first, count):
+                    continue                     # runs eagerly around its collectives
+                self._graphs[seg] = self.prog.capture(first, count)
+
     def forward(self, training=True, use_graph=False):
         mode = "train" if training else "eval"
         self.run("fwd_" + mode, use_graph)
@@ -287,6 +296,54 @@ class Engine:
         self.backward(use_graph)
         self.optimizer_step(use_graph)
         return self.io("scalars")
+
+    # ---- HBM-resident training tables (TrainCfg.resident_units) --------------------------------------------------------
+    def load_dataset(self, x, labels, x2=None, perm=None, seed=0):
+        """Copy the preprocessed training tables ([N, L] per modality, int64 source labels [N]) into the engine's workspace, set
+        the permutation the staged steps walk through (default: identity) and the noise seed; the batch cursor starts at 0."""
+        N = self.train_cfg.resident_units
+        if N <= 0:
+            raise HipEngineError("load_dataset needs TrainCfg(resident_units=N)")
+        self.io("data_x").copy_(x.reshape(N, -1))
+        if x2 is not None:
+            self.io("data_x2").copy_(x2.reshape(N, -1))
+        lo, hi = (int(v) for v in torch.aminmax(labels))
+        if lo < 0 or hi >= self.cfg.num_sources:
+            raise IndexError(f"source label out of range: values span [{lo}, {hi}] but the source embedding has {self.cfg.num_sources} rows")
+        self.io("data_labels").copy_(labels)
+        self.set_permutation(torch.arange(N) if perm is None else perm)
+        self.io("seed").fill_(int(seed))
+        self.io("cursor").zero_()
+
+    def set_permutation(self, perm):
+        """The order in which staged steps visit the units (a new shuffle per epoch is a new call, or a longer cursor walk over
+        one permutation: batch j of the walk is perm[j*B:(j+1)*B], wrapping after N // (B * dp_world) batches per rank)."""
+        p = self.io("perm")
+        if perm.numel() != p.numel():
+            raise ValueError(f"the permutation must list all {p.numel()} resident units")
+        p.copy_(perm.to(torch.int64))
+
+    def train_step_staged(self, use_graph=True):
+        """One optimisation step on the next batch of the resident tables: HP_OP_STAGE_BATCH (index gather + Philox eps) +
+        forward + backward + optimiser as ONE graph replay where nothing sits between them, else stage+forward | backward | opt
+        (the caller all-reduces between `backward` and `optimizer_step` itself: see staged_forward)."""
+        if "stage" not in self.plan.ops.segments:
+            raise HipEngineError("train_step_staged needs TrainCfg(resident_units=N)")
+        if use_graph and "step_staged" in self.plan.ops.segments and self.train_cfg.sync_bn_world <= 1:
+            self.run("step_staged", True)
+        else:
+            self.run("stage", use_graph)
+            self.run("fwd_train", use_graph)
+            self.run("bwd", use_graph)
+            self.run("opt", use_graph)
+        for p in self.num_batches_tracked:
+            self.num_batches_tracked[p] += 1
+        return self.io("scalars")
+
+    def staged_forward(self, use_graph=True):
+        """stage + training forward only (data-parallel callers: backward -> gradient all-reduce -> optimizer_step follow)"""
+        self.run("stage", use_graph)
+        return self.forward(True, use_graph)
 
     def scalars(self):
         """(loss, mse1, mse2, kl_mean) of the last forward, synchronising (= the reference's loss.item())."""

@@ -85,6 +85,12 @@ class TrainCfg:
     reuse_workspace: bool = True        # liveness-based packing of the workspace arena (pack_workspace): tensors that only the backward
                                         # pass touches share memory once dead, and so do the eval forward's; training-forward tensors
                                         # (all needed by the backward pass) and named I/O slots keep their own memory
+    resident_units: int = 0             # > 0: the training tables ([N][L] per modality + int64 labels) live in the workspace and a
+                                        # "stage" segment (HP_OP_STAGE_BATCH + cursor increment) gathers each step's batch by index from a
+                                        # resident permutation and draws eps with Philox — "step_staged" = stage + fwd_train + bwd + opt is
+                                        # then ONE graph per optimisation step with no host work in it (Engine.load_dataset / train_step_staged)
+    dp_world: int = 1                   # data-parallel interleave of the staged batches: rank r of `dp_world` takes batch j*world + r
+    dp_rank: int = 0
     optimizer: str = "adamw"            # "adamw" (model.py:93) | "schedulefree" (hippie/optimizers.py:18-209)
     warmup_steps: int = 0               # schedule-free only
     sf_r: float = 0.0
@@ -910,6 +916,11 @@ class Lowering:
         pl._boff = sf_off + 8
         self.sf_ref = Ref(P.BUF, sf_off * 4)
         pl.io["sf_state"] = (self.sf_ref, (4,), "f8")
+        # batch cursor + noise seed of the staged steps (int64 each); always present, like the scalars above
+        cur_off = _round_up(pl._boff, 4)
+        pl._boff = cur_off + 4
+        cursor, seed = Ref(P.BUF, cur_off * 4), Ref(P.BUF, cur_off * 4 + 8)
+        pl.io["cursor"], pl.io["seed"] = (cursor, (1,), "i8"), (seed, (1,), "i8")
         lens = [cfg.output_size] if not multi else [cfg.output_size, cfg.output_size2]
         xs = [pl.f32(B * L, "x" if i == 0 else "x2", (B, 1, L)) for i, L in enumerate(lens)]
         self.src = pl.ws(8 * B, "src", (B,), "i8")
@@ -919,6 +930,22 @@ class Lowering:
         self.slab = pl.ws(0)                 # sized at the end (placed last)
         loss = pl.stat(4, replicated=False)
         norm2 = pl.stat(1, replicated=False)
+        # ---------------- resident training tables + the staging segment ----------------
+        N = int(self.train.resident_units)
+        if N > 0:
+            W, R = max(1, int(self.train.dp_world)), int(self.train.dp_rank)
+            spe = N // (B * W)               # whole batches per epoch and rank (the ragged tail of a permutation is dropped)
+            if spe < 1 or not 0 <= R < W:
+                raise ValueError(f"resident_units={N}: need at least batch * dp_world = {B * W} units and 0 <= dp_rank < dp_world")
+            tabs = [pl.f32(N * L, "data_x" if i == 0 else "data_x2", (N, L)) for i, L in enumerate(lens)]
+            dlab = pl.ws(8 * N, "data_labels", (N,), "i8")
+            perm = pl.ws(8 * N, "perm", (N,), "i8")
+            self.o.begin("stage")
+            self.o.add(P.STAGE_BATCH, 0, i=[B, lens[0], lens[1] if multi else 0, z, spe, W, R, N],
+                       buf=[tabs[0], tabs[1] if multi else None, dlab, perm, cursor, xs[0], xs[1] if multi else None, self.src, eps, seed],
+                       note="gather the batch by index + Philox eps")
+            self.o.add(P.STEP_INC, 0, buf=[cursor], note="batch cursor += 1")
+            self.o.end()
 
         segs = {}
         for mode in ("train", "eval"):
@@ -1066,6 +1093,9 @@ class Lowering:
             o0, oc = self.o.segments["opt"]
             if f0 + fc == b0 and b0 + bc == o0:
                 self.o.segments["step"] = (f0, fc + bc + oc)
+                if "stage" in self.o.segments and sum(self.o.segments["stage"]) == f0:
+                    # gather + eps + forward + backward + optimiser: one graph per optimisation step, nothing of the host in it
+                    self.o.segments["step_staged"] = (self.o.segments["stage"][0], self.o.segments["stage"][1] + fc + bc + oc)
             if t.optimizer == "schedulefree":
                 # AdamWScheduleFree.eval() / .train(): y <-> x swaps (hippie/optimizers.py:82-103)
                 for seg, w in (("sf_eval", 1.0 - 1.0 / t.beta1), ("sf_train", 1.0 - t.beta1)):

@@ -25,7 +25,7 @@ assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
 (CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
  POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
  REPARAM_KL_BWD, MSE_FWD_BWD, TAIL_FWD, TAIL_BWD_X, TAIL_BWD_W, LOSS_FINALIZE, GRADNORM, ADAMW, STEP_INC,
- ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR, SF_SCHEDULE, ADAMW_SF, LERP, STATS_SYNC) = range(1, 36)
+ ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR, SF_SCHEDULE, ADAMW_SF, LERP, STATS_SYNC, STAGE_BATCH) = range(1, 37)
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
@@ -217,6 +217,14 @@ def _check(lib, rc, what):
         raise HipEngineError(f"{what}: {lib.hp_last_error().decode()}")
 
 
+# Stream capture is exclusive: while one thread captures a range into a hipGraph no other thread of this process may run,
+# replay or capture a program (on ROCm 7 a foreign launch during a thread-local capture ends it with "operation failed due
+# to a previous error during capture").  Concurrent fits (hippie_amd.trainer.fit_concurrently) additionally capture
+# everything they will replay BEFORE their threads start.
+import threading
+_CAPTURE_LOCK = threading.RLock()
+
+
 class DeviceProgram:
     """A validated program bound to six arena base pointers."""
 
@@ -231,15 +239,18 @@ class DeviceProgram:
         _check(self.lib, rc, "hp_program_create")
 
     def run(self, first, count, stream=0):
-        _check(self.lib, self.lib.hp_program_run(self.handle, first, count, ctypes.c_void_p(stream)), "hp_program_run")
+        with _CAPTURE_LOCK:
+            _check(self.lib, self.lib.hp_program_run(self.handle, first, count, ctypes.c_void_p(stream)), "hp_program_run")
 
     def capture(self, first, count):
         seg = ctypes.c_int(-1)
-        _check(self.lib, self.lib.hp_program_capture(self.handle, first, count, ctypes.byref(seg)), "hp_program_capture")
+        with _CAPTURE_LOCK:
+            _check(self.lib, self.lib.hp_program_capture(self.handle, first, count, ctypes.byref(seg)), "hp_program_capture")
         return seg.value
 
     def replay(self, seg, stream=0):
-        _check(self.lib, self.lib.hp_program_replay(self.handle, seg, ctypes.c_void_p(stream)), "hp_program_replay")
+        with _CAPTURE_LOCK:
+            _check(self.lib, self.lib.hp_program_replay(self.handle, seg, ctypes.c_void_p(stream)), "hp_program_replay")
 
     def profile(self, first, count, stream=0):
         out = (ctypes.c_float * count)()

@@ -122,7 +122,9 @@ class Trainer:
             import torch.distributed as dist
             dist.barrier(group=self.process_group)
 
-    def fit(self, module, train_dataloaders, val_dataloaders=None):
+    def prepare(self, module):
+        """The settings `fit` applies to the module before its first step (each may re-lower the model's engines): Lightning's
+        gradient_clip_val / deterministic / precision / strategy."""
         module.trainer = self
         self._setup_distributed()
         if self.deterministic and not module.model.deterministic:
@@ -131,6 +133,9 @@ class Trainer:
         module.set_gradient_clip(self.gradient_clip_val)
         module.model.set_parallel(self.world_size, self.process_group, self.sync_batchnorm)
         module.model.set_precision(self.precision)
+
+    def fit(self, module, train_dataloaders, val_dataloaders=None):
+        self.prepare(module)
         # The asynchronous mode (device-side label flag, per-step losses kept on the device) is a property of THIS loop,
         # which raises the deferred errors at every epoch end.  Outside it — `model(...)`, `get_embeddings` after fit() —
         # nobody would, so both settings are restored on the way out: labels are range-checked on the host again
@@ -242,6 +247,18 @@ def fit_concurrently(jobs):
             if val is not None:
                 vals.append(_freeze(val))
         planned.append((_Frozen(trains), _Frozen(vals) if val is not None else None))
+    # Everything the threads will replay is lowered and captured NOW, one job after the other: stream capture does not tolerate
+    # another thread's launches (hippie_amd.program._CAPTURE_LOCK), and lowering is host work better not interleaved either.
+    for (tr, mod, _, _), (trains, vals) in zip(jobs, planned):
+        tr.prepare(mod)
+        if not mod.model.use_graph:
+            continue
+        for passes, segs in ((trains, ("fwd_train", "bwd", "opt")), (vals, ("fwd_eval",))):
+            shapes = set()
+            for batch in (passes.passes[0] if passes is not None and passes.passes else ()):
+                shapes.add((int(batch[0].shape[0]), batch[-1].ndim == 2))
+            for B_, with_class in shapes:
+                mod.model.engine(B_, with_class).capture_segments(segs)
     errors = [None] * len(jobs)
     dev = jobs[0][0]._dev(jobs[0][1])
     main = torch.cuda.current_stream(dev)

@@ -291,6 +291,20 @@ enum {
    * ranks before the next op runs.  The library executes it as a no-op; the host splits the range here and
    * issues the collective (hippie_amd/engine.py).  i[0]=count.  buf: 0 SLOT */
   HP_OP_STATS_SYNC = 35,
+  /* The loader of the hot path on HBM-resident tables + the reparameterisation noise, as one launch, so that a whole
+   * optimisation step is ONE captured graph with nothing of the host in it.  Replaces, for preprocessed tables already in
+   * HBM: DataLoader(Subset(ConcatDataset), batch_size, shuffle) index gather + default collate
+   * (scripts/train_model_with_multimodal.py:155-166) and `eps = torch.randn_like(std)` (hippie/model.py:48).
+   *   j = (CURSOR[0] mod i[4]) * i[5] + i[6]          batch number inside the epoch's permutation (i[5] = world, i[6] = rank:
+   *                                                   the DistributedSampler-style interleave of data-parallel ranks)
+   *   r = PERM[j*B + b];   X[b][:] = TABLE[r][:]  (and X2[b][:] = TABLE2[r][:]);   SRC[b] = LABELS[r]
+   *   EPS[b*z + k] = standard normal: Philox4x32-10(counter = (CURSOR lo, CURSOR hi, (b*z + k) / 4, 0), key = SEED lo, hi)
+   *                  -> 4 x u32 -> u = ((v >> 8) + 0.5) * 2^-24 -> Box-Muller pairs (sqrt(-2 ln u0) * cos / sin(2 pi u1))
+   * The op does NOT advance CURSOR: an HP_OP_STEP_INC on it follows in the program.  A PERM entry outside [0, N) reads row 0.
+   * i[0]=B i[1]=L i[2]=L2 (0 = no second table) i[3]=z i[4]=batches per epoch i[5]=world i[6]=rank i[7]=N (table rows)
+   * buf: 0 TABLE[N][L] 1 TABLE2[N][L2] 2 LABELS(int64[N]) 3 PERM(int64[>= i[4]*i[5]*B]) 4 CURSOR(int64[1])
+   *      5 X 6 X2 7 SRC(int64[B]) 8 EPS 9 SEED(int64[1]) */
+  HP_OP_STAGE_BATCH = 36,
   HP_OP__COUNT
 };
 

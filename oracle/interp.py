@@ -17,6 +17,33 @@ MASK = (1 << 56) - 1
 CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 64, 128, 256
 
 
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox4x32-10 on uint32 numpy arrays (counter words c0..c3, key k0, k1) -> four uint32 arrays."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c0, c1, c2, c3 = [np.asarray(v, dtype=np.uint64) for v in (c0, c1, c2, c3)]
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c0, M1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ np.uint64(k0), lo1, hi0 ^ c3 ^ np.uint64(k1), lo0
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return [v.astype(np.uint32) for v in (c0, c1, c2, c3)]
+
+
+def philox_normal(seed, cursor, n):
+    """HP_OP_STAGE_BATCH's noise: n standard normals for (seed, cursor) (float32; Box-Muller on 24-bit uniforms)."""
+    nq = (n + 3) // 4
+    q = np.arange(nq, dtype=np.uint64)
+    seed, cursor = int(seed) & 0xFFFFFFFFFFFFFFFF, int(cursor) & 0xFFFFFFFFFFFFFFFF
+    v = philox4x32_10(np.full(nq, cursor & 0xFFFFFFFF), np.full(nq, cursor >> 32), q, np.zeros(nq), seed & 0xFFFFFFFF, seed >> 32)
+    u = [((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0) for w in v]
+    r0, r1 = np.sqrt(np.float32(-2) * np.log(u[0])), np.sqrt(np.float32(-2) * np.log(u[2]))
+    t0, t1 = np.float32(6.28318530717958647692) * u[1], np.float32(6.28318530717958647692) * u[3]
+    out = np.stack([r0 * np.cos(t0), r0 * np.sin(t0), r1 * np.cos(t1), r1 * np.sin(t1)], axis=1).astype(np.float32)
+    return out.reshape(-1)[:n]
+
+
 def _bf16(x):
     """round float32 to the nearest bfloat16 (ties to even), returned as float32 — what v_cvt_pk_bf16_f32 does"""
     u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
@@ -499,6 +526,17 @@ def run(ops, A: Arenas, first=0, count=None):
             A.f32(b[1], N * L)[:] = resample_linear(x, L).reshape(-1)
         elif op == 35:         # STATS_SYNC: single-process no-op (the host sums the slot over ranks here)
             pass
+        elif op == 36:         # STAGE_BATCH: index gather from resident tables + Philox noise
+            B, L, L2, z, spe, world, rank, N = [int(v) for v in i[:8]]
+            cur = int(A.i64(b[4], 1)[0])
+            j = (cur % spe) * world + rank
+            rows = A.i64(b[3], spe * world * B)[j * B: (j + 1) * B].copy()
+            rows[(rows < 0) | (rows >= N)] = 0
+            A.f32(b[5], B * L)[:] = A.f32(b[0], N * L).reshape(N, L)[rows].reshape(-1)
+            if L2 > 0 and int(b[1]) != NULL:
+                A.f32(b[6], B * L2)[:] = A.f32(b[1], N * L2).reshape(N, L2)[rows].reshape(-1)
+            A.i64(b[7], B)[:] = A.i64(b[2], N)[rows]
+            A.f32(b[8], B * z)[:] = philox_normal(int(A.i64(b[9], 1)[0]), cur, B * z)
         elif op in (29, 30):   # WGRAD_GROUP / PAIR: its member WGRAD_TAPS records (just before it) were executed in place
             pass
         else:

@@ -1,5 +1,6 @@
 """GPU: the whole engine (planner -> libhippie_hip.so -> MI355X) against the CPU oracle and the
 golden vectors generated from the reference's own modules."""
+import dataclasses
 import os
 import re
 
@@ -573,3 +574,37 @@ def test_config3_training_properties_at_batch_4096():
         assert float((g1 - g2).norm() / g1.norm()) <= 2e-3
         assert torch.isfinite(g0).all()
         del eng
+
+
+def test_staged_step_is_one_graph_and_equals_the_host_staged_step():
+    """TrainCfg(resident_units=N): "step_staged" (HP_OP_STAGE_BATCH + forward + backward + optimiser, ONE hipGraph replay per
+    optimisation step, no torch kernel in it) against an engine that is handed the same rows and the same Philox noise by the
+    host: same losses and parameters, step after step, through a wrap of the permutation."""
+    from oracle import interp
+    z, L, B, N = 10, 50, 16, 80
+    cfg = planner.ModelCfg("unimodal", z, L)
+    om = O.OracleModel("unimodal", z, L, salt=17)
+    x, src, cls, _ = O.synth_inputs(N, L, z, salt=17)
+    tc = planner.TrainCfg(lr=1e-5, clip=1.0, deterministic_wgrad=True)
+    staged = Engine(cfg, B, dataclasses.replace(tc, resident_units=N))
+    plain = Engine(cfg, B, tc)
+    for e in (staged, plain):
+        e.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    perm = torch.from_numpy(np.random.default_rng(3).permutation(N))
+    staged.load_dataset(x.cuda().reshape(N, L), src.cuda(), perm=perm.cuda(), seed=99)
+    spe = N // B
+    for step in range(spe + 2):
+        staged.train_step_staged(use_graph=True)
+        rows = perm[(step % spe) * B: (step % spe + 1) * B]
+        eps = torch.from_numpy(interp.philox_normal(99, step, B * z).reshape(B, z))
+        plain.set_inputs(x[rows].cuda(), src[rows].cuda(), None, eps.cuda())
+        plain.train_step(use_graph=True)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(staged.scalars(), plain.scalars(), rtol=2e-5, err_msg=f"step {step}")
+    assert int(staged.io("cursor")[0]) == spe + 2 and staged.adam_step == plain.adam_step == spe + 2
+    a, b = staged.state_dict(), plain.state_dict()
+    for k in a:
+        if a[k].dtype.is_floating_point:
+            H.assert_adam_close(n(a[k]), n(b[k]), 1e-5, k, steps=spe + 2, frac=2e-2)
+    with pytest.raises(Exception):
+        plain.train_step_staged()

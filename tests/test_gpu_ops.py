@@ -742,3 +742,44 @@ def test_ranges_that_cut_through_a_launch_unit_are_refused():
             prog.run(first, count)
         with pytest.raises(P.HipEngineError):
             prog.capture(first, count)
+
+
+@pytest.mark.parametrize("two_tables,world,rank", [(False, 1, 0), (True, 2, 1)])
+def test_stage_batch_gathers_rows_and_draws_philox_noise(two_tables, world, rank):
+    """HP_OP_STAGE_BATCH against the interpreter: the gathered rows and labels are exact copies, the noise is the interpreter's
+    Philox stream (same uint32 words; float32 log / sqrt / sincos may differ in the last bits: 2e-6 absolute), for three
+    consecutive cursor values incl. the wrap-around, one and two tables, a rank interleave, an out-of-range index."""
+    Bn, L, L2, z, N = 37, 50, 100, 10, 200
+    img = Img(81)
+    table, table2 = img.f32(N * L), (img.f32(N * L2) if two_tables else None)
+    labels = img.i64(img.rng.integers(0, 5, N))
+    perm = img.rng.permutation(N)
+    perm[5] = N + 3                                     # an index outside the table: reads row 0, never faults
+    permr = img.i64(perm)
+    cursor, seed = img.i64([0]), img.i64([0x1234ABCD5678])
+    x, x2 = img.f32(Bn * L, zero=True), (img.f32(Bn * L2, zero=True) if two_tables else None)
+    src, eps = img.i64(np.zeros(Bn)), img.f32(Bn * z, zero=True)
+    spe = N // (Bn * world)
+    ol = P.OpList()
+    ol.add(P.STAGE_BATCH, 0, [Bn, L, L2 if two_tables else 0, z, spe, world, rank, N], (), [table, table2, labels, permr, cursor, x, x2, src, eps, seed])
+    ol.add(P.STEP_INC, 0, (), (), [cursor])
+    recs = ol.array()
+    image = img.image()
+    A = interp.Arenas([image.size, 4, 4, 4, 4, 4])
+    A.mem[0][:] = image
+    dev = torch.from_numpy(image.copy()).cuda()
+    bases = [dev.data_ptr()] + [0] * 5
+    seen = []
+    for step in range(spe + 1):
+        interp.run(recs, A)
+        for r in recs:
+            P.run_single_op(r, bases, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        gpu, cpu = dev.cpu().numpy(), A.mem[0]
+        for ref, n, dt in ((x, Bn * L, np.float32), (src, Bn, np.int64), (cursor, 1, np.int64)) + (((x2, Bn * L2, np.float32),) if two_tables else ()):
+            np.testing.assert_array_equal(view(gpu, ref, dt, n), view(cpu, ref, dt, n))
+        g, c = view(gpu, eps, np.float32, Bn * z), view(cpu, eps, np.float32, Bn * z)
+        assert np.abs(g - c).max() <= 2e-6 * max(1.0, np.abs(c).max()), np.abs(g - c).max()
+        seen.append(g.copy())
+    assert int(view(dev.cpu().numpy(), cursor, np.int64, 1)[0]) == spe + 1
+    assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[0], seen[-1]), "the noise must depend on the cursor, also across the wrap"

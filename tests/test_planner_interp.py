@@ -210,3 +210,47 @@ def test_sync_batchnorm_two_ranks_equal_the_global_batch_oracle(kind):
             assert np.abs(mine).max() < 1e-5, k
             continue
         H.parity(mine, g.numpy(), og64[k].numpy(), "sync-BN DP grad " + k)
+
+
+def test_staged_step_gathers_the_batch_and_walks_the_permutation():
+    """TrainCfg(resident_units=N): HP_OP_STAGE_BATCH + cursor increment in front of the training forward.  Through the
+    interpreter: each staged step sees exactly the rows perm[j*B:(j+1)*B] (j = (cursor mod batches) * world + rank), labels
+    follow their rows, eps is the Philox stream of (seed, cursor), and "step_staged" is the contiguous range stage..opt."""
+    B, z, L, N = 4, 10, 50, 19
+    plan = planner.lower(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(resident_units=N, dp_world=2, dp_rank=1))
+    ops = plan.ops.array()
+    segs = plan.ops.segments
+    assert segs["step_staged"] == (segs["stage"][0], segs["stage"][1] + segs["step"][1]) and sum(segs["stage"]) == segs["step"][0]
+    om = O.OracleModel("unimodal", z, L, salt=2)
+    x, src, cls, _ = O.synth_inputs(N, L, z, salt=2)
+    A = H.make_arenas(plan)
+    H.load_state(plan, A, om.state)
+    H.set_io(plan, A, "data_x", x.numpy().reshape(N, L))
+    H.set_io(plan, A, "data_labels", src.numpy())
+    perm = np.random.default_rng(0).permutation(N)
+    H.set_io(plan, A, "perm", perm)
+    H.set_io(plan, A, "seed", [77])
+    spe = N // (B * 2)
+    for step in range(2 * spe + 1):                        # wraps around the permutation
+        interp.run(ops, A, *segs["stage"])
+        j = (step % spe) * 2 + 1
+        rows = perm[j * B: (j + 1) * B]
+        np.testing.assert_array_equal(H.get_io(plan, A, "x").reshape(B, L), x.numpy().reshape(N, L)[rows])
+        np.testing.assert_array_equal(H.get_io(plan, A, "src"), src.numpy()[rows])
+        np.testing.assert_array_equal(H.get_io(plan, A, "eps").reshape(-1), interp.philox_normal(77, step, B * z))
+        assert int(H.get_io(plan, A, "cursor")[0]) == step + 1
+    with pytest.raises(ValueError):
+        planner.lower(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(resident_units=3))
+
+
+def test_philox_known_answers_and_moments():
+    """Philox4x32-10 against the published Random123 known-answer vectors; the derived normals have the right moments."""
+    z, f = np.zeros(1), np.full(1, 0xFFFFFFFF)
+    assert [int(v[0]) for v in interp.philox4x32_10(z, z, z, z, 0, 0)] == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert [int(v[0]) for v in interp.philox4x32_10(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)] == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    pi = [0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]
+    got = interp.philox4x32_10(*[np.full(1, v) for v in pi], 0xA4093822, 0x299F31D0)
+    assert [int(v[0]) for v in got] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    x = interp.philox_normal(1234, 7, 1 << 20).astype(np.float64)
+    assert abs(x.mean()) < 5e-3 and abs(x.std() - 1) < 5e-3 and abs((x ** 3).mean()) < 1e-2 and abs((x ** 4).mean() - 3) < 3e-2
+    assert not np.array_equal(interp.philox_normal(1234, 8, 64), interp.philox_normal(1234, 7, 64))
