@@ -596,11 +596,16 @@ def test_staged_step_is_one_graph_and_equals_the_host_staged_step():
     for step in range(spe + 2):
         staged.train_step_staged(use_graph=True)
         rows = perm[(step % spe) * B: (step % spe + 1) * B]
-        eps = torch.from_numpy(interp.philox_normal(99, step, B * z).reshape(B, z))
-        plain.set_inputs(x[rows].cuda(), src[rows].cuda(), None, eps.cuda())
+        # what the in-graph staging put into the input slots: the permutation's rows, exactly, and the Philox stream of (seed, step)
+        xs, ss, es = staged.io("x").clone(), staged.io("src").clone(), staged.io("eps").clone()
+        assert torch.equal(xs.cpu().reshape(B, L), x[rows].reshape(B, L)) and torch.equal(ss.cpu(), src[rows])
+        assert (es.cpu() - torch.from_numpy(interp.philox_normal(99, step, B * z).reshape(B, z))).abs().max() <= 5e-6
+        # the host-staged engine on the very same inputs (the device's float32 log / sincos differ from numpy's in the last bits, and
+        # Adam would amplify that over the steps)
+        plain.set_inputs(xs, ss, None, es)
         plain.train_step(use_graph=True)
         torch.cuda.synchronize()
-        np.testing.assert_allclose(staged.scalars(), plain.scalars(), rtol=2e-5, err_msg=f"step {step}")
+        np.testing.assert_allclose(staged.scalars(), plain.scalars(), rtol=2e-6, err_msg=f"step {step}")
     assert int(staged.io("cursor")[0]) == spe + 2 and staged.adam_step == plain.adam_step == spe + 2
     a, b = staged.state_dict(), plain.state_dict()
     for k in a:

@@ -1,13 +1,29 @@
-# bench + rocprofv3 kernel trace of the same command (GPU box only).   bash tools/measure_round.sh <tag>
+# One round's measurements on the GPU box: bench + per-op table, rocprofv3 kernel trace of the same command (+ timeline),
+# PMC passes (one counter set per run, no trace domains), the labelled secondary lines.   bash tools/measure_round.sh <tag> <git head>
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-T=${1:-r02}
+T=${1:-r03}
+O=$R/gpurun_out/$T
+mkdir -p $O
 cd $R
-timeout -k 10 400 python bench.py --steps 300 --warmup 30 --per-op > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_per_op.txt
-echo "bench done"; cut -c1-200 gpurun_out/${T}_bench.json
+timeout -k 10 400 python bench.py --steps 300 --warmup 30 --per-op > $O/${T}_bench.json 2> $O/${T}_per_op.txt
+echo "bench done: $(cut -c1-160 $O/${T}_bench.json)"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${T}_prof -o ${T} -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-trainer > $R/gpurun_out/${T}_bench_under_rocprof.json 2> $R/gpurun_out/${T}_rocprof.err
-echo "rocprof done"
-find $R/gpurun_out/${T}_prof -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/${T}_kernel_stats.csv \;
-ls $R/gpurun_out/${T}_prof/* | head
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $T -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe > $O/${T}_bench_under_rocprof.json 2> $O/${T}_rocprof.err
+find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/${T}_kernel_stats.csv \;
+find $O/prof -name "*kernel_trace.csv" -exec python3 $R/tools/timeline.py {} 50 5 \; > $O/${T}_timeline.txt 2>&1 || true
+echo "rocprof done: $(head -3 $O/${T}_timeline.txt | tail -1)"
+for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+  tag=$(echo $c | tr ' ' '_')
+  timeout -k 10 280 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-trainer --no-profile --no-dp-probe > $O/pmc_$tag.log 2>&1
+  echo "pmc pass $tag done"
+done
+cd $R
+python3 tools/pmc_summary.py $O conv_taps $O/${T}_conv_pmc.json $2
+rm -rf $O/prof $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum_TCC_MISS_sum
+timeout -k 10 200 python bench.py --dtype bf16 --steps 200 --warmup 20 --no-cpu-baseline --no-trainer --no-dp-probe > $O/${T}_bench_bf16.json 2> $O/${T}_bench_bf16.err
+timeout -k 10 300 python bench.py --batch 4096 --z-dim 32 --wave-len 256 --time-len 32 --units 16384 --steps 20 --warmup 3 --no-cpu-baseline --no-trainer --no-dp-probe --per-op > $O/${T}_bench_config3_B4096.json 2> $O/${T}_per_op_config3_B4096.txt
+timeout -k 10 300 python tools/micro/op_chain_times.py time > $O/${T}_op_chain_time_model.txt 2>&1 || true
+timeout -k 10 300 python tools/micro/op_chain_times.py wave > $O/${T}_op_chain_wave_model.txt 2>&1 || true
+ls $O

@@ -80,7 +80,7 @@ for seg in ("fwd_train", "bwd", "opt"):
         opc = int(r["op"])
         if only and OPN.get(opc) not in only:
             continue
-        nchain = (int(r["flags"]) >> P.FLAG_CHAIN_SHIFT) & P.FLAG_CHAIN_MASK
+        nchain = (int(r["flags"]) >> P.FLAG_GROUP_SHIFT) & P.FLAG_GROUP_MASK
         if opc == P.PAIR:
             mem = sorted([int(r["i"][0]), int(r["i"][1])])
         elif opc == P.WGRAD_GROUP:
