@@ -825,9 +825,12 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
 // Grouped form: ONE launch runs every weight-gradient GEMM of a backward pass.  They are independent
 // leaves whose inputs persist, so their tiles fill the chip together (no per-layer tail, fewer K-splits
 // and atomics, one launch instead of ~38).  blocks[b] = (problem, tile, split, -).
+#ifndef HP_WGRAD_PAD_FLOATS
+#define HP_WGRAD_PAD_FLOATS 0      // experiment (profiles/r03_wgrad_occupancy_ab.txt): extra LDS per workgroup caps the group launch's workgroups per CU
+#endif
 template <int NT, bool BF16 = false>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __restrict__ probs, const int4* __restrict__ blocks) {
-  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64];
+  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64 + HP_WGRAD_PAD_FLOATS];
   const int4 bi = blocks[blockIdx.x];
   const int pj = __builtin_amdgcn_readfirstlane(bi.x);
   const int tile = __builtin_amdgcn_readfirstlane(bi.y);
