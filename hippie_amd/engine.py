@@ -254,6 +254,9 @@ class Engine:
         if training:
             for p in self.num_batches_tracked:
                 self.num_batches_tracked[p] += 1
+        return self._outputs(mode)
+
+    def _outputs(self, mode):
         z = self.cfg.z_dim
         mulv = self.io("mulv_" + mode)
         outs = [self.io("enc_" + mode), mulv[:, :z], mulv[:, z:], self.io("rec_" + mode)]
@@ -342,6 +345,11 @@ class Engine:
 
     def staged_forward(self, use_graph=True):
         """stage + training forward only (data-parallel callers: backward -> gradient all-reduce -> optimizer_step follow)"""
+        if use_graph and "fwd_train_staged" in self.plan.ops.segments and self.train_cfg.sync_bn_world <= 1:
+            self.run("fwd_train_staged", True)
+            for p in self.num_batches_tracked:
+                self.num_batches_tracked[p] += 1
+            return self._outputs("train")
         self.run("stage", use_graph)
         return self.forward(True, use_graph)
 

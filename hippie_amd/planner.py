@@ -1096,6 +1096,8 @@ class Lowering:
                 if "stage" in self.o.segments and sum(self.o.segments["stage"]) == f0:
                     # gather + eps + forward + backward + optimiser: one graph per optimisation step, nothing of the host in it
                     self.o.segments["step_staged"] = (self.o.segments["stage"][0], self.o.segments["stage"][1] + fc + bc + oc)
+                    # ... and the data-parallel form (an all-reduce sits between bwd and opt): gather + eps + forward as one graph
+                    self.o.segments["fwd_train_staged"] = (self.o.segments["stage"][0], self.o.segments["stage"][1] + fc)
             if t.optimizer == "schedulefree":
                 # AdamWScheduleFree.eval() / .train(): y <-> x swaps (hippie/optimizers.py:82-103)
                 for seg, w in (("sf_eval", 1.0 - 1.0 / t.beta1), ("sf_train", 1.0 - t.beta1)):

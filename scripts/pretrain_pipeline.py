@@ -168,7 +168,8 @@ def main(argv=None, eps_source=None):
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and args.strategy != "single_device" and not dist.is_initialized():
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        # (HIPPIE_SINGLE_DEVICE: rehearsal of a multi-rank run with every rank on GPU 0 — the test suite's one-GPU box)
+        torch.cuda.set_device(0 if os.environ.get("HIPPIE_SINGLE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0")))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(os.environ.get("HIPPIE_DIST_BACKEND", "nccl"))
     rank0 = not dist.is_initialized() or dist.get_rank() == 0

@@ -783,3 +783,71 @@ def test_stage_batch_gathers_rows_and_draws_philox_noise(two_tables, world, rank
         seen.append(g.copy())
     assert int(view(dev.cpu().numpy(), cursor, np.int64, 1)[0]) == spe + 1
     assert not np.array_equal(seen[0], seen[1]) and not np.array_equal(seen[0], seen[-1]), "the noise must depend on the cursor, also across the wrap"
+
+
+def _random_tapmaps(rng, count):
+    """Seeded sweep over the tap-map family the planner can emit, with ragged sizes the fixed cases do not have: batch x length
+    products that are not multiples of the 64-row tile, column counts that end inside a tile (N % 64 != 0, N % 4 == 0), every K
+    from 32 to 512, stride 1 / 2, nearest x2 up-sampling, 1 / 3 / 6 taps, forward and transposed weights."""
+    out = []
+    while len(out) < count:
+        kind = rng.choice(["s1", "s2", "1x1", "up", "dgrad_s1", "dgrad_up"])
+        nb = int(rng.integers(1, 6))
+        K = int(rng.choice([32, 64, 96, 128, 256, 512]))
+        N = int(rng.choice([4, 36, 64, 100, 128, 192, 256]))
+        L = int(rng.integers(2, 40))
+        if kind == "s1":
+            tm, kn = TapMap(nb * L, N, K, L, L, L, 1, 0, [(t - 1, t) for t in range(3)]), False
+        elif kind == "s2":
+            Lo = (L - 1) // 2 + 1
+            tm, kn = TapMap(nb * Lo, N, K, Lo, L, L, 2, 0, [(t - 1, t) for t in range(3)]), False
+        elif kind == "1x1":
+            Lo = (L - 1) // 2 + 1
+            tm, kn = TapMap(nb * Lo, N, K, Lo, L, L, 2, 0, [(0, 0)]), False
+        elif kind == "up":
+            tm, kn = TapMap(nb * 2 * L, N, K, 2 * L, L, 2 * L, 1, 1, [(t - 1, t) for t in range(3)]), False
+        elif kind == "dgrad_s1":
+            tm, kn = TapMap(nb * L, N, K, L, L, L, 1, 0, [(1 - t, t) for t in range(3)]), True
+        else:
+            tm, kn = TapMap(nb * L, N, K, L, 2 * L, 2 * L, 2, 0, [(e - t + 1, t) for e in (0, 1) for t in range(3)]), True
+        out.append((kind, tm, kn))
+    return out
+
+
+def test_conv_taps_random_shapes():
+    rng = np.random.default_rng(2026)
+    for k, (kind, tm, w_kn) in enumerate(_random_tapmaps(rng, 36)):
+        img = Img(100 + k)
+        nb = tm.M // tm.Lout
+        a = img.f32(nb * tm.Lin * tm.K)
+        nslab = max(t[1] for t in tm.taps) + 1
+        w = img.f32(nslab * tm.N * tm.K, scale=0.1)
+        bias = bool(k % 3 == 0)
+        out = img.f32(tm.M * tm.N, scale=3.0)
+        bv = img.f32(tm.N) if bias else None
+        st = img.f64(R(tm.N) * 2 * tm.N)
+        flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_STATS
+        recs = rec_of(P.CONV_TAPS, flags, tm.conv_ints(), (), [a, w, out, bv, st])
+        gpu, cpu = run_both(img, recs)
+        what = f"random conv {k} {kind} M={tm.M} N={tm.N} K={tm.K} L={tm.Lout}"
+        check(gpu, cpu, out, tm.M * tm.N, what=what + " out")
+        check_stats(gpu, cpu, st, tm.N, what=what + " stats")
+
+
+def test_wgrad_taps_random_shapes():
+    rng = np.random.default_rng(2027)
+    for k, (kind, tm, _) in enumerate(_random_tapmaps(rng, 60)):
+        if kind.startswith("dgrad") or tm.M < 2:
+            continue
+        img = Img(300 + k)
+        nb = tm.M // tm.Lout
+        dy = img.f32(tm.M * tm.N)
+        x = img.f32(nb * tm.Lin * tm.K)
+        numel = len(tm.taps) * tm.N * tm.K
+        nsplit = int(rng.integers(1, 4))
+        rps = -(-(-(-tm.M // nsplit)) // 32) * 32
+        ns = -(-tm.M // rps)
+        grad = img.f32(numel, scale=0.5)
+        recs = rec_of(P.WGRAD_TAPS, 1, tm.ints() + [ns, rps, numel], (), [dy, x, grad])
+        gpu, cpu = run_both(img, recs)
+        check(gpu, cpu, grad, numel, rel=3e-5, what=f"random wgrad {k} {kind} M={tm.M} N={tm.N} K={tm.K} L={tm.Lout} splits={ns}")
