@@ -43,6 +43,41 @@ def test_conv_taps_bf16(name):
     check(gpu, cpu, out, tm.out_rows * tm.N, rel=2e-5, what=name + " bf16 out")
 
 
+@pytest.mark.parametrize("K,w_kn,in_bn", [(32, False, False), (96, True, False), (96, False, True), (64, False, True), (256, True, True), (128, False, True)])
+def test_conv_taps_bf16_narrow_and_wide_k_steps(K, w_kn, in_bn):
+    """K % 64 != 0 takes the 32-wide K-step body, every K the models use (multiples of 64) the 64-wide one (conv_body_bf16w) — both
+    against the interpreter on identically rounded operands, with and without the BatchNorm + leaky-ReLU input transform in the
+    loader (whose padded rows must be zeros of the ACTIVATION), ragged rows and columns."""
+    Bn, L, N = 5, 13, 100
+    tm = TapMap(Bn * L, N, K, L, L, L, 1, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)])
+    img = Img(67)
+    a = img.f32(Bn * L * K)
+    w = img.f32(3 * N * K, scale=0.1)
+    out = img.f32(tm.M * N, scale=3.0)
+    fl = (P.CONV_W_KN if w_kn else 0) | P.CONV_BF16
+    bufs = [a, w, out, None, None] + [None] * 19
+    ii = tm.conv_ints() + [0, 0]
+    ii += [0] * (40 - len(ii))
+    ff = [0.0] * 6
+    if in_bn:
+        fl |= P.CONV_IN_BN
+        st = img._put((np.stack([np.full(K, 1.5 * Bn * L), np.full(K, 9.0 * Bn * L)]).reshape(-1).astype(np.float64)))     # mean 1.5, E[x^2] 9 in replica 0
+        pad = img.f64((R(K) - 1) * 2 * K)          # the other replicas: zeros (contiguous behind replica 0)
+        gamma, beta, rm = img.f32(K), img.f32(K), img.f32(K, 0.1)
+        rv = img._put(np.abs(img.rng.standard_normal(K)).astype(np.float32) + 0.5)
+        save, coef = img.f32(2 * K, zero=True), img.f32(2 * K, zero=True)
+        ii[31], ii[32] = Bn * L, 0
+        ff[2], ff[3], ff[4] = 0.01, 1e-5, 0.1
+        bufs[5:9] = [gamma, beta, rm, rv]
+        bufs[12:15] = [st, save, coef]
+    ol = P.OpList()
+    ol.add(P.CONV_TAPS, fl, ii, ff, bufs)
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, out, tm.M * N, rel=2e-5, what=f"bf16 conv K={K} kn={w_kn} in_bn={in_bn}")
+    if in_bn:
+        check(gpu, cpu, coef, 2 * K, rel=1e-6, what="IN_BN coefficients")
+
+
 def test_bf16_mfma_operand_layouts_are_exact():
     """A = I with an asymmetric, bf16-exact weight matrix: the [N][K] path (ds_read_b128 fragments) and the [K][N] path
     (hardware transpose reads) must reproduce W bit for bit — catches swapped / transposed operand or C/D layouts."""
