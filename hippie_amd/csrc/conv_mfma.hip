@@ -308,6 +308,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
 // sit on the same SIMD pair-wise, so one wave's global loads / LDS traffic / address arithmetic overlap
 // the other's MFMAs — at batch 512 a layer has only ~256 tiles for 1024 SIMDs, so this is the only way to
 // get two waves per SIMD.  Their partial accumulators are summed once, through LDS, in the epilogue.
+// (Measured and removed, round 3: a dedicated bf16 body with a 64-wide K-step — two 16-byte pieces per operand and thread, 64 KB in flight
+// per workgroup, half the barriers — took a K = 512 layer from 19.8 to 18.2 us and the bf16 line from 185.8 k to 188.2 k samples/s
+// (+1.3 %): in bf16 mode the loop is bound by the rate at which a CU stages fp32 operands through registers into LDS (~43 GB/s per
+// CU), not by bytes in flight or barriers; only bf16-STORED operands change that.)
 // (Measured and removed, round 2: a 64-wide K-step — half the barriers and LDS round trips per MFMA, 126-128 VGPRs, 70 KB
 // of LDS — is no faster at K = 512 (38.1 us either way) and slower at K = 64 (17-18.6 vs 13.4 us: twice the prologue):
 // the per-slice barrier is not what limits the loop.)
@@ -577,192 +581,6 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4,
 }
 
 
-// ------------------------------------------------------------------------------------
-// bf16 mode, 64-wide K-step (every layer of the models: K in {64, 128, 256, 512}).  With bf16 MFMAs a 32-wide step is ONE
-// v_mfma_f32_32x32x16_bf16 per wave (32 cycles): the loop is bound by how many operand bytes a workgroup keeps in flight, not by
-// the matrix pipe (0.36 us per 32-wide step at one workgroup per CU = 16 KB / 45 GB/s).  Here a step is 64 wide — every thread
-// fetches two 16-byte pieces per operand and two slices stay in flight (64 KB per workgroup) — and costs half the barriers per
-// contraction element.  Same tap-map gather, same IN_BN transform, same epilogue as conv_body; operands are rounded to bfloat16
-// exactly as there (to_bf16x4), only the summation order inside a K-slice differs.
-// ------------------------------------------------------------------------------------
-constexpr int kLdaW = 72;                          // bf16 [row][64 k] image: 144-byte rows (16 distinct rows hit 64 distinct banks)
-constexpr int kWideA = 64 * kLdaW / 2;             // floats per A buffer (9 216 bytes)
-constexpr int kWideB = 64 * kLdtH / 2;             // floats per B buffer: [64 k][96] for [K][N] weights (12 288 bytes); the [n][64 k] image fits too
-constexpr int kConvLdsWide = 2 * kWideA + 2 * kWideB;
-
-template <bool W_KN, int MODE>
-__device__ __forceinline__ void conv_body_bf16w(const ConvArgs& p, const int bid, float* smem) {
-  constexpr bool IN_BN = MODE == 1;
-  const TapMap& t = p.t;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int quad = wave & 3, kh = wave >> 2;
-  const int wm = quad >> 1, wn = quad & 1, li = lane & 31, lh = lane >> 5;
-  const int nt = (t.N + 63) >> 6, mt = (t.M + 63) >> 6;
-  const int tile = xcd_remap(bid, mt * nt);
-  const int m0 = (tile / nt) << 6, n0 = (tile % nt) << 6;
-
-  const int ar = tid >> 3, aq = (tid & 7) << 2;      // A (and [n][k] weight) slot: row ar, 16-byte pieces at columns aq and aq + 32
-  const int kr = tid >> 4, nq = (tid & 15) << 2;     // [k][n] weight slot: rows kr and kr + 32, columns nq .. nq + 3
-  const int m_row = m0 + ar;
-  const bool rvalid = m_row < t.M;
-  const int b_row = m_row / t.Lout;
-  const int rbase = b_row * t.Lin;
-  const int rl = t.a * (m_row - b_row * t.Lout);
-
-  const int kper = t.K >> 6;
-  const int nsteps = t.ntaps * kper;
-  const size_t wslab = (size_t)t.N * t.K;
-
-  struct Pref { float4 a0, a1, b0, b1; int kq; };
-  const float* pa; const float* pb;
-  int ia, ha, ib, hb;            // per-step advance and offset of the second piece (0 for rows that read the zero page)
-  int n_tap = 0, kc = 0;
-  auto set_tap = [&](int tap) {
-    const int to = t.tap_o[tap];
-    const bool second = t.tap_src[tap] != 0;
-    const float* wp = (second ? p.W2 : p.W) + (size_t)t.tap_w[tap] * wslab;
-    const float* ap = second ? p.A2 : p.A;
-    const int pos = rl + to;
-    const bool oa = rvalid && pos >= 0 && pos < t.P;
-    pa = oa ? ap + (size_t)(rbase + (pos >> t.sh)) * t.K + aq : hp_zero16;
-    ia = oa ? 64 : 0; ha = oa ? 32 : 0;
-    if (!W_KN) {
-      const bool ob = n0 + ar < t.N;
-      pb = ob ? wp + (size_t)(n0 + ar) * t.K + aq : hp_zero16;
-      ib = ob ? 64 : 0; hb = ob ? 32 : 0;
-    } else {
-      const bool ob = n0 + nq < t.N;
-      pb = ob ? wp + (size_t)kr * t.N + n0 + nq : hp_zero16;
-      ib = ob ? 64 * t.N : 0; hb = ob ? 32 * t.N : 0;
-    }
-  };
-  set_tap(0);
-  auto advance = [&]() {
-    pa += ia; pb += ib;
-    if (++kc == kper) {
-      kc = 0;
-      if (++n_tap < t.ntaps) set_tap(n_tap);
-    }
-  };
-  auto fetch = [&]() -> Pref {
-    Pref r;
-    r.a0 = gload4(pa); r.a1 = gload4(pa + ha);
-    r.b0 = gload4(pb); r.b1 = gload4(pb + hb);
-    r.kq = (ia ? 0 : 2 * t.K) + kc * 64 + aq;          // a padded row reads (scale, shift) = (0, 0): its activation is exactly 0
-    advance();
-    return r;
-  };
-  const float* s_coef = smem + kConvLdsWide;
-  const bool in_bn = IN_BN && p.in_bn;
-  const float in_slope = p.in_slope;
-  auto transform = [&](float4 v, int kq) -> float4 {
-    const float4 sc = *reinterpret_cast<const float4*>(s_coef + kq), sh = *reinterpret_cast<const float4*>(s_coef + t.K + kq);
-    const float vx = fmaf(v.x, sc.x, sh.x), vy = fmaf(v.y, sc.y, sh.y), vz = fmaf(v.z, sc.z, sh.z), vw = fmaf(v.w, sc.w, sh.w);
-    return make_float4(fmaxf(vx, vx * in_slope), fmaxf(vy, vy * in_slope), fmaxf(vz, vz * in_slope), fmaxf(vw, vw * in_slope));
-  };
-  auto stash = [&](int buf, Pref r) {
-    __bf16* Ah = reinterpret_cast<__bf16*>(smem + buf * kWideA);
-    __bf16* Bh = reinterpret_cast<__bf16*>(smem + 2 * kWideA + buf * kWideB);
-    if (IN_BN && in_bn) {
-      r.a0 = transform(r.a0, r.kq);
-      r.a1 = transform(r.a1, r.kq + 32);
-    }
-    *reinterpret_cast<bf16x4*>(Ah + ar * kLdaW + aq) = to_bf16x4(r.a0);
-    *reinterpret_cast<bf16x4*>(Ah + ar * kLdaW + aq + 32) = to_bf16x4(r.a1);
-    if (!W_KN) {
-      *reinterpret_cast<bf16x4*>(Bh + ar * kLdaW + aq) = to_bf16x4(r.b0);
-      *reinterpret_cast<bf16x4*>(Bh + ar * kLdaW + aq + 32) = to_bf16x4(r.b1);
-    } else {
-      *reinterpret_cast<bf16x4*>(Bh + kr * kLdtH + nq) = to_bf16x4(r.b0);
-      *reinterpret_cast<bf16x4*>(Bh + (kr + 32) * kLdtH + nq) = to_bf16x4(r.b1);
-    }
-  };
-
-  f32x16 acc2[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
-
-  // one 64-wide K-step: wave kh owns k = 32*kh .. 32*kh + 31 of the slice, as two 16-deep MFMAs into two accumulators
-#define HP_KSTEP_W(BUF, ST, LD, FETCH, STASH)                                                             \
-  {                                                                                                       \
-    const __bf16* Ah = reinterpret_cast<const __bf16*>(smem + (BUF) * kWideA);                            \
-    const __bf16* Bh = reinterpret_cast<const __bf16*>(smem + 2 * kWideA + (BUF) * kWideB);               \
-    const __bf16* ap_ = Ah + (wm * 32 + li) * kLdaW + kh * 32 + lh * 8;                                   \
-    const bf16x8 af0 = *reinterpret_cast<const bf16x8*>(ap_), af1 = *reinterpret_cast<const bf16x8*>(ap_ + 16); \
-    bf16x8 bf0, bf1;                                                                                      \
-    if (!W_KN) {                                                                                          \
-      const __bf16* bp_ = Bh + (wn * 32 + li) * kLdaW + kh * 32 + lh * 8;                                 \
-      bf0 = *reinterpret_cast<const bf16x8*>(bp_); bf1 = *reinterpret_cast<const bf16x8*>(bp_ + 16);      \
-    } else {                                                                                              \
-      bf0 = tr_operand(Bh, kLdtH, kh * 32, wn * 32, lane);                                                \
-      bf1 = tr_operand(Bh, kLdtH, kh * 32 + 16, wn * 32, lane);                                           \
-    }                                                                                                     \
-    if (FETCH) {                                                                                          \
-      LD.a0 = gload4(pa); LD.a1 = gload4(pa + ha);                                                        \
-      LD.b0 = gload4(pb); LD.b1 = gload4(pb + hb);                                                        \
-      LD.kq = (ia ? 0 : 2 * t.K) + kc * 64 + aq;                                                          \
-      __builtin_amdgcn_sched_barrier(0);                                                                  \
-      advance();                                                                                          \
-    }                                                                                                     \
-    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af0, bf0, acc2[0], 0, 0, 0);                        \
-    if (STASH) stash((BUF) ^ 1, ST);                                                                      \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af1, bf1, acc2[1], 0, 0, 0);                        \
-    __syncthreads();                                                                                      \
-  }
-
-  Pref setA = fetch();                       // slice 0 (in flight while the coefficients are derived)
-  if (IN_BN && in_bn) {
-    // (scale, shift) of the K input channels: the derivation of conv_body / HP_OP_BN_APPLY (bn_coef); workgroup 0 performs the
-    // BatchNorm's side effects
-    float* sc_w = smem + kConvLdsWide;
-    for (int c = tid; c < t.K; c += kConvThreads) {
-      const BnCoef k = bn_coef(true, p.in_Mstat, p.in_stats, t.K, c, p.gamma, p.beta, p.rmean, p.rvar, p.in_eps);
-      sc_w[c] = k.scale;
-      sc_w[t.K + c] = k.shift;
-      sc_w[2 * t.K + c] = 0.f;
-      sc_w[3 * t.K + c] = 0.f;
-      if (bid == 0) bn_side_effects(k, p.in_Mstat, t.K, c, p.in_save, p.rmean, p.rvar, p.in_mom, p.in_coef);
-    }
-    __syncthreads();
-  }
-  stash(0, setA);
-  if (nsteps > 1) setA = fetch();            // slice 1 waits in set A
-  Pref setB = setA;
-  __syncthreads();
-  int s = 0;
-  for (; s + 3 < nsteps; s += 2) {           // steady state: both steps fetch and stash
-    HP_KSTEP_W(0, setA, setB, true, true)
-    HP_KSTEP_W(1, setB, setA, true, true)
-  }
-  const int rem = nsteps - s;                // 1 (only when nsteps == 1), 2 or 3
-  if (rem == 3) {
-    HP_KSTEP_W(0, setA, setB, true, true)
-    HP_KSTEP_W(1, setB, setA, false, true)
-    HP_KSTEP_W(0, setA, setB, false, false)
-  } else if (rem == 2) {
-    HP_KSTEP_W(0, setA, setB, false, true)
-    HP_KSTEP_W(1, setB, setA, false, false)
-  } else {
-    HP_KSTEP_W(0, setA, setB, false, false)
-  }
-#undef HP_KSTEP_W
-  conv_epilogue(p, acc2, smem, bid, m0, n0);
-}
-
-template <bool W_KN, int MODE>
-__global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_taps_bf16w_kernel(ConvArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLdsWide + conv_extra_lds(MODE)];
-  conv_body_bf16w<W_KN, MODE>(p, blockIdx.x, smem);
-}
-template <bool W_KN, int MODE>
-__global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_taps_bf16w_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLdsWide + conv_extra_lds(MODE)];
-  if ((int)blockIdx.x < nblk_a) conv_body_bf16w<W_KN, MODE>(a, blockIdx.x, smem);
-  else conv_body_bf16w<W_KN, MODE>(b, blockIdx.x - nblk_a, smem);
-}
-
 static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   ConvArgs a;
   a.t = tapmap_from(op);
@@ -818,11 +636,6 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
   const bool kn = opa.flags & 1, bf = opa.flags & HP_CONV_BF16;
   const int mode = ma > mb ? ma : mb;
   const dim3 g(na + nb), th(kConvThreads);
-  if (bf && (a.t.K & 63) == 0 && (b.t.K & 63) == 0) {          // bf16, both contractions a multiple of 64: the 64-wide K-step body
-    if (kn) hipLaunchKernelGGL((conv_taps_bf16w_pair_kernel<true, 1>), g, th, 0, s, a, b, na);
-    else hipLaunchKernelGGL((conv_taps_bf16w_pair_kernel<false, 1>), g, th, 0, s, a, b, na);
-    return hipGetLastError();
-  }
   HP_CONV_DISPATCH(conv_taps_pair_kernel, kn, mode, bf, g, th, 0, s, a, b, na);
   return hipGetLastError();
 }
@@ -832,11 +645,6 @@ hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t 
   const dim3 g(hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64)), th(kConvThreads);
   const bool kn = op.flags & 1, bf = op.flags & HP_CONV_BF16;
   const int mode = conv_mode(op.flags);
-  if (bf && (a.t.K & 63) == 0) {
-    if (kn) hipLaunchKernelGGL((conv_taps_bf16w_kernel<true, 1>), g, th, 0, s, a);
-    else hipLaunchKernelGGL((conv_taps_bf16w_kernel<false, 1>), g, th, 0, s, a);
-    return hipGetLastError();
-  }
   HP_CONV_DISPATCH(conv_taps_kernel, kn, mode, bf, g, th, 0, s, a);
   return hipGetLastError();
 }

@@ -44,10 +44,9 @@ def test_conv_taps_bf16(name):
 
 
 @pytest.mark.parametrize("K,w_kn,in_bn", [(32, False, False), (96, True, False), (96, False, True), (64, False, True), (256, True, True), (128, False, True)])
-def test_conv_taps_bf16_narrow_and_wide_k_steps(K, w_kn, in_bn):
-    """K % 64 != 0 takes the 32-wide K-step body, every K the models use (multiples of 64) the 64-wide one (conv_body_bf16w) — both
-    against the interpreter on identically rounded operands, with and without the BatchNorm + leaky-ReLU input transform in the
-    loader (whose padded rows must be zeros of the ACTIVATION), ragged rows and columns."""
+def test_conv_taps_bf16_in_bn_and_ragged_shapes(K, w_kn, in_bn):
+    """bf16 conv against the interpreter on identically rounded operands for K from 32 to 256, with and without the BatchNorm +
+    leaky-ReLU input transform in the loader (whose padded rows must be zeros of the ACTIVATION), ragged rows and columns."""
     Bn, L, N = 5, 13, 100
     tm = TapMap(Bn * L, N, K, L, L, L, 1, 0, [((1 - t) if w_kn else (t - 1), t) for t in range(3)])
     img = Img(67)
