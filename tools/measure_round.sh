@@ -14,6 +14,14 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/${T}_kernel_stats.csv \;
 find $O/prof -name "*kernel_trace.csv" -exec python3 $R/tools/timeline.py {} 50 5 \; > $O/${T}_timeline.txt 2>&1 || true
 echo "rocprof done: $(head -3 $O/${T}_timeline.txt | tail -1)"
+# the same trace with ONE model stepping alone (its kernels never share the GPU: durations are the kernel's own)
+for m in 0 1; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_m$m -o $T -- python3 $R/bench.py --only-model $m --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe --no-profile > $O/${T}_bench_only_model$m.json 2> /dev/null
+  find $O/prof_m$m -name "*kernel_trace.csv" -exec python3 $R/tools/timeline.py {} 50 5 1 \; > $O/${T}_timeline_only_model$m.txt 2>&1 || true
+  rm -rf $O/prof_m$m
+done
+echo "single-model traces done"
+cd /tmp
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '_')
   timeout -k 10 280 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-trainer --no-profile --no-dp-probe > $O/pmc_$tag.log 2>&1
@@ -23,7 +31,7 @@ cd $R
 python3 tools/pmc_summary.py $O conv_taps $O/${T}_conv_pmc.json $2
 rm -rf $O/prof $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum_TCC_MISS_sum
 timeout -k 10 200 python bench.py --dtype bf16 --steps 200 --warmup 20 --no-cpu-baseline --no-trainer --no-dp-probe > $O/${T}_bench_bf16.json 2> $O/${T}_bench_bf16.err
-timeout -k 10 300 python bench.py --batch 4096 --z-dim 32 --wave-len 256 --time-len 32 --units 16384 --steps 20 --warmup 3 --no-cpu-baseline --no-trainer --no-dp-probe --per-op > $O/${T}_bench_config3_B4096.json 2> $O/${T}_per_op_config3_B4096.txt
+timeout -k 10 300 python bench.py --batch 4096 --z-dim 32 --wave-len 256 --time-len 32 --units 1000000 --steps 20 --warmup 3 --no-cpu-baseline --no-trainer --no-dp-probe --per-op > $O/${T}_bench_config3_B4096.json 2> $O/${T}_per_op_config3_B4096.txt
 timeout -k 10 300 python tools/micro/op_chain_times.py time > $O/${T}_op_chain_time_model.txt 2>&1 || true
 timeout -k 10 300 python tools/micro/op_chain_times.py wave > $O/${T}_op_chain_wave_model.txt 2>&1 || true
 ls $O

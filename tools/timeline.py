@@ -1,19 +1,20 @@
 """Timeline of the TIMED steps inside a rocprofv3 --kernel-trace of `bench.py --steps K --warmup W` (two adamw_kernel
 launches per pair-step: the window runs from the end of launch 2W to the end of launch 2(W+K)): kernels in flight, sum of
-kernel durations against the wall time, per-kernel shares.   python tools/timeline.py <kernel_trace.csv> K W"""
+kernel durations against the wall time, per-kernel shares.   python tools/timeline.py <kernel_trace.csv> K W [models per step: 1 under --only-model]"""
 import collections
 import csv
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 K, W = int(sys.argv[2]), int(sys.argv[3])
+MODELS = int(sys.argv[4]) if len(sys.argv) > 4 else 2          # adamw_kernel launches per step: 2 (the pair), 1 under --only-model
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
 adam = [e for e in ev if "adamw_kernel" in e[2]]
-lo, hi = adam[2 * W - 1][1], adam[2 * (W + K) - 1][1]
+lo, hi = adam[MODELS * W - 1][1], adam[MODELS * (W + K) - 1][1]
 ev = [e for e in ev if e[0] >= lo and e[1] <= hi]
 tot = hi - lo
-print(f"rocprofv3 --kernel-trace of `python3 bench.py --steps {K} --warmup {W} --no-cpu-baseline --no-trainer`, the {K} timed steps "
-      f"(between the {2 * W}th and the {2 * (W + K)}th adamw_kernel):")
+print(f"rocprofv3 --kernel-trace of `python3 bench.py --steps {K} --warmup {W} --no-cpu-baseline --no-trainer`" + (" --only-model <m>" if MODELS == 1 else "") +
+      f", the {K} timed steps (between the {MODELS * W}th and the {MODELS * (W + K)}th adamw_kernel):")
 print(f"window {tot / 1e6:.3f} ms -> {tot / 1e6 / K:.3f} ms/step under tracing; {len(ev) / K:.1f} kernels/step")
 pts = sorted([(s, 1) for s, e, n in ev] + [(e, -1) for s, e, n in ev])
 busy = collections.Counter()
