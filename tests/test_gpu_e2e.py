@@ -348,9 +348,10 @@ def test_state_dict_roundtrip_and_reference_keys():
     assert sorted(engm.state_dict().keys()) == sorted(k for k, _, _ in man["multimodal_z10_o50_100"])
 
 
-@pytest.mark.parametrize("B,L", [(2, 50), (3, 100), (65, 33), (513, 50)])
+@pytest.mark.parametrize("B,L", [(2, 50), (3, 100), (65, 33), (513, 50), (6, 2), (7, 3), (64, 1)])
 def test_ragged_batches_and_lengths(B, L):
-    """Tiny, odd and tile-straddling batches / lengths: forward, loss and one full step against the oracle."""
+    """Tiny, odd and tile-straddling batches / lengths (down to inputs of 1-3 samples, where every encoder stage is one position
+    long and the stride-2 input-gradient has no odd phase): forward, loss and one full step against the oracle."""
     c = dict(kind="unimodal", z=10, L=L, B=B, with_class=False, beta=1.0, clip=1.0, lr=1e-4, salt=40 + B)
     eng, oms, batch, batch64, eps = build(**c)
     check_forward(eng, oms, batch, batch64, eps, training=False)
