@@ -89,10 +89,18 @@ class Pair:
                    planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=1.0, fuse_bn=fuse_bn, mfma_dtype=mfma_dtype, reuse_workspace=reuse_ws, **res)]
         self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
+        self.stream_pair = {}
         self.groups = None
         if world > 1 or os.environ.get("HIPPIE_FORCE_DIST"):
             self.use_world_group()
         self.init_params()
+
+    def pick_streams(self):
+        """Which two HIP streams overlap is a lottery of hardware-queue assignment (hippie_amd/streams.py: 4.4 / 5.6 / 8 ms per pair-step
+        for concurrent / same-queue / time-slicing pairs): measured on the evaluation-forward graphs, after RCCL has made its streams."""
+        from hippie_amd.streams import pick_concurrent_streams
+        self.stream_pair.clear()
+        self.streams = pick_concurrent_streams(self.eng, self.device, report=self.stream_pair, refresh=True)
 
     def use_world_group(self):
         """gradient mean-all-reduce between bwd and opt over the default process group.  One communicator: the two models'
@@ -380,13 +388,14 @@ def trainer_rate(device, data, epochs=2):
     from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
     from hippie_amd.trainer import Trainer, fit_concurrently
     N = data[0].shape[0]
-    jobs = []
+    jobs, warm = [], []
     for k, (L, clip) in enumerate(((data[0].shape[1], None), (data[1].shape[1], 1.0))):
         net = hippieUnimodalCVAE(z_dim=Z_DIM, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5, device=device)
         mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3, weight_decay=0.01)
         loader = HbmLoader(data[k], data[2], BATCH, seed=7 + k)
-        Trainer(max_epochs=1, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0).fit(mod, loader)   # warm-up: lowers + captures
+        warm.append((Trainer(max_epochs=1, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0), mod, loader, None))
         jobs.append((Trainer(max_epochs=epochs, gradient_clip_val=clip, enable_checkpointing=False, num_sanity_val_steps=0), mod, loader, None))
+    fit_concurrently(warm)          # warm-up epoch: lowers, captures the graphs, measures which stream pair overlaps (hippie_amd/streams.py)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     fit_concurrently(jobs)
@@ -468,6 +477,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-reuse-ws", action="store_true", help="every workspace tensor in memory of its own (A/B against the liveness-packed arena)")
     ap.add_argument("--only-model", type=int, choices=(0, 1), default=None, help="diagnostic: step only the wave (0) or the time (1) model; the line is then NOT the headline metric")
+    ap.add_argument("--no-pick-streams", action="store_true", help="A/B: take the first two streams torch hands out instead of measuring which pair overlaps")
     ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -541,6 +551,11 @@ def main():
     use_graph = not args.no_graph
     if pair.staged:
         pair.load_tables(data, perm)
+    if world > 1 or force_dist:
+        dist.all_reduce(torch.zeros(1, device=device))       # the communicator's own stream exists before the model streams are chosen
+    if not args.no_pick_streams:
+        pair.pick_streams()
+    stream_pair = dict(pair.stream_pair)
     pair.fork()
     for i in range(args.warmup):
         pair.step(data, batch_idx(i), use_graph)
@@ -587,6 +602,9 @@ def main():
             os.environ["HIPPIE_FORCE_DIST"] = "1"
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
             pair.use_world_group()
+            dist.all_reduce(torch.zeros(1, device=device))
+            if not args.no_pick_streams:
+                pair.pick_streams()
             timed(args.warmup)
             dt_dp = timed(args.steps)
             dp_probe = {"ms_per_step": dt_dp / args.steps * 1e3, "value": BATCH * args.steps / dt_dp, "ratio_to_value": dt / dt_dp,
@@ -650,7 +668,7 @@ def main():
                         "when --batch 8192 --z-dim 64 --wave-len 256 --time-len 32" if args.model_type == "multimodal" else
                         f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units"),
                        "model_type": args.model_type,
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "staged_in_graph": pair.staged, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "lockstep": pair.lockstep,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "staged_in_graph": pair.staged, "stream_pair": stream_pair or None, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "lockstep": pair.lockstep,
                        "final_loss_wave": loss[0], "final_loss_time": loss[-1],
                        # every HIPPIE_* variable of this run (measurement knobs act only under HIPPIE_DEBUG_KNOBS=1): {} = the product defaults
                        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("HIPPIE_")}},

@@ -1,0 +1,80 @@
+"""Choosing HIP streams that really run side by side.
+
+The wave and the time model step on two HIP streams (hippie/… trains them one after the other, scripts/train_model_with_multimodal.py:208,224;
+here their kernels share the GPU).  ROCm multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues, and the firmware
+spreads those queues over a few pipes: which queue a `torch.cuda.Stream()` lands on depends on how many streams the process (torch,
+RCCL, the profiler) created before it.  Measured on MI355X (`profiles/r03_queue_pair_probe.txt`, tools/micro/queue_pair_probe.py) a
+pair of streams is one of three kinds: concurrent (4.40 ms per pair-step), the same hardware queue (5.64 ms = back to back), or two
+queues that time-slice each other (7.5-8.6 ms — slower than back to back).  Which pair is which is a lottery, so it is measured:
+`pick_concurrent_streams` replays every engine's evaluation-forward graph (no state changes: no running statistics, no parameters,
+no step counters) on candidate pairs until one overlaps.
+"""
+from __future__ import annotations
+
+import torch
+
+CANDIDATES = 6
+SEGMENT = "fwd_eval"
+_CHOSEN = {}          # device index -> (streams, report): a stream keeps its hardware queue for life, so one measurement per process
+
+
+def _pair_time(engines, streams, device, replays):
+    cur = torch.cuda.current_stream(device)
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record(cur)
+    for s in streams:
+        s.wait_stream(cur)
+    for _ in range(replays):
+        for e, s in zip(engines, streams):
+            with torch.cuda.stream(s):
+                e.run(SEGMENT, True)
+    for s in streams:
+        cur.wait_stream(s)
+    t1.record(cur)
+    t1.synchronize()
+    return t0.elapsed_time(t1) * 1e3 / replays
+
+
+def pick_concurrent_streams(engines, device=None, candidates=CANDIDATES, replays=3, accept=0.85, report=None, refresh=False):
+    """One stream per engine, chosen so that the engines' graphs overlap.  engines: hippie_amd.engine.Engine objects whose plans hold
+    a "fwd_eval" segment (every model plan does).  One engine: a fresh stream, nothing to measure.  More than two engines: the pair
+    is found for the first two and the rest take the remaining candidates in order.
+
+    Cost matters (the reference's own pretraining fit is 31 steps): the two graphs are first timed back to back on ONE stream; candidate
+    pairs are then tried in order and the first one at or below `accept` x that time is taken (concurrent pairs measure 0.75-0.80 of
+    it, same-queue pairs 1.0, time-slicing pairs 1.15-1.5) — normally two or three measurements of a few milliseconds.  If none
+    qualifies the fastest pair seen wins.
+    report: optional dict, filled with {"chosen": [i, j], "us": t, "serial_us": t1, "tried": {"i,j": us}} (bench.py prints it).
+    The result is kept per device for the life of the process (a later fit reuses it); refresh=True measures again — after something
+    else (an RCCL communicator) has created streams of its own."""
+    device = torch.device(device if device is not None else engines[0].device)
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if not refresh and key in _CHOSEN and len(_CHOSEN[key][0]) >= len(engines):
+        if report is not None:
+            report.update(_CHOSEN[key][1], cached=True)
+        return _CHOSEN[key][0][:len(engines)]
+    with torch.cuda.device(device):
+        pool = [torch.cuda.Stream(device=device) for _ in range(max(candidates, len(engines)))]
+        if len(engines) < 2:
+            return pool[:len(engines)]
+        pair = engines[:2]
+        for e in pair:
+            e.capture_segments((SEGMENT,))
+        torch.cuda.synchronize(device)
+        _pair_time(pair, (pool[0], pool[0]), device, 1)                     # first replay of a graph uploads it
+        serial = min(_pair_time(pair, (s, s), device, replays) for s in pool[:2])      # a stream can be slow by itself: best of two
+        tried = {}
+        for j in range(1, len(pool)):
+            for i in range(j):
+                tried[(i, j)] = _pair_time(pair, (pool[i], pool[j]), device, replays)
+                if tried[(i, j)] <= accept * serial:
+                    break
+            else:
+                continue
+            break
+        (i, j), t = min(tried.items(), key=lambda kv: kv[1])
+        rep = dict(chosen=[i, j], us=round(t, 1), serial_us=round(serial, 1), tried={f"{a},{b}": round(v) for (a, b), v in tried.items()})
+        if report is not None:
+            report.update(rep)
+        _CHOSEN[key] = ([pool[i], pool[j]] + [s for k, s in enumerate(pool) if k not in (i, j)], rep)
+        return _CHOSEN[key][0][:len(engines)]

@@ -249,6 +249,7 @@ def fit_concurrently(jobs):
         planned.append((_Frozen(trains), _Frozen(vals) if val is not None else None))
     # Everything the threads will replay is lowered and captured NOW, one job after the other: stream capture does not tolerate
     # another thread's launches (hippie_amd.program._CAPTURE_LOCK), and lowering is host work better not interleaved either.
+    cal = []                                               # one engine per job for the stream-pair measurement
     for (tr, mod, _, _), (trains, vals) in zip(jobs, planned):
         tr.prepare(mod)
         if not mod.model.use_graph:
@@ -259,10 +260,18 @@ def fit_concurrently(jobs):
                 shapes.add((int(batch[0].shape[0]), batch[-1].ndim == 2))
             for B_, with_class in shapes:
                 mod.model.engine(B_, with_class).capture_segments(segs)
+                if passes is trains and len(cal) < len(planned) and (not cal or cal[-1][0] is not mod):
+                    cal.append((mod, mod.model.engine(B_, with_class)))
     errors = [None] * len(jobs)
     dev = jobs[0][0]._dev(jobs[0][1])
     main = torch.cuda.current_stream(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in jobs]
+    if len(cal) == len(jobs):
+        # which pairs of HIP streams really overlap is a lottery of hardware-queue assignment (hippie_amd/streams.py): measured, on
+        # the evaluation-forward graphs (they change no state), before the first step
+        from .streams import pick_concurrent_streams
+        streams = pick_concurrent_streams([e for _, e in cal], dev)
+    else:
+        streams = [torch.cuda.Stream(device=dev) for _ in jobs]
 
     def run(k):
         tr, mod, _, _ = jobs[k]

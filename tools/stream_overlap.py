@@ -1,7 +1,7 @@
 """How much do the two model streams actually overlap?  From a rocprofv3 --kernel-trace of the default bench command: per queue,
 busy time, gaps between consecutive kernels (the dependent-launch floor), and the fraction of each queue's kernel time during
 which the other model's queue also has a kernel in flight — split by kernel family.
-python tools/stream_overlap.py <kernel_trace.csv> K W"""
+python tools/stream_overlap.py <kernel_trace.csv> K W [one_step_listing.txt]"""
 import collections
 import csv
 import sys
@@ -58,3 +58,15 @@ for q in qs:
           f"sum of gaps {sum(gaps) / 1e3 / K:.0f} us/step")
     for k, v in dur.most_common():
         print(f"   {k:12s} {v / 1e3 / K:8.1f} us/step, {100 * ov[k] / v:5.1f} % of it beside a kernel of the other model")
+
+if len(sys.argv) > 4:
+    # one step of both queues as a merged list: start offset (us), queue, duration (us), workgroups, kernel
+    full = {(int(r["Start_Timestamp"]), r["Queue_Id"]): r for r in rows}
+    a0, a1 = adam[2 * (W + K // 2) - 1][1], adam[2 * (W + K // 2 + 1) - 1][1]
+    with open(sys.argv[4], "w") as f:
+        for s, e, n, q in ev:
+            if a0 <= s < a1:
+                r = full[(s, q)]
+                wg = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // max(1, int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"]))
+                short = n.replace("(anonymous namespace)::", "").split("(")[0].replace("hp::", "").replace("void ", "")[:70]
+                f.write(f"{(s - a0) / 1e3:9.2f} {'  ' if q == qs[0] else '          '}q{q} {(e - s) / 1e3:8.2f} us {wg:6d} wg  lds {r.get('LDS_Block_Size', r.get('LDS_Block_Size_v', '?')):>6s} vgpr {r.get('VGPR_Count', '?'):>3s}+{r.get('Accum_VGPR_Count', '?'):<3s} {short}\n")
