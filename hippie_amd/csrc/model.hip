@@ -256,4 +256,86 @@ int hp_model_synchronize(HpModel* m, void* stream) {
   return 0;
 }
 
+// ---- streams for a host that holds two models ------------------------------------------------------------------------
+int hp_stream_create(void** out) {
+  if (!out) return merr("hp_stream_create: null argument");
+  hipStream_t s = nullptr;
+  const hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+  if (e != hipSuccess) return merr(std::string("hp_stream_create: ") + hipGetErrorString(e));
+  *out = s;
+  return 0;
+}
+
+int hp_stream_destroy(void* stream) {
+  if (!stream) return 0;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) return merr(std::string("hp_stream_destroy: ") + hipGetErrorString(e));
+  return 0;
+}
+
+int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float accept, void** stream_a, void** stream_b, float report[3]) {
+  if (!a || !b || !stream_a || !stream_b) return merr("hp_pick_concurrent_streams: null argument");
+  if (!a->on_device || !b->on_device) return merr("hp_pick_concurrent_streams: a model was loaded with HP_MODEL_NO_DEVICE");
+  if (!find_segment(a, "fwd_eval") || !find_segment(b, "fwd_eval")) return merr("hp_pick_concurrent_streams: both models need a 'fwd_eval' segment");
+  if (candidates < 2 || candidates > 16) return merr("hp_pick_concurrent_streams: candidates must be 2..16");
+  if (!(accept > 0.f)) accept = 0.85f;
+  constexpr int kReplays = 3;
+  std::vector<hipStream_t> pool(candidates, nullptr);
+  hipStream_t T = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // start, end, done a, done b
+  hipError_t e = hipStreamCreateWithFlags(&T, hipStreamNonBlocking);
+  for (int k = 0; k < candidates && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&pool[k], hipStreamNonBlocking);
+  for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&ev[k]);
+  int rc = e == hipSuccess ? 0 : merr(std::string("hp_pick_concurrent_streams: ") + hipGetErrorString(e));
+  // both evaluation-forward graphs `replays` times, a on sa and b on sb, bracketed on the timing stream T
+  auto timed = [&](hipStream_t sa, hipStream_t sb, int replays, float* us) -> int {
+    hipError_t q = hipEventRecord(ev[0], T);
+    if (q == hipSuccess) q = hipStreamWaitEvent(sa, ev[0], 0);
+    if (q == hipSuccess && sb != sa) q = hipStreamWaitEvent(sb, ev[0], 0);
+    if (q != hipSuccess) return merr(std::string("hp_pick_concurrent_streams: ") + hipGetErrorString(q));
+    for (int r = 0; r < replays; ++r) {
+      if (hp_model_run(a, "fwd_eval", 1, sa)) return 1;
+      if (hp_model_run(b, "fwd_eval", 1, sb)) return 1;
+    }
+    q = hipEventRecord(ev[2], sa);
+    if (q == hipSuccess) q = hipEventRecord(ev[3], sb);
+    if (q == hipSuccess) q = hipStreamWaitEvent(T, ev[2], 0);
+    if (q == hipSuccess) q = hipStreamWaitEvent(T, ev[3], 0);
+    if (q == hipSuccess) q = hipEventRecord(ev[1], T);
+    if (q == hipSuccess) q = hipEventSynchronize(ev[1]);
+    float ms = 0.f;
+    if (q == hipSuccess) q = hipEventElapsedTime(&ms, ev[0], ev[1]);
+    if (q != hipSuccess) return merr(std::string("hp_pick_concurrent_streams: ") + hipGetErrorString(q));
+    *us = ms * 1e3f / replays;
+    return 0;
+  };
+  int bi = 0, bj = 1, tried = 0;
+  float best = 1e30f, serial = 1e30f;
+  if (rc == 0) {
+    float t = 0.f;
+    rc = timed(pool[0], pool[0], 1, &t);                       // first replay of a graph uploads it
+    for (int k = 0; k < 2 && rc == 0; ++k) {                   // a stream can be slow by itself: best of two
+      rc = timed(pool[k], pool[k], kReplays, &t);
+      if (rc == 0 && t < serial) serial = t;
+    }
+    bool done = false;
+    for (int j = 1; j < candidates && rc == 0 && !done; ++j)
+      for (int i = 0; i < j && rc == 0 && !done; ++i) {
+        rc = timed(pool[i], pool[j], kReplays, &t);
+        ++tried;
+        if (rc == 0 && t < best) { best = t; bi = i; bj = j; }
+        done = rc == 0 && t <= accept * serial;
+      }
+  }
+  for (int k = 0; k < 4; ++k) if (ev[k]) hipEventDestroy(ev[k]);
+  if (T) hipStreamDestroy(T);
+  for (int k = 0; k < candidates; ++k)
+    if (pool[k] && (rc != 0 || (k != bi && k != bj))) hipStreamDestroy(pool[k]);
+  if (rc != 0) return rc;
+  *stream_a = pool[bi];
+  *stream_b = pool[bj];
+  if (report) { report[0] = best; report[1] = serial; report[2] = (float)tried; }
+  return 0;
+}
+
 }  // extern "C"

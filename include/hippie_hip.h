@@ -392,6 +392,20 @@ int hp_model_write(HpModel* m, const char* name, const void* src, int64_t nbytes
 int hp_model_read(HpModel* m, const char* name, void* dst, int64_t nbytes, int dst_on_device, void* stream);
 int hp_model_synchronize(HpModel* m, void* stream);
 
+/* ---- streams for a host that holds two models -------------------------------------------------------------------------------------
+ * The reference fits the waveform model and the timing model one after the other (scripts/train_model_with_multimodal.py:208,224); a
+ * host of this library steps them side by side on two HIP streams (4.4 ms per pair of steps instead of 5.9 at batch 512).  `stream`
+ * arguments everywhere in this header are hipStream_t values passed as void*; a host without the HIP headers makes them here.
+ * Which PAIR of streams really overlaps is decided by how the runtime maps streams onto hardware queues — a pair is concurrent, shares one
+ * queue (= back to back) or time-slices (slower than back to back), depending on what else in the process created streams before
+ * (DESIGN.md section 5.3).  hp_pick_concurrent_streams creates `candidates` (2..16) streams, times both models' "fwd_eval" graphs (which
+ * change no parameter, statistic or counter) back to back on one stream and then on candidate pairs, and returns the first pair at or
+ * below accept (0 = 0.85) x the serial time — else the fastest pair seen; the other candidates are destroyed.  Only the eval-mode output
+ * slots ("enc_eval", "rec_eval", ...) are overwritten.  The two streams belong to the caller (hp_stream_destroy).  report (may be NULL): pair us, serial us, pairs tried. */
+int hp_stream_create(void** out);
+int hp_stream_destroy(void* stream);
+int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float accept, void** stream_a, void** stream_b, float report[3]);
+
 #ifdef __cplusplus
 }
 #endif

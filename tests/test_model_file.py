@@ -143,3 +143,43 @@ def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph):
     ls = [float(v) for v in om.losses((x, src, None) if kind == "unimodal" else (x, x2, src, None), outs, 1.0)]
     mine = [got[0][0], got[0][1], got[0][3]] if kind == "unimodal" else list(got[0])
     np.testing.assert_allclose(mine, ls, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_plain_c_host_steps_two_models_on_picked_streams(tmp_path):
+    """tests/c_host/host_pair.c: the wave and the time model side by side on the two streams hp_pick_concurrent_streams returns,
+    against the Python engines stepping one after the other on the default stream."""
+    from hippie_amd.engine import Engine
+    z, B, lr, steps = 10, 16, 1e-6, 3
+    args, wants = [], []
+    for j, (L, clip, salt) in enumerate(((50, 0.0, 4), (100, 1.0, 5))):
+        d = tmp_path / f"m{j}"
+        d.mkdir()
+        plan, om, path, pv, bv = _export(d, "unimodal", z, L, B, salt=salt, clip=clip, lr=lr)
+        x, src, cls, eps = O.synth_inputs(B, L, z, salt=salt)
+        inputs = str(d / "inputs.bin")
+        with open(inputs, "wb") as f:
+            f.write(x.numpy().astype(np.float32).tobytes() + src.numpy().astype(np.int64).tobytes() + eps.numpy().astype(np.float32).tobytes())
+        args += [path, inputs]
+        eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=lr, clip=clip))
+        eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
+        eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+        want = []
+        for _ in range(steps):
+            eng.train_step(use_graph=False)
+            want.append(eng.scalars())
+        wants.append(np.array(want))
+    exe = str(tmp_path / "host_pair")
+    libdir = os.path.join(ROOT, "hippie_amd")
+    subprocess.run(["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "c_host", "host_pair.c"), "-o", exe, "-L", libdir, "-lhippie_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe] + args + [str(steps)], check=True, capture_output=True, text=True, timeout=300).stdout
+    lines = out.strip().splitlines()
+    pick = dict(zip(lines[0].split()[1::2], lines[0].split()[2::2]))
+    assert lines[0].startswith("pick ") and pick["distinct"] == "1" and float(pick["pair_us"]) > 0 and 1 <= int(pick["tried"]) <= 15, out
+    for j in range(2):
+        got = np.array([[float(v) for v in ln.split()[4:]] for ln in lines if ln.startswith(f"model {j} step ")])
+        assert got.shape == (steps, 4), out
+        np.testing.assert_allclose(got, wants[j], rtol=1e-5)        # same kernels; only the order of atomic sums differs
+        assert f"model {j} batches_tracked {steps}" in out
