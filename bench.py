@@ -90,6 +90,7 @@ class Pair:
         self.eng = [Engine(c, BATCH, t, device=device) for c, t in zip(cfgs, tcs)]
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
         self.stream_pair = {}
+        self.stream_priority = True      # --no-stream-priority (A/B): both model streams at normal priority
         self.groups = None
         if world > 1 or os.environ.get("HIPPIE_FORCE_DIST"):
             self.use_world_group()
@@ -100,7 +101,7 @@ class Pair:
         for concurrent / same-queue / time-slicing pairs): measured on the evaluation-forward graphs, after RCCL has made its streams."""
         from hippie_amd.streams import pick_concurrent_streams
         self.stream_pair.clear()
-        self.streams = pick_concurrent_streams(self.eng, self.device, report=self.stream_pair, refresh=True)
+        self.streams = pick_concurrent_streams(self.eng, self.device, report=self.stream_pair, refresh=True, prioritise_longer=self.stream_priority)
 
     def use_world_group(self):
         """gradient mean-all-reduce between bwd and opt over the default process group.  One communicator: the two models'
@@ -478,6 +479,7 @@ def main():
     ap.add_argument("--no-reuse-ws", action="store_true", help="every workspace tensor in memory of its own (A/B against the liveness-packed arena)")
     ap.add_argument("--only-model", type=int, choices=(0, 1), default=None, help="diagnostic: step only the wave (0) or the time (1) model; the line is then NOT the headline metric")
     ap.add_argument("--no-pick-streams", action="store_true", help="A/B: take the first two streams torch hands out instead of measuring which pair overlaps")
+    ap.add_argument("--no-stream-priority", action="store_true", help="A/B: no high-priority stream for the longer chain (the time model)")
     ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
@@ -540,6 +542,7 @@ def main():
                 fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type,
                 staged=not args.no_staged, rank=rank)
     pair.only = args.only_model
+    pair.stream_priority = not args.no_stream_priority
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)

@@ -280,27 +280,30 @@ int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float acc
   if (candidates < 2 || candidates > 16) return merr("hp_pick_concurrent_streams: candidates must be 2..16");
   if (!(accept > 0.f)) accept = 0.85f;
   constexpr int kReplays = 3;
-  std::vector<hipStream_t> pool(candidates, nullptr);
+  // pool[0]: normal priority, pool[1]: high priority (for the model whose graph takes longer alone: free-running, the shorter chain
+  // otherwise finishes its steps first and the longer one runs its last steps alone — tools/micro/balance_probe.py)
+  std::vector<hipStream_t> pool[2] = {std::vector<hipStream_t>(candidates, nullptr), std::vector<hipStream_t>(candidates, nullptr)};
   hipStream_t T = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};      // start, end, done a, done b
-  hipError_t e = hipStreamCreateWithFlags(&T, hipStreamNonBlocking);
-  for (int k = 0; k < candidates && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&pool[k], hipStreamNonBlocking);
+  int least = 0, greatest = 0;
+  hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&T, hipStreamNonBlocking);
+  for (int k = 0; k < candidates && e == hipSuccess; ++k) e = hipStreamCreateWithFlags(&pool[0][k], hipStreamNonBlocking);
+  for (int k = 0; k < candidates && e == hipSuccess; ++k) e = hipStreamCreateWithPriority(&pool[1][k], hipStreamNonBlocking, greatest);
   for (int k = 0; k < 4 && e == hipSuccess; ++k) e = hipEventCreate(&ev[k]);
   int rc = e == hipSuccess ? 0 : merr(std::string("hp_pick_concurrent_streams: ") + hipGetErrorString(e));
-  // both evaluation-forward graphs `replays` times, a on sa and b on sb, bracketed on the timing stream T
+  // the evaluation-forward graphs `replays` times, a on sa and / or b on sb (null: that model sits out), bracketed on the timing stream T
   auto timed = [&](hipStream_t sa, hipStream_t sb, int replays, float* us) -> int {
     hipError_t q = hipEventRecord(ev[0], T);
-    if (q == hipSuccess) q = hipStreamWaitEvent(sa, ev[0], 0);
-    if (q == hipSuccess && sb != sa) q = hipStreamWaitEvent(sb, ev[0], 0);
+    if (q == hipSuccess && sa) q = hipStreamWaitEvent(sa, ev[0], 0);
+    if (q == hipSuccess && sb && sb != sa) q = hipStreamWaitEvent(sb, ev[0], 0);
     if (q != hipSuccess) return merr(std::string("hp_pick_concurrent_streams: ") + hipGetErrorString(q));
     for (int r = 0; r < replays; ++r) {
-      if (hp_model_run(a, "fwd_eval", 1, sa)) return 1;
-      if (hp_model_run(b, "fwd_eval", 1, sb)) return 1;
+      if (sa && hp_model_run(a, "fwd_eval", 1, sa)) return 1;
+      if (sb && hp_model_run(b, "fwd_eval", 1, sb)) return 1;
     }
-    q = hipEventRecord(ev[2], sa);
-    if (q == hipSuccess) q = hipEventRecord(ev[3], sb);
-    if (q == hipSuccess) q = hipStreamWaitEvent(T, ev[2], 0);
-    if (q == hipSuccess) q = hipStreamWaitEvent(T, ev[3], 0);
+    if (sa) { q = hipEventRecord(ev[2], sa); if (q == hipSuccess) q = hipStreamWaitEvent(T, ev[2], 0); }
+    if (q == hipSuccess && sb) { q = hipEventRecord(ev[3], sb); if (q == hipSuccess) q = hipStreamWaitEvent(T, ev[3], 0); }
     if (q == hipSuccess) q = hipEventRecord(ev[1], T);
     if (q == hipSuccess) q = hipEventSynchronize(ev[1]);
     float ms = 0.f;
@@ -309,19 +312,24 @@ int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float acc
     *us = ms * 1e3f / replays;
     return 0;
   };
-  int bi = 0, bj = 1, tried = 0;
-  float best = 1e30f, serial = 1e30f;
+  int bi = 0, bj = 0, tried = 0, pa = 0, pb = 0;
+  float best = 1e30f, serial = 0.f;
   if (rc == 0) {
-    float t = 0.f;
-    rc = timed(pool[0], pool[0], 1, &t);                       // first replay of a graph uploads it
+    float t = 0.f, alone[2] = {1e30f, 1e30f};
+    rc = timed(pool[0][0], pool[0][0], 1, &t);                 // first replay of a graph uploads it
     for (int k = 0; k < 2 && rc == 0; ++k) {                   // a stream can be slow by itself: best of two
-      rc = timed(pool[k], pool[k], kReplays, &t);
-      if (rc == 0 && t < serial) serial = t;
+      rc = timed(pool[0][k], nullptr, kReplays, &t);
+      if (rc == 0 && t < alone[0]) alone[0] = t;
+      if (rc == 0) rc = timed(nullptr, pool[0][k], kReplays, &t);
+      if (rc == 0 && t < alone[1]) alone[1] = t;
     }
+    serial = alone[0] + alone[1];
+    pa = alone[0] > alone[1] ? 1 : 0;                          // which pool each model draws from
+    pb = 1 - pa;
     bool done = false;
-    for (int j = 1; j < candidates && rc == 0 && !done; ++j)
-      for (int i = 0; i < j && rc == 0 && !done; ++i) {
-        rc = timed(pool[i], pool[j], kReplays, &t);
+    for (int j = 0; j < candidates && rc == 0 && !done; ++j)
+      for (int i = 0; i < candidates && rc == 0 && !done; ++i) {
+        rc = timed(pool[pa][i], pool[pb][j], kReplays, &t);
         ++tried;
         if (rc == 0 && t < best) { best = t; bi = i; bj = j; }
         done = rc == 0 && t <= accept * serial;
@@ -329,11 +337,14 @@ int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float acc
   }
   for (int k = 0; k < 4; ++k) if (ev[k]) hipEventDestroy(ev[k]);
   if (T) hipStreamDestroy(T);
-  for (int k = 0; k < candidates; ++k)
-    if (pool[k] && (rc != 0 || (k != bi && k != bj))) hipStreamDestroy(pool[k]);
+  for (int q = 0; q < 2; ++q)
+    for (int k = 0; k < candidates; ++k) {
+      const bool keep = rc == 0 && ((q == pa && k == bi) || (q == pb && k == bj));
+      if (pool[q][k] && !keep) hipStreamDestroy(pool[q][k]);
+    }
   if (rc != 0) return rc;
-  *stream_a = pool[bi];
-  *stream_b = pool[bj];
+  *stream_a = pool[pa][bi];
+  *stream_b = pool[pb][bj];
   if (report) { report[0] = best; report[1] = serial; report[2] = (float)tried; }
   return 0;
 }

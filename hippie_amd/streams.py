@@ -35,16 +35,19 @@ def _pair_time(engines, streams, device, replays):
     return t0.elapsed_time(t1) * 1e3 / replays
 
 
-def pick_concurrent_streams(engines, device=None, candidates=CANDIDATES, replays=3, accept=0.85, report=None, refresh=False):
+def pick_concurrent_streams(engines, device=None, candidates=CANDIDATES, replays=3, accept=0.85, report=None, refresh=False, prioritise_longer=True):
     """One stream per engine, chosen so that the engines' graphs overlap.  engines: hippie_amd.engine.Engine objects whose plans hold
     a "fwd_eval" segment (every model plan does).  One engine: a fresh stream, nothing to measure.  More than two engines: the pair
     is found for the first two and the rest take the remaining candidates in order.
 
-    Cost matters (the reference's own pretraining fit is 31 steps): the two graphs are first timed back to back on ONE stream; candidate
-    pairs are then tried in order and the first one at or below `accept` x that time is taken (concurrent pairs measure 0.75-0.80 of
-    it, same-queue pairs 1.0, time-slicing pairs 1.15-1.5) — normally two or three measurements of a few milliseconds.  If none
-    qualifies the fastest pair seen wins.
-    report: optional dict, filled with {"chosen": [i, j], "us": t, "serial_us": t1, "tried": {"i,j": us}} (bench.py prints it).
+    Cost matters (the reference's own pretraining fit is 31 steps): each graph is first timed alone; candidate pairs are then tried
+    in order and the first one at or below `accept` x the sum of the two is taken (concurrent pairs measure 0.75-0.80 of it, same-queue
+    pairs 1.0, time-slicing pairs 1.15-1.5) — normally a handful of measurements of a few milliseconds.  If none qualifies the fastest
+    pair seen wins.
+    prioritise_longer: the engine whose graph takes longer alone gets a HIGH-priority stream (the other a normal one).  Free-running,
+    the shorter chain (the waveform model) otherwise finishes its steps first and the longer one runs its last steps alone:
+    tools/micro/balance_probe.py, 4.34 -> 4.26 ms per pair-step when the time model's stream has priority.
+    report: optional dict, filled with {"chosen": [i, j], "us": t, "serial_us": t1, "alone_us": [..], "high_priority": k, "tried": {"i,j": us}}.
     The result is kept per device for the life of the process (a later fit reuses it); refresh=True measures again — after something
     else (an RCCL communicator) has created streams of its own."""
     device = torch.device(device if device is not None else engines[0].device)
@@ -54,7 +57,8 @@ def pick_concurrent_streams(engines, device=None, candidates=CANDIDATES, replays
             report.update(_CHOSEN[key][1], cached=True)
         return _CHOSEN[key][0][:len(engines)]
     with torch.cuda.device(device):
-        pool = [torch.cuda.Stream(device=device) for _ in range(max(candidates, len(engines)))]
+        n = max(candidates, len(engines))
+        pool = [torch.cuda.Stream(device=device) for _ in range(n)]
         if len(engines) < 2:
             return pool[:len(engines)]
         pair = engines[:2]
@@ -62,19 +66,29 @@ def pick_concurrent_streams(engines, device=None, candidates=CANDIDATES, replays
             e.capture_segments((SEGMENT,))
         torch.cuda.synchronize(device)
         _pair_time(pair, (pool[0], pool[0]), device, 1)                     # first replay of a graph uploads it
-        serial = min(_pair_time(pair, (s, s), device, replays) for s in pool[:2])      # a stream can be slow by itself: best of two
+        # a stream can be slow by itself: best of two
+        alone = [min(_pair_time([e], (s,), device, replays) for s in pool[:2]) for e in pair]
+        serial = alone[0] + alone[1]
+        hi = None
+        pools = [pool, pool]
+        if prioritise_longer:
+            hi = 0 if alone[0] > alone[1] else 1
+            pools[hi] = [torch.cuda.Stream(device=device, priority=-1) for _ in range(n)]
         tried = {}
-        for j in range(1, len(pool)):
-            for i in range(j):
-                tried[(i, j)] = _pair_time(pair, (pool[i], pool[j]), device, replays)
+        for j in range(n):
+            for i in range(n if hi is not None else j):
+                # i indexes the first engine's pool, j the second's (one shared pool without priorities: i < j)
+                tried[(i, j)] = _pair_time(pair, (pools[0][i], pools[1][j]), device, replays)
                 if tried[(i, j)] <= accept * serial:
                     break
             else:
                 continue
             break
         (i, j), t = min(tried.items(), key=lambda kv: kv[1])
-        rep = dict(chosen=[i, j], us=round(t, 1), serial_us=round(serial, 1), tried={f"{a},{b}": round(v) for (a, b), v in tried.items()})
+        rep = dict(chosen=[i, j], us=round(t, 1), serial_us=round(serial, 1), alone_us=[round(v, 1) for v in alone], high_priority=hi,
+                   tried={f"{a},{b}": round(v) for (a, b), v in tried.items()})
         if report is not None:
             report.update(rep)
-        _CHOSEN[key] = ([pool[i], pool[j]] + [s for k, s in enumerate(pool) if k not in (i, j)], rep)
+        chosen = [pools[0][i], pools[1][j]]
+        _CHOSEN[key] = (chosen + [s for s in pool if s not in chosen], rep)
         return _CHOSEN[key][0][:len(engines)]

@@ -399,8 +399,9 @@ int hp_model_synchronize(HpModel* m, void* stream);
  * Which PAIR of streams really overlaps is decided by how the runtime maps streams onto hardware queues — a pair is concurrent, shares one
  * queue (= back to back) or time-slices (slower than back to back), depending on what else in the process created streams before
  * (DESIGN.md section 5.3).  hp_pick_concurrent_streams creates `candidates` (2..16) streams, times both models' "fwd_eval" graphs (which
- * change no parameter, statistic or counter) back to back on one stream and then on candidate pairs, and returns the first pair at or
- * below accept (0 = 0.85) x the serial time — else the fastest pair seen; the other candidates are destroyed.  Only the eval-mode output
+ * change no parameter, statistic or counter) each alone and then on candidate pairs — the model whose graph takes longer alone on a
+ * HIGH-priority stream, so that the two free-running chains finish together — and returns the first pair at or
+ * below accept (0 = 0.85) x the sum of the two alone — else the fastest pair seen; the other candidates are destroyed.  Only the eval-mode output
  * slots ("enc_eval", "rec_eval", ...) are overwritten.  The two streams belong to the caller (hp_stream_destroy).  report (may be NULL): pair us, serial us, pairs tried. */
 int hp_stream_create(void** out);
 int hp_stream_destroy(void* stream);

@@ -177,7 +177,7 @@ def test_plain_c_host_steps_two_models_on_picked_streams(tmp_path):
     out = subprocess.run([exe] + args + [str(steps)], check=True, capture_output=True, text=True, timeout=300).stdout
     lines = out.strip().splitlines()
     pick = dict(zip(lines[0].split()[1::2], lines[0].split()[2::2]))
-    assert lines[0].startswith("pick ") and pick["distinct"] == "1" and float(pick["pair_us"]) > 0 and 1 <= int(pick["tried"]) <= 15, out
+    assert lines[0].startswith("pick ") and pick["distinct"] == "1" and float(pick["pair_us"]) > 0 and 1 <= int(pick["tried"]) <= 36, out
     for j in range(2):
         got = np.array([[float(v) for v in ln.split()[4:]] for ln in lines if ln.startswith(f"model {j} step ")])
         assert got.shape == (steps, 4), out
