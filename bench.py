@@ -556,7 +556,7 @@ def main():
         pair.load_tables(data, perm)
     if world > 1 or force_dist:
         dist.all_reduce(torch.zeros(1, device=device))       # the communicator's own stream exists before the model streams are chosen
-    if not args.no_pick_streams:
+    if not args.no_pick_streams and pair.only is None:
         pair.pick_streams()
     stream_pair = dict(pair.stream_pair)
     pair.fork()

@@ -10,10 +10,12 @@ cd $R
 timeout -k 10 400 python bench.py --steps 300 --warmup 30 --per-op > $O/${T}_bench.json 2> $O/${T}_per_op.txt
 echo "bench done: $(cut -c1-160 $O/${T}_bench.json)"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $T -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe > $O/${T}_bench_under_rocprof.json 2> $O/${T}_rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $T -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe --no-pick-streams > $O/${T}_bench_under_rocprof.json 2> $O/${T}_rocprof.err
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/${T}_kernel_stats.csv \;
 find $O/prof -name "*kernel_trace.csv" -exec python3 $R/tools/timeline.py {} 50 5 \; > $O/${T}_timeline.txt 2>&1 || true
 echo "rocprof done: $(head -3 $O/${T}_timeline.txt | tail -1)"
+# (--no-pick-streams in the profiler runs: the stream-pair measurement replays the models' EVAL-forward graphs, whose conv launches — same kernel
+# names, different epilogue, partly on badly overlapping stream pairs — would be counted into rocprof's per-kernel averages and PMC means)
 # the same trace with ONE model stepping alone (its kernels never share the GPU: durations are the kernel's own)
 for m in 0 1; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_m$m -o $T -- python3 $R/bench.py --only-model $m --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe --no-profile > $O/${T}_bench_only_model$m.json 2> /dev/null
@@ -24,7 +26,7 @@ echo "single-model traces done"
 cd /tmp
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | tr ' ' '_')
-  timeout -k 10 280 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-trainer --no-profile --no-dp-probe > $O/pmc_$tag.log 2>&1
+  timeout -k 10 280 rocprofv3 --pmc $c --output-format csv -d $O/pmc_$tag -o pmc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-trainer --no-profile --no-dp-probe --no-pick-streams > $O/pmc_$tag.log 2>&1
   echo "pmc pass $tag done"
 done
 cd $R

@@ -21,7 +21,7 @@ if "TCC_HIT_sum" in mean:
 from bench import csrc_digest
 res["meta"] = {"csrc_digest": csrc_digest(), "batch": 512, "z_dim": 10, "wave_len": 50, "time_len": 100,
                "git_head": sys.argv[4] if len(sys.argv) > 4 else None,
-               "command": "rocprofv3 --pmc <counter> -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-trainer --no-profile --no-staged (one counter set per pass)"}
+               "command": "rocprofv3 --pmc <counter> -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-trainer --no-profile --no-dp-probe --no-pick-streams (one counter set per pass)"}
 res["per_kernel_mean"] = {c: {k: sum(v) / len(v) for k, v in sorted(d.items())} for c, d in by_kernel.items()}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_mean"}))
