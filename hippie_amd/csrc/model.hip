@@ -222,6 +222,20 @@ int hp_model_train_step(HpModel* m, int use_graph, void* stream) {
   if (rc == 0) rc = hp_model_optimizer_step(m, use_graph, stream);
   return rc;
 }
+int hp_model_train_step_staged(HpModel* m, int use_graph, void* stream) {
+  if (!m) return merr("hp_model_train_step_staged: null argument");
+  if (!find_segment(m, "stage")) return merr("hp_model_train_step_staged: the model was exported without resident tables (hippie_amd.export --resident-units N)");
+  int rc;
+  if (find_segment(m, "step_staged")) rc = hp_model_run(m, "step_staged", use_graph, stream);
+  else {
+    rc = hp_model_run(m, "stage", use_graph, stream);
+    if (rc == 0) rc = hp_model_run(m, "fwd_train", use_graph, stream);
+    if (rc == 0) rc = hp_model_run(m, "bwd", use_graph, stream);
+    if (rc == 0) rc = hp_model_run(m, "opt", use_graph, stream);
+  }
+  if (rc == 0) m->batches_tracked += 1;
+  return rc;
+}
 int64_t hp_model_batches_tracked(const HpModel* m) { return m ? m->batches_tracked : -1; }
 
 int hp_model_write(HpModel* m, const char* name, const void* src, int64_t nbytes, int src_on_device, void* stream) {

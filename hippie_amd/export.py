@@ -63,7 +63,8 @@ def save_model(plan, path, param_values=None, buf_values=None):
     sizes = arena_sizes(plan)
     cfg = plan.cfg
     config = [1 if cfg.kind == "multimodal" else 0, cfg.z_dim, cfg.output_size, cfg.output_size2, cfg.class_hidden_dim, cfg.num_sources,
-              cfg.num_classes, plan.B, 1 if plan.with_class else 0, plan.n_active] + [0] * 6
+              cfg.num_classes, plan.B, 1 if plan.with_class else 0, plan.n_active,
+              plan.train.resident_units, plan.train.dp_world, plan.train.dp_rank] + [0] * 3
     has_init = (1 if param_values is not None else 0) | (2 if buf_values is not None else 0)
     with open(path, "wb") as f:
         f.write(MAGIC)
@@ -150,11 +151,16 @@ def main(argv=None):
     ap.add_argument("--weight-decay", type=float, default=0.01)
     ap.add_argument("--beta", type=float, default=1.0)
     ap.add_argument("--clip", type=float, default=0.0)
+    ap.add_argument("--resident-units", type=int, default=0, help="N > 0: the training tables live in the workspace and the file also holds the "
+                    "'stage' / 'step_staged' segments (hp_model_train_step_staged: loader + step as one graph)")
+    ap.add_argument("--dp-world", type=int, default=1)
+    ap.add_argument("--dp-rank", type=int, default=0)
     ap.add_argument("--seed", type=int, default=None, help="also store the reference constructor's random initialisation under this torch seed")
     ap.add_argument("-o", "--output", required=True)
     a = ap.parse_args(argv)
     cfg = planner.ModelCfg(a.kind, a.z_dim, a.output_size, a.output_size2, 5, a.num_sources, a.num_classes)
-    plan = planner.lower(cfg, a.batch, planner.TrainCfg(lr=a.lr, weight_decay=a.weight_decay, beta=a.beta, clip=a.clip), with_class=a.with_class)
+    plan = planner.lower(cfg, a.batch, planner.TrainCfg(lr=a.lr, weight_decay=a.weight_decay, beta=a.beta, clip=a.clip, resident_units=a.resident_units,
+                                                        dp_world=a.dp_world, dp_rank=a.dp_rank), with_class=a.with_class)
     pv = bv = None
     if a.seed is not None:
         import torch

@@ -350,7 +350,8 @@ int hp_run_op(const HpOp* op, void* const bases[HP_NUM_SPACES], void* stream);
  * (loss, mse1, mse2, kl_mean) of the last forward, "enc_train" / "enc_eval" float[B][z] (the embedding), "mulv_*"
  * float[B][2z] = (mu | logvar), "rec_*" / "rec2_*" reconstructions, "adam_step" int64[1].  Parameters are addressed by
  * their reference keys ("encoder.conv1.weight", ...); layout 1 = conv weight stored tap-major [k][Cout][Cin].
- * Segments: "fwd_train", "bwd", "opt", "step" (= the three, one graph), "fwd_eval", "enc_eval" (encoder half only). */
+ * Segments: "fwd_train", "bwd", "opt", "step" (= the three, one graph), "fwd_eval", "enc_eval" (encoder half only); with resident
+ * tables also "stage" (HP_OP_STAGE_BATCH + cursor increment), "step_staged" (= stage + step), "fwd_train_staged". */
 typedef struct HpModel HpModel;
 typedef struct HpTensorInfo {
   char name[112];           /* reference state_dict key, or I/O slot name */
@@ -384,6 +385,14 @@ int hp_model_forward(HpModel* m, int training, int use_graph, void* stream);
 int hp_model_backward(HpModel* m, int use_graph, void* stream);
 int hp_model_optimizer_step(HpModel* m, int use_graph, void* stream);
 int hp_model_train_step(HpModel* m, int use_graph, void* stream);
+/* The same step INCLUDING the loader (HP_OP_STAGE_BATCH: batch gather by index from HBM-resident tables + Philox noise), for a model
+ * exported with `--resident-units N`: one graph replay per optimisation step, nothing of the host in it.  Before the first step write
+ * the slots "data_x" float[N][L] (multimodal: + "data_x2" float[N][L2]), "data_labels" int64[N] (source ids), "perm" int64[N] (the
+ * epoch's shuffle: batch j is perm[j*B .. (j+1)*B)), "seed" int64[1]; "cursor" int64[1] counts the steps taken (write 0 to restart;
+ * it wraps over N / (B * world) batches).  config[10..12] of hp_model_config = N, data-parallel world, rank.  Replaces
+ * DataLoader(..., batch_size, shuffle=True) + training_step + backward + optimizer.step (scripts/train_model_with_multimodal.py:155-166,
+ * 200-224).  Under data parallelism use hp_model_run("stage" | "fwd_train" | "bwd"), the host's all-reduce, then "opt". */
+int hp_model_train_step_staged(HpModel* m, int use_graph, void* stream);
 /* BatchNorm num_batches_tracked (training forwards so far; the reference keeps it as an int64 buffer per layer). */
 int64_t hp_model_batches_tracked(const HpModel* m);
 /* Copy nbytes (must equal the tensor's size) into / out of a named tensor, stream-ordered; a host destination is

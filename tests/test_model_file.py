@@ -183,3 +183,86 @@ def test_plain_c_host_steps_two_models_on_picked_streams(tmp_path):
         assert got.shape == (steps, 4), out
         np.testing.assert_allclose(got, wants[j], rtol=1e-5)        # same kernels; only the order of atomic sums differs
         assert f"model {j} batches_tracked {steps}" in out
+
+
+def test_staged_model_file_config_and_segments(tmp_path):
+    """--resident-units: the file carries the loader segments and says so in its config words (no GPU needed)."""
+    cfg = planner.ModelCfg("unimodal", 10, 50)
+    plan = planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, resident_units=40, dp_world=2, dp_rank=1))
+    path = str(tmp_path / "staged.hpm")
+    export.save_model(plan, path)
+    d = export.read_model(path)
+    assert d["config"][10:13] == [40, 2, 1]
+    assert {"stage", "step_staged", "fwd_train_staged"} <= set(d["segments"])
+    assert {"data_x", "data_labels", "perm", "seed", "cursor"} <= {t["name"].decode() for t in d["io"]}
+    lib = P.load_library()
+    m = ctypes.c_void_p()
+    assert lib.hp_model_load(path.encode(), export.NO_DEVICE, ctypes.byref(m)) == 0, lib.hp_last_error()
+    out = (ctypes.c_int32 * 16)()
+    assert lib.hp_model_config(m, out) == 0 and list(out)[10:13] == [40, 2, 1]
+    assert lib.hp_model_train_step_staged(m, 1, None) != 0 and b"HP_MODEL_NO_DEVICE" in lib.hp_last_error()
+    lib.hp_model_destroy(m)
+    # a file without resident tables refuses the staged verb by name
+    plan2, om, path2, pv, bv = _export(tmp_path, B=4)
+    assert lib.hp_model_load(path2.encode(), export.NO_DEVICE, ctypes.byref(m)) == 0
+    assert lib.hp_model_train_step_staged(m, 1, None) != 0 and b"resident" in lib.hp_last_error()
+    lib.hp_model_destroy(m)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_graph", [1, 0])
+def test_c_level_staged_steps_match_the_python_engine(tmp_path, use_graph):
+    """hp_model_train_step_staged (loader + step in one graph) through ctypes against Engine.train_step_staged on the same tables,
+    permutation and seed: same kernels, same Philox noise -> the same scalars step by step."""
+    from hippie_amd.engine import Engine
+    z, L, B, N, lr, steps = 10, 50, 16, 80, 1e-6, 4
+    cfg = planner.ModelCfg("unimodal", z, L)
+    tc = planner.TrainCfg(lr=lr, clip=1.0, resident_units=N)
+    plan = planner.lower(cfg, B, tc)
+    om = O.OracleModel("unimodal", z, L, salt=7)
+    pv, bv = export.arena_values(plan, {k: v.detach() for k, v in om.state.items()})
+    path = str(tmp_path / "staged.hpm")
+    export.save_model(plan, path, pv, bv)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, L, generator=g)
+    labels = torch.randint(0, 5, (N,), generator=g)
+    perm = torch.randperm(N, generator=g)
+    seed = 99
+
+    eng = Engine(cfg, B, tc)
+    eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    eng.load_dataset(x.cuda(), labels.cuda(), perm=perm.cuda(), seed=seed)
+    want = []
+    for _ in range(steps):
+        eng.train_step_staged(use_graph=bool(use_graph))
+        want.append(eng.scalars())
+
+    lib = P.load_library()
+    m = ctypes.c_void_p()
+    assert lib.hp_model_load(path.encode(), 0, ctypes.byref(m)) == 0, lib.hp_last_error()
+
+    def write(name, arr):
+        a = np.ascontiguousarray(arr)
+        assert lib.hp_model_write(m, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.nbytes, 0, None) == 0, lib.hp_last_error()
+        assert lib.hp_model_synchronize(m, None) == 0
+
+    write("data_x", x.numpy().astype(np.float32))
+    write("data_labels", labels.numpy().astype(np.int64))
+    write("perm", perm.numpy().astype(np.int64))
+    write("seed", np.array([seed], dtype=np.int64))
+    write("cursor", np.array([0], dtype=np.int64))
+    got = []
+    for _ in range(steps):
+        assert lib.hp_model_train_step_staged(m, use_graph, None) == 0, lib.hp_last_error()
+        sc = (ctypes.c_float * 4)()
+        assert lib.hp_model_read(m, b"scalars", sc, 16, 0, None) == 0
+        got.append(list(sc))
+    cur = (ctypes.c_int64 * 1)()
+    assert lib.hp_model_read(m, b"cursor", cur, 8, 0, None) == 0 and cur[0] == steps
+    assert lib.hp_model_batches_tracked(m) == steps
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=1e-5)
+    # the batch the last step trained on is the permutation's: row b of "x" is table row perm[(steps-1)*B + b]
+    xb = np.zeros((B, L), dtype=np.float32)
+    assert lib.hp_model_read(m, b"x", xb.ctypes.data_as(ctypes.c_void_p), xb.nbytes, 0, None) == 0
+    np.testing.assert_array_equal(xb, x.numpy()[perm.numpy()[(steps - 1) * B: steps * B]])
+    lib.hp_model_destroy(m)
