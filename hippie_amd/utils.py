@@ -21,3 +21,16 @@ def get_embeddings(dataloader_wave, dataloader_time, wave_model, time_model):
     ew = torch.cat(emb_w, dim=0).detach().cpu().numpy()
     et = torch.cat(emb_t, dim=0).detach().cpu().numpy()
     return ew, et, np.concatenate([ew, et], axis=1)
+
+
+def get_embeddings_multimodal(loader, model):
+    """scripts/train_model_with_multimodal.py:22-35: forward every (data1, data2, labels) batch through the multimodal module in eval
+    mode, keep `enc` (output[0]) and row-standardise it with numpy's POPULATION std (np.std, ddof=0 — unlike get_embeddings above,
+    which follows scripts/utils.py and torch.std).  Returns one numpy array [N, z]."""
+    model.eval()
+    out = []
+    for sample in loader:
+        e = model(sample)[0].detach().cpu().numpy()
+        e = (e - np.mean(e, axis=1, keepdims=True)) / np.std(e, axis=1, keepdims=True)
+        out.extend(e)
+    return np.array(out)

@@ -19,6 +19,11 @@ LabelEncoder + `random_split` at --train-val-split, `[class, source]` label pair
 PRETRAIN checkpoints minus `class_embedding` (strict=False), lr/10, gradient clipping on BOTH trainers, best
 checkpoint (+ optimiser state) reloaded, embeddings at batch 128, the 5..19-neighbour kNN sweep (scikit-learn, CPU)
 and the `{dataset}_{waveform,isi,joint}_{knn,embeddings}.csv` files.
+
+`--model-type multimodal` (:618-790): ONE MultiModalCVAE over (waveform, isi) pairs, pretrain -> label-free fine-tune at lr / 10 ->
+`pretraining_{dataset}_joint_embeddings.csv`.  The reference's own branch cannot get past its first dataset — it asks
+EphysDatasetLabeled for mode="both", which the class asserts away (hippie/dataloading.py:67) — so this is the branch with the dataset
+its training_step expects, (waveform, isi, label) rows (main_multimodal).
 """
 import argparse
 import json
@@ -155,13 +160,111 @@ class _Concat:
         return _L()
 
 
+class _ConcatJoint:
+    """The dataset the reference's multimodal branch MEANT to build (scripts/...:638 asks EphysDatasetLabeled for mode="both", which
+    its constructor refuses, dataloading.py:67): rows of (waveform[1,50], isi[1,100], label) — what MultiModalCVAETrainModule's
+    training_step unpacks (hippie/model.py:454-458) and what EphysDataset's own mode "both" returns (dataloading.py:55-56)."""
+
+    def __init__(self, wave_parts, time_parts):
+        self.wave, self.time = _Concat(wave_parts), _Concat(time_parts)
+        assert torch.equal(self.wave.labels, self.time.labels)
+        self.labels = self.wave.labels
+
+    def loader(self, indices, batch_size, shuffle):
+        indices = list(indices)
+        index_loader = torch.utils.data.DataLoader(indices, batch_size=batch_size, shuffle=shuffle)
+        t = self
+
+        def rows(j):
+            j = j.to(t.wave.data.device)
+            return t.wave.data.index_select(0, j).unsqueeze(1), t.time.data.index_select(0, j).unsqueeze(1), t.labels.index_select(0, j)
+
+        class _L:
+            def __iter__(s):
+                for j in index_loader:
+                    yield rows(j)
+
+            def __len__(s):
+                return len(index_loader)
+
+            def shard(s, rank, world, epoch, seed=0):
+                from hippie_amd.parallel import shard_indices
+                pos = shard_indices(len(indices), rank, world, epoch=epoch, seed=seed, shuffle=shuffle)
+                mine = torch.as_tensor(indices, dtype=torch.int64)[pos]
+                for i in range(0, len(mine), batch_size):
+                    yield rows(mine[i: i + batch_size])
+        return _L()
+
+
+def main_multimodal(args, eps_source, rank0):
+    """The multimodal branch of the reference script (scripts/train_model_with_multimodal.py:618-790): ONE MultiModalCVAE over
+    (waveform, isi) pairs — pretraining on the pool, label-free fine-tuning on the target at a tenth of the learning rate, joint
+    embeddings CSV.  As written the reference stops at its first dataset (mode="both" is asserted away, dataloading.py:67); this is
+    the branch with that dataset returning (waveform, isi, label), everything else as there: gradient clipping on, --beta and the
+    modality weights honoured (:670-677), a single pretraining_{dataset}_joint_embeddings.csv standardised with np.std (:22-35)."""
+    from hippie_amd.model import MultiModalCVAE, MultiModalCVAETrainModule
+    from hippie_amd.utils import get_embeddings_multimodal
+    num_sources = max(DATASET_FILES.values()) + 1
+    wave_parts, time_parts = [], []
+    for folder, sid in pretrain_pool(args.dataset).items():
+        wf = pd.read_csv(os.path.join(args.data_root, folder, "waveforms.csv")).to_numpy()
+        isi = pd.read_csv(os.path.join(args.data_root, folder, "isi_dist.csv")).to_numpy()
+        source = np.full((wf.shape[0]), sid)
+        print(f"Folder {folder} has shapes {wf.shape} and {isi.shape}")
+        wave_parts.append(EphysDatasetLabeled(wf, isi, source, mode="wave", normalize=False))
+        time_parts.append(EphysDatasetLabeled(wf, isi, source, mode="time", normalize=False))
+    joint = _ConcatJoint(wave_parts, time_parts)
+    n = len(joint.labels)
+    prop = args.train_val_split
+    train_idx, test_idx = random_split(list(range(n)), [int(prop * n), n - int(prop * n)])
+    bs = args.batch_size
+
+    def trainer(epochs, tag):
+        return Trainer(max_epochs=epochs, gradient_clip_val=args.gradient_clip_val, patience=args.early_stopping_patience,
+                       default_root_dir=os.path.join(args.output_dir, "checkpoints", f"joint_{tag}"),
+                       logger_path=os.path.join(args.output_dir, f"joint_{tag}_log.jsonl"),
+                       precision=args.precision, strategy=args.strategy, sync_batchnorm=args.sync_batchnorm)
+
+    net = MultiModalCVAE(z_dim=args.z_dim, output_size_wave=50, output_size_isi=100, class_hidden_dim=5, num_sources=num_sources, num_classes=5)
+    net.set_eps_source(eps_source)
+    mod = MultiModalCVAETrainModule(net, learning_rate=args.learning_rate, weight_decay=args.weight_decay, beta=args.beta,
+                                    mod1_weight=args.mod1_weight, mod2_weight=args.mod2_weight)
+    tr = trainer(args.pretrain_max_epochs, "pretrain")
+    tr.fit(mod, joint.loader(train_idx, bs, True), joint.loader(test_idx, bs, False))
+    if tr.best_model_path:
+        mod.load_state_dict(torch.load(tr.best_model_path, weights_only=False)["state_dict"])
+    wf_ft = pd.read_csv(os.path.join(args.data_root, args.dataset, "waveforms.csv")).dropna(axis=1).to_numpy()
+    isi_ft = pd.read_csv(os.path.join(args.data_root, args.dataset, "isi_dist.csv")).dropna(axis=1).to_numpy()
+    label_ft = np.full((wf_ft.shape[0]), DATASET_FILES[args.dataset])
+    ft = _ConcatJoint([EphysDatasetLabeled(wf_ft, isi_ft, label_ft, mode="wave", normalize=False)],
+                      [EphysDatasetLabeled(wf_ft, isi_ft, label_ft, mode="time", normalize=False)])
+    m = len(label_ft)
+    if args.finetune_without_labels:
+        p2 = args.finetune_split
+        tr_i, te_i = random_split(list(range(m)), [int(p2 * m), m - int(p2 * m)])
+        mod = MultiModalCVAETrainModule(mod.model, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay, beta=args.beta,
+                                        mod1_weight=args.mod1_weight, mod2_weight=args.mod2_weight)
+        tr2 = trainer(args.finetune_max_epochs, "finetune")
+        tr2.fit(mod, ft.loader(tr_i, bs, False), ft.loader(te_i, bs, False))
+        if tr2.best_model_path:
+            mod.load_state_dict(torch.load(tr2.best_model_path, weights_only=False)["state_dict"])
+        emb = get_embeddings_multimodal(ft.loader(te_i, bs, False), mod)       # the held-out 90 % (:775)
+    else:
+        emb = get_embeddings_multimodal(ft.loader(range(m), bs, False), mod)
+    path = os.path.join(args.output_dir, f"pretraining_{args.dataset}_joint_embeddings.csv")
+    if rank0:
+        pd.DataFrame({"embeddings": list(emb)}).to_csv(path)
+        with open(os.path.join(args.output_dir, "run_config.json"), "w") as f:
+            json.dump(vars(args), f)
+    if args.supervised:
+        raise SystemExit("--supervised is reproduced for the unimodal branch only (scripts/...:349-616)")
+    return {"joint": path}
+
+
 def main(argv=None, eps_source=None):
     """eps_source: callable(engine) -> [B, z] noise for every forward of the networks built here (parity tests run the whole
     pipeline on a prescribed sequence); None = torch's device generator, as the reference's torch.randn_like."""
     args = build_parser().parse_args(argv)
-    if args.model_type != "unimodal":
-        raise SystemExit("the reference's multimodal script branch builds EphysDatasetLabeled(mode='both'), which its own "
-                         "dataset class rejects (dataloading.py:67); only the unimodal pipeline is reproduced")
     os.makedirs(args.output_dir, exist_ok=True)
     # under a launcher (torchrun: one process per GPU) this is a DDP run, as Lightning would make it (scripts/...:200-207):
     # RCCL ("nccl") over xGMI, rank r on GPU LOCAL_RANK; rank 0 writes checkpoints, logs and CSVs
@@ -174,6 +277,8 @@ def main(argv=None, eps_source=None):
         dist.init_process_group(os.environ.get("HIPPIE_DIST_BACKEND", "nccl"))
     rank0 = not dist.is_initialized() or dist.get_rank() == 0
     torch.manual_seed(42)
+    if args.model_type == "multimodal":
+        return main_multimodal(args, eps_source, rank0)
     num_sources = max(DATASET_FILES.values()) + 1
     wave_parts, time_parts = [], []
     for folder, sid in pretrain_pool(args.dataset).items():

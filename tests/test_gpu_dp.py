@@ -370,20 +370,22 @@ def test_rccl_world1_data_parallel_step_equals_plain_step_bit_for_bit():
         assert sa == sb, (sa, sb)
 
 
-def _pipeline_rank(rank, world, port, data_root, out_dir, q):
+def _pipeline_rank(rank, world, port, data_root, out_dir, q, model_type="unimodal"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
                       HIPPIE_SINGLE_DEVICE="1", HIPPIE_DIST_BACKEND="gloo")
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
     import pretrain_pipeline as pp
     paths = pp.main(["--dataset", "cellexplorer-celltype", "--data-root", data_root, "--output-dir", out_dir, "--batch-size", "32",
-                     "--pretrain-max-epochs", "2", "--finetune-max-epochs", "1", "--z_dim", "5", "--learning-rate", "1e-4", "--strategy", "ddp"])
+                     "--pretrain-max-epochs", "2", "--finetune-max-epochs", "1", "--z_dim", "5", "--learning-rate", "1e-4", "--strategy", "ddp",
+                     "--model-type", model_type])
     q.put((rank, paths))
     dist.destroy_process_group()
 
 
-def test_pipeline_script_runs_data_parallel_under_a_launcher(tmp_path):
-    """BASELINE configs[3]'s route: `torchrun --nproc-per-node N scripts/pretrain_pipeline.py` — here two ranks started by hand (gloo,
+@pytest.mark.parametrize("model_type", ["unimodal", "multimodal"])
+def test_pipeline_script_runs_data_parallel_under_a_launcher(tmp_path, model_type):
+    """BASELINE configs[3]'s route (multimodal: configs[4]'s): `torchrun --nproc-per-node N scripts/pretrain_pipeline.py` — here two ranks started by hand (gloo,
     both on the one GPU): the script initialises the process group itself, shards its loaders, trains both models data-parallel
     (pretrain -> rank-0 checkpoint reload on every rank -> fine-tune), and rank 0 alone writes logs, checkpoints and the CSVs."""
     import pandas as pd
@@ -396,7 +398,7 @@ def test_pipeline_script_runs_data_parallel_under_a_launcher(tmp_path):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_rank, args=(r, world, port, str(data), str(out), q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_rank, args=(r, world, port, str(data), str(out), q, model_type)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=900) for _ in range(world))
@@ -404,12 +406,14 @@ def test_pipeline_script_runs_data_parallel_under_a_launcher(tmp_path):
         p.join(120)
         assert p.exitcode == 0
     assert res[0] == res[1]
-    for name in ("waveform", "isi", "joint"):
+    multimodal = model_type == "multimodal"
+    for name in (("joint",) if multimodal else ("waveform", "isi", "joint")):
         df = pd.read_csv(res[0][name])
         emb = np.stack([np.array(v.strip("[]").split(), dtype=float) for v in df["embeddings"]])
-        assert np.isfinite(emb).all() and emb.shape[1] == (10 if name == "joint" else 5)
+        assert np.isfinite(emb).all() and emb.shape[1] == (5 if multimodal or name != "joint" else 10)
     logs = sorted(f for f in os.listdir(out) if f.endswith("_log.jsonl"))
-    assert logs == ["time_finetune_log.jsonl", "time_pretrain_log.jsonl", "wave_finetune_log.jsonl", "wave_pretrain_log.jsonl"]
+    assert logs == (["joint_finetune_log.jsonl", "joint_pretrain_log.jsonl"] if multimodal else
+                    ["time_finetune_log.jsonl", "time_pretrain_log.jsonl", "wave_finetune_log.jsonl", "wave_pretrain_log.jsonl"])
     import json
-    rec = [json.loads(ln) for ln in open(out / "wave_pretrain_log.jsonl")]
+    rec = [json.loads(ln) for ln in open(out / ("joint_pretrain_log.jsonl" if multimodal else "wave_pretrain_log.jsonl"))]
     assert len(rec) == 2 and all(r["world_size"] == 2 for r in rec)            # written once (rank 0), two epochs

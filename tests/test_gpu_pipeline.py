@@ -61,6 +61,36 @@ def test_pipeline_end_to_end(tmp_path):
     assert len(tr) == int(0.8 * n) and len(set(tr.indices) & set(te.indices)) == 0
 
 
+@pytest.mark.parametrize("extra", [[], ["--precision", "bf16", "--mod1-weight", "0.7", "--mod2-weight", "1.3", "--beta", "0.5"]])
+def test_multimodal_pipeline_branch(tmp_path, extra):
+    """--model-type multimodal: the branch the reference script means to run (:618-790; as shipped it stops at
+    EphysDatasetLabeled(mode="both"), dataloading.py:67): one MultiModalCVAE pretrained on the pool, fine-tuned without labels at lr / 10,
+    the held-out 90 % of the target embedded and row-standardised with np.std (get_embeddings_multimodal, :22-35)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pretrain_pipeline as pp
+    rng = np.random.default_rng(1)
+    data = tmp_path / "datasets"
+    data.mkdir()
+    spec = make_root(data, rng)
+    out = tmp_path / "out"
+    paths = pp.main(["--dataset", "cellexplorer-area", "--model-type", "multimodal", "--data-root", str(data), "--output-dir", str(out),
+                     "--batch-size", "64", "--pretrain-max-epochs", "2", "--z_dim", "6"] + extra)
+    assert set(paths) == {"joint"}
+    m = spec["cellexplorer-area"][0]
+    df = pd.read_csv(paths["joint"])
+    assert list(df.columns) == ["Unnamed: 0", "embeddings"] and len(df) == m - int(0.1 * m)
+    emb = np.array([np.array(v.strip("[]").split(), dtype=float) for v in df["embeddings"]])
+    assert emb.shape == (m - int(0.1 * m), 6) and np.isfinite(emb).all()
+    np.testing.assert_allclose(emb.mean(1), 0, atol=1e-6)
+    np.testing.assert_allclose(emb.std(1), 1, atol=1e-5)          # population std, as np.std in the reference's helper
+    logs = sorted(l for l in os.listdir(out) if l.endswith("_log.jsonl"))
+    assert logs == ["joint_finetune_log.jsonl", "joint_pretrain_log.jsonl"]
+    import json
+    recs = [json.loads(l) for l in open(out / "joint_pretrain_log.jsonl")]
+    assert len(recs) == 2 and all(np.isfinite(r["val_loss"]) for r in recs) and "train_mse_loss1" in recs[0] and "train_mse_loss2" in recs[0]
+    assert any(f.endswith(".ckpt") for f in os.listdir(out / "checkpoints" / "joint_pretrain"))
+
+
 def test_supervised_stage(tmp_path):
     """--supervised: class labels, balanced sampler, class_embedding re-created, kNN + embedding CSVs."""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
