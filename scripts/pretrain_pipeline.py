@@ -23,7 +23,7 @@ and the `{dataset}_{waveform,isi,joint}_{knn,embeddings}.csv` files.
 `--model-type multimodal` (:618-790): ONE MultiModalCVAE over (waveform, isi) pairs, pretrain -> label-free fine-tune at lr / 10 ->
 `pretraining_{dataset}_joint_embeddings.csv`.  The reference's own branch cannot get past its first dataset — it asks
 EphysDatasetLabeled for mode="both", which the class asserts away (hippie/dataloading.py:67) — so this is the branch with the dataset
-its training_step expects, (waveform, isi, label) rows (main_multimodal).
+its training_step expects, (waveform, isi, label) rows (main_multimodal); `--supervised` runs its supervised stage (:790-960) too.
 """
 import argparse
 import json
@@ -256,9 +256,83 @@ def main_multimodal(args, eps_source, rank0):
         pd.DataFrame({"embeddings": list(emb)}).to_csv(path)
         with open(os.path.join(args.output_dir, "run_config.json"), "w") as f:
             json.dump(vars(args), f)
+    paths = {"joint": path}
     if args.supervised:
-        raise SystemExit("--supervised is reproduced for the unimodal branch only (scripts/...:349-616)")
-    return {"joint": path}
+        paths.update(supervised_stage_multimodal(args, num_sources, tr.best_model_path, trainer, eps_source))
+    return paths
+
+
+def supervised_stage_multimodal(args, num_sources, joint_path, trainer, eps_source=None):
+    """scripts/train_model_with_multimodal.py:790-960 (multimodal branch; the same stage as supervised_stage below for ONE joint model):
+    LabelEncoder + random_split, [class, source] label pairs, BalancedBatchSampler at --supervised-batch-size, a fresh MultiModalCVAE with
+    num_classes = #train classes loaded from the PRETRAIN checkpoint minus class_embedding (strict=False), lr / 10, gradient clipping,
+    best checkpoint reloaded, embeddings at batch 128, the 5..19-neighbour kNN sweep, {dataset}_joint_{knn,embeddings}.csv."""
+    from sklearn.metrics import balanced_accuracy_score, confusion_matrix
+    from sklearn.neighbors import KNeighborsClassifier
+    from sklearn.preprocessing import LabelEncoder
+    from hippie_amd.dataloading import BalancedBatchSampler
+    from hippie_amd.model import MultiModalCVAE, MultiModalCVAETrainModule
+    from hippie_amd.utils import get_embeddings_multimodal
+    dataset = args.dataset
+    root = os.path.join(args.data_root, dataset)
+    sup_wf = pd.read_csv(os.path.join(root, "waveforms.csv")).to_numpy()
+    sup_isi = pd.read_csv(os.path.join(root, "isi_dist.csv")).to_numpy()
+    if os.path.exists(os.path.join(root, "labels.csv")):
+        raw = pd.read_csv(os.path.join(root, "labels.csv"))[args.label_column].values
+        le = LabelEncoder().fit(raw)
+        sup_labels = le.transform(raw)
+    else:
+        print(f"No labels.csv found for {dataset}")
+        sup_labels = np.zeros(len(sup_wf))
+        le = LabelEncoder().fit(sup_labels)
+    n = len(sup_wf)
+    train_size = int(args.train_val_split * n)
+    tr_i, va_i = random_split(list(range(n)), [train_size, n - train_size])
+    tr_i, va_i = list(tr_i), list(va_i)
+    label_train, label_val = sup_labels[tr_i], sup_labels[va_i]
+    num_class_labels = len(np.unique(label_train))
+    sid = DATASET_FILES[dataset]
+
+    def table(idx, lab):
+        pair = np.vstack((lab, sid * np.ones_like(lab))).T             # [class, source], model.py:456-458
+        return _ConcatJoint([EphysDatasetLabeled(sup_wf[idx], sup_isi[idx], pair, mode="wave", normalize=False)],
+                            [EphysDatasetLabeled(sup_wf[idx], sup_isi[idx], pair, mode="time", normalize=False)])
+    tr_t, va_t = table(tr_i, label_train), table(va_i, label_val)
+    net = MultiModalCVAE(z_dim=args.z_dim, output_size_wave=50, output_size_isi=100, class_hidden_dim=5, num_sources=num_sources,
+                         num_classes=num_class_labels)
+    net.set_eps_source(eps_source)
+    mod = MultiModalCVAETrainModule(net, learning_rate=(1 / 10) * args.learning_rate, weight_decay=args.weight_decay, beta=args.beta,
+                                    mod1_weight=args.mod1_weight, mod2_weight=args.mod2_weight)
+    if joint_path:
+        sd = torch.load(joint_path, weights_only=False)["state_dict"]
+        sd.pop("model.class_embedding.weight")
+        mod.load_state_dict(sd, strict=False)
+    order = list(BalancedBatchSampler(range(len(tr_i)), torch.as_tensor(label_train)))
+    sb = args.supervised_batch_size
+    tr = trainer(args.supervised_max_epochs, "supervised")
+    tr.fit(mod, tr_t.loader(order, sb, False), va_t.loader(range(len(va_i)), sb, False))
+    if tr.best_model_path:
+        mod.load_state_dict(torch.load(tr.best_model_path, weights_only=False)["state_dict"])
+    mod.eval()
+    e_tr = get_embeddings_multimodal(tr_t.loader(range(len(tr_i)), 128, False), mod)
+    e_va = get_embeddings_multimodal(va_t.loader(range(len(va_i)), sb, False), mod)
+    neighbor_options = list(range(5, 20))
+    acc = []
+    for k in neighbor_options:
+        knn = KNeighborsClassifier(n_neighbors=min(k, len(e_tr))).fit(e_tr, label_train)
+        acc.append(balanced_accuracy_score(label_val, knn.predict(e_va)))
+    best_k = neighbor_options[int(np.argmax(acc))]
+    pred = KNeighborsClassifier(n_neighbors=min(best_k, len(e_tr))).fit(e_tr, label_train).predict(e_va)
+    confusion_matrix(label_val, pred)
+    out = {"joint_balanced_accuracy": acc}
+    out["joint_knn"] = os.path.join(args.output_dir, f"{dataset}_joint_knn.csv")
+    pd.DataFrame({"pred": le.inverse_transform(pred.astype(int)), "true": le.inverse_transform(label_val.astype(int))}).to_csv(out["joint_knn"])
+    e_all = get_embeddings_multimodal(table(list(range(n)), sup_labels).loader(range(n), 128, False), mod)
+    df = pd.DataFrame(e_all)
+    df["label"] = le.inverse_transform(sup_labels.astype(int))
+    out["joint_supervised_embeddings"] = os.path.join(args.output_dir, f"{dataset}_joint_embeddings.csv")
+    df.to_csv(out["joint_supervised_embeddings"])
+    return out
 
 
 def main(argv=None, eps_source=None):

@@ -119,6 +119,28 @@ def test_supervised_stage(tmp_path):
     assert any(f.endswith(".ckpt") for f in os.listdir(out / "checkpoints" / "wave_supervised"))
 
 
+def test_supervised_stage_multimodal(tmp_path):
+    """--model-type multimodal --supervised (scripts/...:790-960): one joint model, joint kNN + embedding CSVs."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import pretrain_pipeline as pp
+    rng = np.random.default_rng(4)
+    data = tmp_path / "datasets"
+    data.mkdir()
+    spec = make_root(data, rng)
+    n = spec["extracellular-mouse-a1"][0]
+    names = np.array(["PV", "SST", "PYR"])[rng.choice(3, size=n, p=[0.5, 0.3, 0.2])]
+    pd.DataFrame({"0": names}).to_csv(data / "extracellular-mouse-a1" / "labels.csv")
+    out = tmp_path / "out"
+    paths = pp.main(["--dataset", "extracellular-mouse-a1", "--model-type", "multimodal", "--data-root", str(data), "--output-dir", str(out),
+                     "--batch-size", "64", "--supervised-batch-size", "16", "--z_dim", "5", "--supervised", "--label-column", "0"])
+    knn = pd.read_csv(paths["joint_knn"])
+    assert list(knn.columns) == ["Unnamed: 0", "pred", "true"] and len(knn) == n - int(0.8 * n) and set(knn["pred"]) <= {"PV", "SST", "PYR"}
+    emb = pd.read_csv(paths["joint_supervised_embeddings"])
+    assert len(emb) == n and list(emb.columns)[-1] == "label" and emb.shape[1] == 5 + 2
+    assert np.isfinite(emb[[str(i) for i in range(5)]].to_numpy()).all() and len(paths["joint_balanced_accuracy"]) == 15
+    assert any(f.endswith(".ckpt") for f in os.listdir(out / "checkpoints" / "joint_supervised"))
+
+
 def test_inference_script_roundtrip(tmp_path):
     """checkpoints written by the Trainer -> scripts/inference.py -> embedding CSVs in the reference's layout"""
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
