@@ -408,6 +408,33 @@ def trainer_rate(device, data, epochs=2):
                     "(hippie_amd.trainer.fit_concurrently), as scripts/pretrain_pipeline.py runs them"}
 
 
+def embedding_rate(device, data, passes=3):
+    """Throughput of the REFERENCE-API inference path (scripts/inference_from_trained_model.py:130-151 -> scripts/utils.py:75-101):
+    hippie_amd.utils.get_embeddings over the whole synthetic pool at batch 512 — both modules in eval mode, `enc` of every batch
+    (eval-mode BatchNorm folded into the conv epilogues, decoder skipped), row-standardised, wave | time concatenated, copied to the host.
+    units/s = N * passes / wall time."""
+    from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
+    from hippie_amd.utils import get_embeddings
+    N = data[0].shape[0]
+    mods, loaders = [], []
+    for k in range(2):
+        net = hippieUnimodalCVAE(z_dim=Z_DIM, output_size=data[k].shape[1], class_hidden_dim=5, num_sources=5, num_classes=5, device=device)
+        mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-3, weight_decay=0.01)
+        mod.eval()
+        mods.append(mod)
+        x, labels = data[k], data[2]
+        loaders.append([(x[i: i + BATCH].unsqueeze(1), labels[i: i + BATCH]) for i in range(0, N, BATCH)])
+    get_embeddings(loaders[0], loaders[1], mods[0], mods[1])          # warm-up: lowers + captures the eval graphs
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        ew, et, joint = get_embeddings(loaders[0], loaders[1], mods[0], mods[1])
+    dt = time.perf_counter() - t0
+    assert joint.shape == (N, 2 * Z_DIM) and np.isfinite(joint).all()
+    return {"value": N * passes / dt, "unit": "units/s", "passes": passes, "units_per_pass": N, "batch": BATCH, "wall_s": dt,
+            "path": "hippie_amd.utils.get_embeddings (wave + time modules in eval mode, encoder half only, row-standardised embeddings on the host)"}
+
+
 def cpu_baseline(steps=20, warm=3):
     """The torch-CPU oracle (kind 'port': a restatement of the reference's PyTorch path, pinned to it
     by tests/golden) on this host: wave step + time step (clip 1.0) at batch 512; median of `steps` timed
@@ -699,6 +726,11 @@ def main():
             tr = trainer_rate(device, data) if args.dtype == "f32" else None
             out["trainer_samples_per_s"] = tr["value"] if tr else None
             out["trainer_path"] = tr
+        if world == 1 and not args.no_trainer and args.model_type == "unimodal" and args.dtype == "f32":
+            try:
+                out["inference_path"] = embedding_rate(device, data)
+            except Exception as ex:             # never lose the line over a secondary figure
+                out["inference_path"] = {"error": repr(ex)[:200]}
         if not args.no_cpu_baseline and world == 1 and args.model_type == "unimodal":       # reported at N=1 only (the other ranks would sit in the barrier)
             out["cpu_baseline"] = cpu_baseline()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
