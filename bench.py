@@ -91,6 +91,7 @@ class Pair:
         self.streams = [torch.cuda.Stream(device=device) for _ in self.eng]
         self.stream_pair = {}
         self.stream_priority = True      # --no-stream-priority (A/B): both model streams at normal priority
+        self.run_ahead = 2               # --run-ahead: how many steps the host may queue ahead of the GPU (0 = unbounded)
         self.groups = None
         if world > 1 or os.environ.get("HIPPIE_FORCE_DIST"):
             self.use_world_group()
@@ -173,6 +174,24 @@ class Pair:
                 e.optimizer_step(use_graph)
         if self.lockstep:
             self.join()
+
+    def run(self, n, data, batch_idx, first, use_graph=True):
+        """n steps with the host at most `run_ahead` steps ahead of the slower model stream (0: unbounded — everything is queued within
+        a few milliseconds).  A bounded run-ahead keeps the two free-running models within a couple of steps of each other and the
+        hardware queues shallow: tools/micro/runahead_probe.py, 4.32-4.33 ms per pair-step at a depth of 2 against 4.35-4.38 unbounded
+        (4.40 against 4.43-4.45 in a 20-step run); a depth of 1 stalls the pipeline (4.52)."""
+        D = self.run_ahead
+        ring = [[None] * max(D, 1) for _ in self.streams]
+        for i in range(n):
+            if D and i >= D:
+                for k in range(len(self.streams)):
+                    ring[k][i % D].synchronize()
+            self.step(data, batch_idx(first + i), use_graph)
+            if D:
+                for k, s in enumerate(self.streams):
+                    ev = torch.cuda.Event()
+                    ev.record(s)
+                    ring[k][i % D] = ev
 
 
 def _nbuf(r, slots):
@@ -506,6 +525,7 @@ def main():
     ap.add_argument("--no-reuse-ws", action="store_true", help="every workspace tensor in memory of its own (A/B against the liveness-packed arena)")
     ap.add_argument("--only-model", type=int, choices=(0, 1), default=None, help="diagnostic: step only the wave (0) or the time (1) model; the line is then NOT the headline metric")
     ap.add_argument("--no-pick-streams", action="store_true", help="A/B: take the first two streams torch hands out instead of measuring which pair overlaps")
+    ap.add_argument("--run-ahead", type=int, default=2, help="steps the host may queue ahead of the GPU (0 = unbounded, the A/B)")
     ap.add_argument("--no-stream-priority", action="store_true", help="A/B: no high-priority stream for the longer chain (the time model)")
     ap.add_argument("--lockstep", action="store_true", help="join the two model streams after every step (default: only at the ends of the run)")
     ap.add_argument("--per-op", action="store_true", help="print the per-op time table to stderr")
@@ -570,6 +590,7 @@ def main():
                 staged=not args.no_staged, rank=rank)
     pair.only = args.only_model
     pair.stream_priority = not args.no_stream_priority
+    pair.run_ahead = max(0, args.run_ahead)
     steps_per_epoch = N_UNITS // (BATCH * world)
     g = torch.Generator(device="cpu").manual_seed(1234)
     perm = torch.randperm(N_UNITS, generator=g).to(device)
@@ -587,8 +608,7 @@ def main():
         pair.pick_streams()
     stream_pair = dict(pair.stream_pair)
     pair.fork()
-    for i in range(args.warmup):
-        pair.step(data, batch_idx(i), use_graph)
+    pair.run(args.warmup, data, batch_idx, 0, use_graph)
     pair.join()
     torch.cuda.synchronize()
     if world > 1:
@@ -596,8 +616,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pair.fork()
-    for i in range(args.steps):
-        pair.step(data, batch_idx(args.warmup + i), use_graph)
+    pair.run(args.steps, data, batch_idx, args.warmup, use_graph)
     pair.join()
     torch.cuda.synchronize()
     if world > 1:
@@ -614,8 +633,7 @@ def main():
         torch.cuda.synchronize()
         t = time.perf_counter()
         pair.fork()
-        for i in range(n):
-            pair.step(data, batch_idx(args.warmup + i), use_graph)
+        pair.run(n, data, batch_idx, args.warmup, use_graph)
         pair.join()
         torch.cuda.synchronize()
         return time.perf_counter() - t
@@ -698,7 +716,7 @@ def main():
                         "when --batch 8192 --z-dim 64 --wave-len 256 --time-len 32" if args.model_type == "multimodal" else
                         f"NON-DEFAULT shape: wave L={args.wave_len} + time L={args.time_len}, z_dim={args.z_dim}, batch {args.batch}, {N_UNITS} synthetic units"),
                        "model_type": args.model_type,
-                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "staged_in_graph": pair.staged, "stream_pair": stream_pair or None, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "lockstep": pair.lockstep,
+                       "global_batch": BATCH * world, "parallelism": f"dp{world}", "dist_backend": dist_backend, "hip_graph": use_graph, "staged_in_graph": pair.staged, "stream_pair": stream_pair or None, "run_ahead": pair.run_ahead, "fused_batchnorm": not args.no_fuse_bn, "workspace_mb": [round(e.plan.ws_bytes / 1e6, 1) for e in pair.eng], "workspace_unpacked_mb": [round((e.plan.ws_unpacked or e.plan.ws_bytes) / 1e6, 1) for e in pair.eng], "only_model": pair.only, "lockstep": pair.lockstep,
                        "final_loss_wave": loss[0], "final_loss_time": loss[-1],
                        # every HIPPIE_* variable of this run (measurement knobs act only under HIPPIE_DEBUG_KNOBS=1): {} = the product defaults
                        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("HIPPIE_")}},

@@ -23,11 +23,15 @@ class Trainer:
     def __init__(self, max_epochs=1, gradient_clip_val=None, default_root_dir="checkpoints", patience=30,
                  monitor="val_loss", logger_path=None, num_sanity_val_steps=2, device=None, enable_checkpointing=True,
                  sync_every_step=False, deterministic=False, strategy="auto", devices="auto", sync_batchnorm=False,
-                 precision="32", process_group=None, seed=0):
+                 precision="32", process_group=None, seed=0, run_ahead=2):
         """sync_every_step: True reproduces the reference's per-step `loss.item()` host sync (hippie/model.py:114) and
         checks labels on the host every step; False (default) keeps the step asynchronous — hipGraph replays, per-step
-        losses kept on the device and averaged at the epoch end, label range errors raised at the epoch end."""
+        losses kept on the device and averaged at the epoch end, label range errors raised at the epoch end.
+        run_ahead: in the asynchronous mode, how many steps the host may queue ahead of the GPU (0 = unbounded).  Two keeps the
+        hardware queue shallow and concurrent fits (fit_concurrently) within a couple of steps of each other — measured 1 % faster than
+        queueing a whole epoch at once (bench.py Pair.run, tools/micro/runahead_probe.py)."""
         self.sync_every_step = sync_every_step
+        self.run_ahead = max(0, int(run_ahead))
         self.deterministic = deterministic      # Lightning's flag: bit-reproducible runs (ordered weight-gradient sums, no fp32 atomics)
         self.max_epochs, self.gradient_clip_val = max_epochs, gradient_clip_val
         self.root, self.patience, self.monitor = default_root_dir, patience, monitor
@@ -162,12 +166,19 @@ class Trainer:
             module.train()
             t0 = time.perf_counter()
             n = 0
+            D = 0 if self.sync_every_step else self.run_ahead
+            ring = [None] * max(D, 1)
             for i, batch in enumerate(self._shard(train_dataloaders, epoch)):
+                if D and ring[i % D] is not None:
+                    ring[i % D].synchronize()              # step i - D is done: the host stays at most D steps ahead
                 batch = self._to_device(batch, dev)
                 module.optimizer.zero_grad()
                 loss = module.training_step(batch, i)
                 loss.backward()
                 module.optimizer.step()
+                if D:
+                    ring[i % D] = torch.cuda.Event()
+                    ring[i % D].record(torch.cuda.current_stream(dev))
                 self.global_step += 1
                 n += batch[0].shape[0]
             torch.cuda.current_stream(dev).synchronize()      # this fit's stream only: a concurrent fit (fit_concurrently) keeps running
