@@ -238,6 +238,36 @@ int hp_model_train_step_staged(HpModel* m, int use_graph, void* stream) {
 }
 int64_t hp_model_batches_tracked(const HpModel* m) { return m ? m->batches_tracked : -1; }
 
+int hp_model_set_optimizer(HpModel* m, float lr, float weight_decay, int reset_state) {
+  if (!m) return merr("hp_model_set_optimizer: null argument");
+  if (!(lr >= 0.f) || !(weight_decay >= 0.f)) return merr("hp_model_set_optimizer: lr and weight_decay must be >= 0");
+  int patched = 0;
+  for (auto& op : m->ops)
+    if (op.op == HP_OP_ADAMW) { op.f[0] = lr; op.f[4] = weight_decay; ++patched; }
+  if (!patched) return merr("hp_model_set_optimizer: the program holds no HP_OP_ADAMW record");
+  // the constants sit inside the executor's copy of the records and inside every captured graph: both are rebuilt
+  // (hp_program_create validates again; graphs are captured again on their next use)
+  HpProgram* fresh = nullptr;
+  int64_t fake_bytes[HP_NUM_SPACES];
+  void* bases[HP_NUM_SPACES];
+  for (int k = 0; k < HP_NUM_SPACES; ++k) { fake_bytes[k] = m->hdr.arena_bytes[k]; bases[k] = m->on_device ? m->arenas[k] : nullptr; }
+  if (hp_program_create(m->ops.data(), (int)m->ops.size(), bases, fake_bytes, &fresh)) return 1;
+  if (m->prog) hp_program_destroy(m->prog);
+  m->prog = fresh;
+  m->graphs.clear();
+  if (reset_state && m->on_device) {
+    // a new optim.AdamW(model.parameters()) as the reference's module constructor makes (hippie/model.py:93): zero moments, step 0
+    hipError_t e = hipMemset(m->arenas[HP_SPACE_M], 0, m->hdr.arena_bytes[HP_SPACE_M]);
+    if (e == hipSuccess) e = hipMemset(m->arenas[HP_SPACE_V], 0, m->hdr.arena_bytes[HP_SPACE_V]);
+    HpTensorInfo t;
+    if (e == hipSuccess && hp_model_find(m, "adam_step", &t) == 0)
+      e = hipMemset(static_cast<char*>(m->arenas[t.space]) + t.offset_bytes, 0, t.numel * dtype_size(t.dtype));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) return merr(std::string("hp_model_set_optimizer: ") + hipGetErrorString(e));
+  }
+  return 0;
+}
+
 int hp_model_write(HpModel* m, const char* name, const void* src, int64_t nbytes, int src_on_device, void* stream) {
   HpTensorInfo t;
   if (!m || !src) return merr("hp_model_write: null argument");

@@ -150,7 +150,7 @@ EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_crea
            "hp_run_op",
            "hp_model_load", "hp_model_destroy", "hp_model_config", "hp_model_tensor_count", "hp_model_tensor_info", "hp_model_find",
            "hp_model_arena", "hp_model_program", "hp_model_segment", "hp_model_run", "hp_model_forward", "hp_model_backward",
-           "hp_model_optimizer_step", "hp_model_train_step", "hp_model_train_step_staged", "hp_model_batches_tracked", "hp_model_write", "hp_model_read",
+           "hp_model_optimizer_step", "hp_model_train_step", "hp_model_train_step_staged", "hp_model_set_optimizer", "hp_model_batches_tracked", "hp_model_write", "hp_model_read",
            "hp_model_synchronize", "hp_stream_create", "hp_stream_destroy", "hp_pick_concurrent_streams")
 
 
@@ -201,6 +201,7 @@ def load_library():
     lib.hp_model_forward.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
     for fn in (lib.hp_model_backward, lib.hp_model_optimizer_step, lib.hp_model_train_step, lib.hp_model_train_step_staged):
         fn.argtypes = [vp, ctypes.c_int, vp]
+    lib.hp_model_set_optimizer.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_int]
     lib.hp_model_batches_tracked.argtypes = [vp]
     lib.hp_model_batches_tracked.restype = i64
     lib.hp_model_write.argtypes = [vp, cp, vp, i64, ctypes.c_int, vp]

@@ -393,6 +393,12 @@ int hp_model_train_step(HpModel* m, int use_graph, void* stream);
  * DataLoader(..., batch_size, shuffle=True) + training_step + backward + optimizer.step (scripts/train_model_with_multimodal.py:155-166,
  * 200-224).  Under data parallelism use hp_model_run("stage" | "fwd_train" | "bwd"), the host's all-reduce, then "opt". */
 int hp_model_train_step_staged(HpModel* m, int use_graph, void* stream);
+/* New optimiser constants for the next stage without re-exporting: every HP_OP_ADAMW record gets lr and weight_decay, the executor and
+ * the captured graphs are rebuilt.  reset_state != 0 also zeroes both moment arenas and the step counter — what the reference does when it
+ * wraps the pretrained network in a NEW train module for fine-tuning at a tenth of the learning rate
+ * (scripts/train_model_with_multimodal.py:263-268: the module constructor builds a fresh optim.AdamW, hippie/model.py:93).  Gradient
+ * clipping on / off changes the program's structure (HP_OP_GRADNORM) and needs a new export. */
+int hp_model_set_optimizer(HpModel* m, float lr, float weight_decay, int reset_state);
 /* BatchNorm num_batches_tracked (training forwards so far; the reference keeps it as an int64 buffer per layer). */
 int64_t hp_model_batches_tracked(const HpModel* m);
 /* Copy nbytes (must equal the tensor's size) into / out of a named tensor, stream-ordered; a host destination is

@@ -266,3 +266,64 @@ def test_c_level_staged_steps_match_the_python_engine(tmp_path, use_graph):
     assert lib.hp_model_read(m, b"x", xb.ctypes.data_as(ctypes.c_void_p), xb.nbytes, 0, None) == 0
     np.testing.assert_array_equal(xb, x.numpy()[perm.numpy()[(steps - 1) * B: steps * B]])
     lib.hp_model_destroy(m)
+
+
+def test_set_optimizer_host_only(tmp_path):
+    plan, om, path, pv, bv = _export(tmp_path, B=4)
+    lib = P.load_library()
+    m = ctypes.c_void_p()
+    assert lib.hp_model_load(path.encode(), export.NO_DEVICE, ctypes.byref(m)) == 0
+    assert lib.hp_model_set_optimizer(m, 1e-4, 0.01, 1) == 0, lib.hp_last_error()
+    assert lib.hp_model_set_optimizer(m, -1.0, 0.01, 0) != 0 and b"lr" in lib.hp_last_error()
+    lib.hp_model_destroy(m)
+
+
+@pytest.mark.gpu
+def test_c_level_fine_tune_stage_new_lr_fresh_adamw(tmp_path):
+    """hp_model_set_optimizer(lr / 10, wd, reset) = the reference re-wrapping the pretrained network in a new train module
+    (scripts/...:263-268): parameters and BatchNorm buffers kept, AdamW moments and step count zeroed, new learning rate — against the
+    Python surface doing exactly that."""
+    from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
+    z, L, B, lr = 10, 50, 16, 1e-5
+    plan, om, path, pv, bv = _export(tmp_path, "unimodal", z, L, B, salt=6, clip=0.0, lr=lr)
+    x, src, cls, eps = O.synth_inputs(B, L, z, salt=6)
+    # Python surface: two steps, new module at lr / 10 (fresh AdamW), two more steps
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    net.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    net.set_eps_source(lambda eng: eps.cuda())
+    want = []
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=lr, weight_decay=0.01)
+    for stage in range(2):
+        for i in range(2):
+            mod.optimizer.zero_grad()
+            loss = mod.training_step((x.cuda().view(B, 1, L), src.cuda()), i)
+            loss.backward()
+            mod.optimizer.step()
+            want.append(float(loss.item()))
+        mod = hippieUnimodalEmbeddingModelCVAE(mod.model, learning_rate=lr / 10, weight_decay=0.01)
+    w_want = net.state_dict()["encoder.conv1.weight"].double().sum().item()
+
+    lib = P.load_library()
+    m = ctypes.c_void_p()
+    assert lib.hp_model_load(path.encode(), 0, ctypes.byref(m)) == 0, lib.hp_last_error()
+    for name, arr in (("x", x.numpy().astype(np.float32)), ("src", src.numpy().astype(np.int64)), ("eps", eps.numpy().astype(np.float32))):
+        a = np.ascontiguousarray(arr)
+        assert lib.hp_model_write(m, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.nbytes, 0, None) == 0, lib.hp_last_error()
+        lib.hp_model_synchronize(m, None)
+    got = []
+    for stage in range(2):
+        for i in range(2):
+            assert lib.hp_model_train_step(m, 1, None) == 0, lib.hp_last_error()
+            sc = (ctypes.c_float * 4)()
+            assert lib.hp_model_read(m, b"scalars", sc, 16, 0, None) == 0
+            got.append(sc[0])
+        assert lib.hp_model_set_optimizer(m, lr / 10, 0.01, 1) == 0, lib.hp_last_error()
+        step = (ctypes.c_int64 * 1)()
+        assert lib.hp_model_read(m, b"adam_step", step, 8, 0, None) == 0 and step[0] == 0
+    np.testing.assert_allclose(got, want, rtol=2e-6)
+    t = TensorInfo()
+    assert lib.hp_model_find(m, b"encoder.conv1.weight", ctypes.byref(t)) == 0
+    w = np.zeros(t.numel, dtype=np.float32)
+    assert lib.hp_model_read(m, b"encoder.conv1.weight", w.ctypes.data_as(ctypes.c_void_p), w.nbytes, 0, None) == 0
+    np.testing.assert_allclose(w.astype(np.float64).sum(), w_want, rtol=1e-6)
+    lib.hp_model_destroy(m)
