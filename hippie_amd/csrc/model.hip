@@ -42,7 +42,7 @@ struct HpModel {
   std::vector<HpOp> ops;
   std::vector<HpmSegment> segments;
   std::vector<HpTensorInfo> tensors[3];          // params, buffers, io slots
-  std::vector<float> init_param, init_buf;
+  std::vector<float> init_param, init_buf, init_m, init_v;
   void* arenas[HP_NUM_SPACES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   HpProgram* prog = nullptr;
   std::map<std::string, int> graphs;             // segment name -> captured segment id
@@ -107,6 +107,13 @@ int hp_model_load(const char* path, int flags, HpModel** out) {
     m->init_buf.resize(h.arena_bytes[HP_SPACE_BUF] / 4);
     if (!read_exact(f, m->init_buf.data(), h.arena_bytes[HP_SPACE_BUF])) return bail("short file (buffer values)");
   }
+  if (h.has_init & 4) {      // AdamW moments (hp_model_save): exp_avg, exp_avg_sq in the parameter arena's layout
+    m->init_m.resize(h.arena_bytes[HP_SPACE_M] / 4);
+    m->init_v.resize(h.arena_bytes[HP_SPACE_V] / 4);
+    if (!read_exact(f, m->init_m.data(), h.arena_bytes[HP_SPACE_M]) || !read_exact(f, m->init_v.data(), h.arena_bytes[HP_SPACE_V]))
+      return bail("short file (optimiser moments)");
+  }
+  m->batches_tracked = h.config[13];
   fclose(f);
   f = nullptr;
   for (auto& s : m->segments) {
@@ -130,9 +137,38 @@ int hp_model_load(const char* path, int flags, HpModel** out) {
   hipError_t e = hipSuccess;
   if (!m->init_param.empty()) e = hipMemcpy(m->arenas[HP_SPACE_PARAM], m->init_param.data(), h.arena_bytes[HP_SPACE_PARAM], hipMemcpyHostToDevice);
   if (e == hipSuccess && !m->init_buf.empty()) e = hipMemcpy(m->arenas[HP_SPACE_BUF], m->init_buf.data(), h.arena_bytes[HP_SPACE_BUF], hipMemcpyHostToDevice);
+  if (e == hipSuccess && !m->init_m.empty()) e = hipMemcpy(m->arenas[HP_SPACE_M], m->init_m.data(), h.arena_bytes[HP_SPACE_M], hipMemcpyHostToDevice);
+  if (e == hipSuccess && !m->init_v.empty()) e = hipMemcpy(m->arenas[HP_SPACE_V], m->init_v.data(), h.arena_bytes[HP_SPACE_V], hipMemcpyHostToDevice);
   if (e != hipSuccess) { hp_model_destroy(m); return merr(std::string("hp_model_load: upload: ") + hipGetErrorString(e)); }
   if (hp_program_create(m->ops.data(), h.n_ops, m->arenas, h.arena_bytes, &m->prog)) { hp_model_destroy(m); return 1; }
   *out = m;
+  return 0;
+}
+
+int hp_model_save(HpModel* m, const char* path, int with_optimizer) {
+  if (!m || !path) return merr("hp_model_save: null argument");
+  if (!m->on_device) return merr("hp_model_save: the model was loaded with HP_MODEL_NO_DEVICE");
+  hipError_t e = hipDeviceSynchronize();
+  const int which[4] = {HP_SPACE_PARAM, HP_SPACE_BUF, HP_SPACE_M, HP_SPACE_V};
+  std::vector<char> host[4];
+  for (int k = 0; k < (with_optimizer ? 4 : 2) && e == hipSuccess; ++k) {
+    host[k].resize(m->hdr.arena_bytes[which[k]]);
+    e = hipMemcpy(host[k].data(), m->arenas[which[k]], host[k].size(), hipMemcpyDeviceToHost);
+  }
+  if (e != hipSuccess) return merr(std::string("hp_model_save: ") + hipGetErrorString(e));
+  HpmHeader h = m->hdr;
+  h.has_init = 3 | (with_optimizer ? 4 : 0);
+  h.config[13] = (int32_t)m->batches_tracked;
+  FILE* f = fopen(path, "wb");
+  if (!f) return merr(std::string("hp_model_save: cannot open ") + path);
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+  ok = ok && fwrite(m->ops.data(), sizeof(HpOp), m->ops.size(), f) == m->ops.size();
+  ok = ok && (m->segments.empty() || fwrite(m->segments.data(), sizeof(HpmSegment), m->segments.size(), f) == m->segments.size());
+  for (int w = 0; w < 3 && ok; ++w)
+    ok = m->tensors[w].empty() || fwrite(m->tensors[w].data(), sizeof(HpTensorInfo), m->tensors[w].size(), f) == m->tensors[w].size();
+  for (int k = 0; k < (with_optimizer ? 4 : 2) && ok; ++k) ok = fwrite(host[k].data(), 1, host[k].size(), f) == host[k].size();
+  ok = (fclose(f) == 0) && ok;
+  if (!ok) return merr(std::string("hp_model_save: write failed: ") + path);
   return 0;
 }
 

@@ -131,10 +131,65 @@ def read_model(path):
     if has_init & 2:
         bv = np.frombuffer(raw, dtype=np.float32, count=sizes[P.BUF] // 4, offset=off)
         off += sizes[P.BUF]
+    mv = vv = None
+    if has_init & 4:           # AdamW moments (hp_model_save(..., with_optimizer=1))
+        mv = np.frombuffer(raw, dtype=np.float32, count=sizes[P.ADAM_M] // 4, offset=off)
+        off += sizes[P.ADAM_M]
+        vv = np.frombuffer(raw, dtype=np.float32, count=sizes[P.ADAM_V] // 4, offset=off)
+        off += sizes[P.ADAM_V]
     assert off == len(raw), (off, len(raw))
     return dict(version=version, abi=abi, arena_bytes=sizes, config=config, ops=ops,
                 segments={s["name"].decode(): (int(s["first"]), int(s["count"])) for s in segs},
-                params=tabs[0], bufs=tabs[1], io=tabs[2], param_values=pv, buf_values=bv)
+                params=tabs[0], bufs=tabs[1], io=tabs[2], param_values=pv, buf_values=bv, m_values=mv, v_values=vv)
+
+
+def _param_tensor(t, arena):
+    """one parameter out of an arena image, in the reference's layout (conv weights are stored tap-major)"""
+    import torch
+    shape = [int(v) for v in t["shape"][: int(t["ndim"])]]
+    flat = np.array(arena[int(t["offset_bytes"]) // 4: int(t["offset_bytes"]) // 4 + int(t["numel"])])
+    if int(t["layout"]) == 1:
+        co, ci, k = shape
+        flat = flat.reshape(k, co, ci).transpose(1, 2, 0)
+    return torch.from_numpy(np.ascontiguousarray(flat.reshape(shape)))
+
+
+def checkpoint_from_file(path):
+    """A model file written by hp_model_save (a C host's checkpoint) as the reference's checkpoint dict: {"state_dict": parameters,
+    BatchNorm running statistics and num_batches_tracked under "model.<reference key>" (what pl.ModelCheckpoint stores for the train
+    module, hippie/model.py:76-93), "optimizer_states": [torch.optim.AdamW.state_dict() layout]} — loadable by
+    hippieUnimodalEmbeddingModelCVAE.load_state_dict here and in the reference."""
+    import torch
+    from collections import OrderedDict
+    d = read_model(path)
+    if d["param_values"] is None or d["buf_values"] is None:
+        raise ValueError(f"{path} holds no parameter / buffer values (export --seed, or hp_model_save)")
+    sd = OrderedDict()
+    for t in d["params"]:
+        sd["model." + t["name"].decode()] = _param_tensor(t, d["param_values"])
+    tracked = int(d["config"][13])
+    for t in d["bufs"]:
+        k = t["name"].decode()
+        o = int(t["offset_bytes"]) // 4
+        sd["model." + k] = torch.from_numpy(np.array(d["buf_values"][o: o + int(t["numel"])]))
+        if k.endswith("running_var"):
+            sd["model." + k[: -len("running_var")] + "num_batches_tracked"] = torch.tensor(tracked, dtype=torch.int64)
+    out = {"state_dict": sd}
+    if d["m_values"] is not None:
+        step = 0
+        for t in d["io"]:
+            if t["name"].decode() == "adam_step":
+                o = int(t["offset_bytes"])
+                step = int(np.frombuffer(d["buf_values"].tobytes()[o: o + 8], dtype=np.int64)[0])
+        adam = next(r for r in d["ops"] if int(r["op"]) == P.ADAMW)
+        state = OrderedDict()
+        for i, t in enumerate(d["params"]):
+            state[i] = dict(step=torch.tensor(float(step)), exp_avg=_param_tensor(t, d["m_values"]), exp_avg_sq=_param_tensor(t, d["v_values"]))
+        group = dict(lr=float(adam["f"][0]), betas=(float(adam["f"][1]), float(adam["f"][2])), eps=float(adam["f"][3]), weight_decay=float(adam["f"][4]),
+                     amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                     params=list(range(len(state))))
+        out["optimizer_states"] = [dict(state=state, param_groups=[group], param_names=[t["name"].decode() for t in d["params"]])]
+    return out
 
 
 def main(argv=None):
@@ -156,8 +211,18 @@ def main(argv=None):
     ap.add_argument("--dp-world", type=int, default=1)
     ap.add_argument("--dp-rank", type=int, default=0)
     ap.add_argument("--seed", type=int, default=None, help="also store the reference constructor's random initialisation under this torch seed")
-    ap.add_argument("-o", "--output", required=True)
+    ap.add_argument("--to-ckpt", nargs=2, metavar=("MODEL.hpm", "OUT.ckpt"), default=None,
+                    help="convert a file written by hp_model_save into a reference-format .ckpt (torch.save of checkpoint_from_file) and exit")
+    ap.add_argument("-o", "--output", default=None)
     a = ap.parse_args(argv)
+    if a.to_ckpt:
+        import torch
+        ck = checkpoint_from_file(a.to_ckpt[0])
+        torch.save(ck, a.to_ckpt[1])
+        print(f"{a.to_ckpt[1]}: {len(ck['state_dict'])} state_dict entries" + (", AdamW state" if "optimizer_states" in ck else ""))
+        return
+    if not a.output:
+        ap.error("-o / --output is required")
     cfg = planner.ModelCfg(a.kind, a.z_dim, a.output_size, a.output_size2, 5, a.num_sources, a.num_classes)
     plan = planner.lower(cfg, a.batch, planner.TrainCfg(lr=a.lr, weight_decay=a.weight_decay, beta=a.beta, clip=a.clip, resident_units=a.resident_units,
                                                         dp_world=a.dp_world, dp_rank=a.dp_rank), with_class=a.with_class)

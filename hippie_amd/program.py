@@ -145,7 +145,7 @@ def debug_knob(name, default=None):
 
 LIB_PATH = debug_knob("HIPPIE_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhippie_hip.so")
 
-EXPORTS = ("hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",
+EXPORTS = ("hp_model_save", "hp_abi_version", "hp_last_error", "hp_device_info", "hp_program_create", "hp_program_destroy",
            "hp_program_validate", "hp_program_run", "hp_program_capture", "hp_program_replay", "hp_program_profile",
            "hp_run_op",
            "hp_model_load", "hp_model_destroy", "hp_model_config", "hp_model_tensor_count", "hp_model_tensor_info", "hp_model_find",
@@ -188,6 +188,7 @@ def load_library():
     cp, i64 = ctypes.c_char_p, ctypes.c_int64
     lib.hp_model_load.argtypes = [cp, ctypes.c_int, ctypes.POINTER(vp)]
     lib.hp_model_destroy.argtypes = [vp]
+    lib.hp_model_save.argtypes = [vp, cp, ctypes.c_int]
     lib.hp_model_config.argtypes = [vp, ctypes.POINTER(ctypes.c_int32)]
     lib.hp_model_tensor_count.argtypes = [vp, ctypes.c_int]
     lib.hp_model_tensor_info.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]

@@ -367,6 +367,12 @@ typedef struct HpTensorInfo {
 
 int hp_model_load(const char* path, int flags, HpModel** out);
 int hp_model_destroy(HpModel* m);
+/* Checkpoint from a host without Python: writes the model as an .hpm file again, with the CURRENT parameters, BatchNorm buffers (incl.
+ * the AdamW step counter and, for staged models, the batch cursor, which live in the buffer arena), num_batches_tracked (config word 13)
+ * and — with_optimizer != 0 — both AdamW moment arenas, so that hp_model_load resumes exactly where training stopped (the reference's
+ * .ckpt = {"state_dict", "optimizer_states"}, written by pl.ModelCheckpoint).  `python -m hippie_amd.export --to-ckpt file.hpm out.ckpt`
+ * converts such a file into a reference-format .ckpt (reference state_dict keys and layouts; torch.optim.AdamW state). */
+int hp_model_save(HpModel* m, const char* path, int with_optimizer);
 /* out[0..9] = kind (0 unimodal, 1 multimodal), z_dim, output_size, output_size2, class_hidden_dim, num_sources, num_classes,
  * batch, with_class, number of floats AdamW updates. */
 int hp_model_config(const HpModel* m, int32_t out[16]);

@@ -327,3 +327,72 @@ def test_c_level_fine_tune_stage_new_lr_fresh_adamw(tmp_path):
     assert lib.hp_model_read(m, b"encoder.conv1.weight", w.ctypes.data_as(ctypes.c_void_p), w.nbytes, 0, None) == 0
     np.testing.assert_allclose(w.astype(np.float64).sum(), w_want, rtol=1e-6)
     lib.hp_model_destroy(m)
+
+
+@pytest.mark.gpu
+def test_c_level_checkpoint_save_resume_and_ckpt_conversion(tmp_path):
+    """hp_model_save after two steps -> (a) hp_model_load + two more steps == four uninterrupted steps; (b) export.checkpoint_from_file is
+    the reference's checkpoint dict: it loads into the Python train module (state_dict keys of tests/golden/manifest.json, optimiser
+    state) which then takes the same next step."""
+    import json
+    from hippie_amd.model import hippieUnimodalCVAE, hippieUnimodalEmbeddingModelCVAE
+    z, L, B, lr = 10, 50, 16, 1e-5
+    plan, om, path, pv, bv = _export(tmp_path, "unimodal", z, L, B, salt=8, clip=0.0, lr=lr)
+    x, src, cls, eps = O.synth_inputs(B, L, z, salt=8)
+    lib = P.load_library()
+
+    def load(p):
+        m = ctypes.c_void_p()
+        assert lib.hp_model_load(p.encode(), 0, ctypes.byref(m)) == 0, lib.hp_last_error()
+        for name, arr in (("x", x.numpy().astype(np.float32)), ("src", src.numpy().astype(np.int64)), ("eps", eps.numpy().astype(np.float32))):
+            a = np.ascontiguousarray(arr)
+            assert lib.hp_model_write(m, name.encode(), a.ctypes.data_as(ctypes.c_void_p), a.nbytes, 0, None) == 0
+            lib.hp_model_synchronize(m, None)
+        return m
+
+    def steps(m, n):
+        out = []
+        for _ in range(n):
+            assert lib.hp_model_train_step(m, 1, None) == 0, lib.hp_last_error()
+            sc = (ctypes.c_float * 4)()
+            assert lib.hp_model_read(m, b"scalars", sc, 16, 0, None) == 0
+            out.append(sc[0])
+        return out
+
+    ref = load(path)
+    want = steps(ref, 4)
+    lib.hp_model_destroy(ref)
+    a = load(path)
+    got = steps(a, 2)
+    saved = str(tmp_path / "ckpt.hpm")
+    assert lib.hp_model_save(a, saved.encode(), 1) == 0, lib.hp_last_error()
+    lib.hp_model_destroy(a)
+    b = load(saved)
+    assert lib.hp_model_batches_tracked(b) == 2
+    got += steps(b, 2)
+    lib.hp_model_destroy(b)
+    np.testing.assert_allclose(got, want, rtol=2e-6)          # resumed == uninterrupted (moments, step count, running statistics all restored)
+
+    ck = export.checkpoint_from_file(saved)
+    manifest = json.load(open(os.path.join(ROOT, "tests", "golden", "manifest.json")))
+    keys = {"model." + k: tuple(shape) for k, shape, _ in manifest["unimodal_z10_o50"]}      # the reference module's own state_dict() listing
+    assert set(ck["state_dict"]) == set(keys), set(ck["state_dict"]) ^ set(keys)
+    for k, shp in keys.items():
+        assert tuple(ck["state_dict"][k].shape) == shp, k
+    assert int(ck["state_dict"]["model.encoder.bn1.num_batches_tracked"]) == 2
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    net.set_eps_source(lambda eng: eps.cuda())
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=lr, weight_decay=0.01)
+    mod.load_state_dict(ck["state_dict"])
+    mod.optimizer.zero_grad()
+    loss = mod.training_step((x.cuda().view(B, 1, L), src.cuda()), 0)         # lowers the engine the optimiser state is loaded into
+    mod.load_state_dict(ck["state_dict"])
+    mod.optimizer.load_state_dict(ck["optimizer_states"][0])
+    nxt = []
+    for i in range(2):
+        mod.optimizer.zero_grad()
+        loss = mod.training_step((x.cuda().view(B, 1, L), src.cuda()), i)
+        loss.backward()
+        mod.optimizer.step()
+        nxt.append(float(loss.item()))
+    np.testing.assert_allclose(nxt, want[2:], rtol=2e-6)
