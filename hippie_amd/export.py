@@ -211,6 +211,9 @@ def main(argv=None):
     ap.add_argument("--dp-world", type=int, default=1)
     ap.add_argument("--dp-rank", type=int, default=0)
     ap.add_argument("--seed", type=int, default=None, help="also store the reference constructor's random initialisation under this torch seed")
+    ap.add_argument("--from-ckpt", default=None, metavar="FILE.ckpt",
+                    help="initial parameters / BatchNorm buffers from a reference-format checkpoint (torch.save'd {'state_dict': {'model.<key>': tensor}}, "
+                         "as pl.ModelCheckpoint writes for the reference's train modules): weights trained by the reference, served from a C host")
     ap.add_argument("--to-ckpt", nargs=2, metavar=("MODEL.hpm", "OUT.ckpt"), default=None,
                     help="convert a file written by hp_model_save into a reference-format .ckpt (torch.save of checkpoint_from_file) and exit")
     ap.add_argument("-o", "--output", default=None)
@@ -227,7 +230,16 @@ def main(argv=None):
     plan = planner.lower(cfg, a.batch, planner.TrainCfg(lr=a.lr, weight_decay=a.weight_decay, beta=a.beta, clip=a.clip, resident_units=a.resident_units,
                                                         dp_world=a.dp_world, dp_rank=a.dp_rank), with_class=a.with_class)
     pv = bv = None
-    if a.seed is not None:
+    if a.from_ckpt:
+        import torch
+        ck = torch.load(a.from_ckpt, map_location="cpu", weights_only=False)
+        sd = ck.get("state_dict", ck)
+        sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
+        missing = [k for k in plan.params if k not in sd]
+        if missing:
+            raise SystemExit(f"{a.from_ckpt}: no entry for {missing[:3]}{' ...' if len(missing) > 3 else ''}")
+        pv, bv = arena_values(plan, sd)
+    elif a.seed is not None:
         import torch
         from .model import reference_init_state
         sd = reference_init_state(cfg, torch.Generator().manual_seed(a.seed))

@@ -396,3 +396,18 @@ def test_c_level_checkpoint_save_resume_and_ckpt_conversion(tmp_path):
         mod.optimizer.step()
         nxt.append(float(loss.item()))
     np.testing.assert_allclose(nxt, want[2:], rtol=2e-6)
+
+
+def test_checkpoint_conversion_round_trip_on_the_host(tmp_path):
+    """model file with values -> reference-format .ckpt (--to-ckpt) -> model file again (--from-ckpt): the same arena images."""
+    plan, om, path, pv, bv = _export(tmp_path, "unimodal", 10, 50, 4, salt=2)
+    ck = str(tmp_path / "m.ckpt")
+    export.main(["--to-ckpt", path, ck])
+    sd = torch.load(ck, weights_only=False)["state_dict"]
+    assert sd["model.encoder.conv1.weight"].shape == (64, 1, 3) and sd["model.encoder.layer1.0.conv1.weight"].shape == (64, 64, 3)
+    np.testing.assert_array_equal(sd["model.encoder.layer1.0.conv1.weight"].numpy(), om.state["encoder.layer1.0.conv1.weight"].detach().numpy())
+    back = str(tmp_path / "back.hpm")
+    export.main(["--kind", "unimodal", "--z-dim", "10", "--output-size", "50", "--batch", "4", "--from-ckpt", ck, "-o", back])
+    d = export.read_model(back)
+    np.testing.assert_array_equal(d["param_values"], np.asarray(pv, dtype=np.float32).reshape(-1))
+    np.testing.assert_array_equal(d["buf_values"][: len(bv)], np.asarray(bv, dtype=np.float32).reshape(-1))
