@@ -68,12 +68,27 @@ int dtype_size(int dt) { return dt == 0 ? 4 : 8; }
 
 extern "C" {
 
+namespace {
+int model_load(const char* path, int flags, HpModel** out);
+int model_save(HpModel* m, const char* path, int with_optimizer);
+}
+// (std::bad_alloc from a vector sized by a damaged header must not cross the C boundary: the library never aborts)
 int hp_model_load(const char* path, int flags, HpModel** out) {
+  try { return model_load(path, flags, out); } catch (const std::exception& ex) { return merr(std::string("hp_model_load: ") + ex.what()); }
+}
+int hp_model_save(HpModel* m, const char* path, int with_optimizer) {
+  try { return model_save(m, path, with_optimizer); } catch (const std::exception& ex) { return merr(std::string("hp_model_save: ") + ex.what()); }
+}
+}  // extern "C"
+namespace {
+int model_load(const char* path, int flags, HpModel** out) {
   if (!path || !out) return merr("hp_model_load: null argument");
   FILE* f = fopen(path, "rb");
   if (!f) return merr(std::string("hp_model_load: cannot open ") + path);
   HpModel* m = new HpModel();
-  auto bail = [&](const std::string& why) { fclose(f); hp_model_destroy(m); return merr("hp_model_load: " + why); };
+  // whatever way this function is left (an error return, an exception from a vector sized by a damaged header): file closed, model freed
+  struct Guard { FILE*& f; HpModel*& m; ~Guard() { if (f) fclose(f); if (m) hp_model_destroy(m); } } guard{f, m};
+  auto bail = [&](const std::string& why) { return merr("hp_model_load: " + why); };
   if (!read_exact(f, &m->hdr, sizeof m->hdr)) return bail("short file (header)");
   const HpmHeader& h = m->hdr;
   if (memcmp(h.magic, "HPMODEL", 8) != 0) return bail("not an .hpm file (bad magic)");
@@ -83,7 +98,7 @@ int hp_model_load(const char* path, int flags, HpModel** out) {
       h.n_bufs < 0 || h.n_bufs > (1 << 20) || h.n_io < 0 || h.n_io > 4096)
     return bail("implausible table sizes");
   for (int k = 0; k < HP_NUM_SPACES; ++k)
-    if (h.arena_bytes[k] <= 0 || (h.arena_bytes[k] & 3)) return bail("bad arena size");
+    if (h.arena_bytes[k] <= 0 || (h.arena_bytes[k] & 3) || h.arena_bytes[k] > (int64_t(1) << 40)) return bail("bad arena size");
   m->ops.resize(h.n_ops);
   m->segments.resize(h.n_segments);
   if (!read_exact(f, m->ops.data(), sizeof(HpOp) * h.n_ops)) return bail("short file (ops)");
@@ -95,7 +110,7 @@ int hp_model_load(const char* path, int flags, HpModel** out) {
     for (auto& t : m->tensors[w]) {
       t.name[sizeof t.name - 1] = 0;
       if (t.space < 0 || t.space >= HP_NUM_SPACES || t.offset_bytes < 0 || t.numel < 0 || t.dtype < 0 || t.dtype > 2 ||
-          t.offset_bytes + t.numel * dtype_size(t.dtype) > h.arena_bytes[t.space])
+          t.offset_bytes > h.arena_bytes[t.space] || t.numel > (h.arena_bytes[t.space] - t.offset_bytes) / dtype_size(t.dtype))
         return bail(std::string("tensor '") + t.name + "' lies outside its arena");
     }
   }
@@ -118,20 +133,21 @@ int hp_model_load(const char* path, int flags, HpModel** out) {
   f = nullptr;
   for (auto& s : m->segments) {
     s.name[sizeof s.name - 1] = 0;
-    if (s.first < 0 || s.count < 0 || s.first + s.count > h.n_ops) { hp_model_destroy(m); return merr("hp_model_load: segment out of range"); }
+    if (s.first < 0 || s.count < 0 || (int64_t)s.first + s.count > h.n_ops) { return merr("hp_model_load: segment out of range"); }
   }
   if (flags & HP_MODEL_NO_DEVICE) {
     // host-only: validate the records against the declared arena sizes (no allocation, no GPU)
     void* fake[HP_NUM_SPACES];
     for (int k = 0; k < HP_NUM_SPACES; ++k) fake[k] = nullptr;
-    if (hp_program_create(m->ops.data(), h.n_ops, fake, h.arena_bytes, &m->prog)) { hp_model_destroy(m); return 1; }
+    if (hp_program_create(m->ops.data(), h.n_ops, fake, h.arena_bytes, &m->prog)) { return 1; }
     *out = m;
+    m = nullptr;
     return 0;
   }
   for (int k = 0; k < HP_NUM_SPACES; ++k) {
     hipError_t e = hipMalloc(&m->arenas[k], h.arena_bytes[k]);
     if (e == hipSuccess) e = hipMemset(m->arenas[k], 0, h.arena_bytes[k]);
-    if (e != hipSuccess) { hp_model_destroy(m); return merr(std::string("hp_model_load: arena allocation: ") + hipGetErrorString(e)); }
+    if (e != hipSuccess) { return merr(std::string("hp_model_load: arena allocation: ") + hipGetErrorString(e)); }
   }
   m->on_device = true;
   hipError_t e = hipSuccess;
@@ -139,13 +155,14 @@ int hp_model_load(const char* path, int flags, HpModel** out) {
   if (e == hipSuccess && !m->init_buf.empty()) e = hipMemcpy(m->arenas[HP_SPACE_BUF], m->init_buf.data(), h.arena_bytes[HP_SPACE_BUF], hipMemcpyHostToDevice);
   if (e == hipSuccess && !m->init_m.empty()) e = hipMemcpy(m->arenas[HP_SPACE_M], m->init_m.data(), h.arena_bytes[HP_SPACE_M], hipMemcpyHostToDevice);
   if (e == hipSuccess && !m->init_v.empty()) e = hipMemcpy(m->arenas[HP_SPACE_V], m->init_v.data(), h.arena_bytes[HP_SPACE_V], hipMemcpyHostToDevice);
-  if (e != hipSuccess) { hp_model_destroy(m); return merr(std::string("hp_model_load: upload: ") + hipGetErrorString(e)); }
-  if (hp_program_create(m->ops.data(), h.n_ops, m->arenas, h.arena_bytes, &m->prog)) { hp_model_destroy(m); return 1; }
+  if (e != hipSuccess) { return merr(std::string("hp_model_load: upload: ") + hipGetErrorString(e)); }
+  if (hp_program_create(m->ops.data(), h.n_ops, m->arenas, h.arena_bytes, &m->prog)) { return 1; }
   *out = m;
+  m = nullptr;
   return 0;
 }
 
-int hp_model_save(HpModel* m, const char* path, int with_optimizer) {
+int model_save(HpModel* m, const char* path, int with_optimizer) {
   if (!m || !path) return merr("hp_model_save: null argument");
   if (!m->on_device) return merr("hp_model_save: the model was loaded with HP_MODEL_NO_DEVICE");
   hipError_t e = hipDeviceSynchronize();
@@ -171,6 +188,8 @@ int hp_model_save(HpModel* m, const char* path, int with_optimizer) {
   if (!ok) return merr(std::string("hp_model_save: write failed: ") + path);
   return 0;
 }
+}  // namespace
+extern "C" {
 
 int hp_model_destroy(HpModel* m) {
   if (!m) return 0;

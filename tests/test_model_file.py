@@ -92,6 +92,14 @@ def test_damaged_files_are_refused(tmp_path):
     off = 152
     assert load(raw[:off] + ops.tobytes() + raw[off + ops.nbytes:]) != 0 and b"out of range" in lib.hp_last_error()
     assert lib.hp_model_load(str(tmp_path / "missing.hpm").encode(), 0, ctypes.byref(m)) != 0
+    # header fields a damaged file could carry: an absurd arena size, a segment range that overflows int32
+    huge = bytearray(raw)
+    huge[40:48] = (1 << 50).to_bytes(8, "little")
+    assert load(bytes(huge)) != 0 and b"arena size" in lib.hp_last_error()
+    seg_off = 152 + d["ops"].nbytes
+    wild = bytearray(raw)
+    wild[seg_off + 32: seg_off + 40] = (2**31 - 1).to_bytes(4, "little") * 2
+    assert load(bytes(wild)) != 0 and b"segment out of range" in lib.hp_last_error()
 
 
 @pytest.mark.gpu
