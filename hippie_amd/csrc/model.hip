@@ -296,6 +296,10 @@ int64_t hp_model_batches_tracked(const HpModel* m) { return m ? m->batches_track
 int hp_model_set_optimizer(HpModel* m, float lr, float weight_decay, int reset_state) {
   if (!m) return merr("hp_model_set_optimizer: null argument");
   if (!(lr >= 0.f) || !(weight_decay >= 0.f)) return merr("hp_model_set_optimizer: lr and weight_decay must be >= 0");
+  if (m->on_device) {        // the executor and its captured graphs are about to be replaced: nothing of them may still be running
+    const hipError_t e0 = hipDeviceSynchronize();
+    if (e0 != hipSuccess) return merr(std::string("hp_model_set_optimizer: ") + hipGetErrorString(e0));
+  }
   int patched = 0;
   for (auto& op : m->ops)
     if (op.op == HP_OP_ADAMW) { op.f[0] = lr; op.f[4] = weight_decay; ++patched; }
