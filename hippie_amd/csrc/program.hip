@@ -371,6 +371,7 @@ int hp_program_create(const HpOp* ops, int n_ops, void* const bases[HP_NUM_SPACE
 
 int hp_program_destroy(HpProgram* p) {
   if (!p) return 0;
+  (void)hipDeviceSynchronize();      // replays of these graphs (and kernels reading the group tables) may still be in flight on the caller's streams
   for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
   for (auto g : p->graphs) if (g) hipGraphDestroy(g);
   free_groups(p->groups);
