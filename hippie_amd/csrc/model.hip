@@ -376,6 +376,32 @@ int hp_stream_destroy(void* stream) {
   return 0;
 }
 
+// events: what a host needs to bound how far it queues ahead of the GPU (bench.py Pair.run: two steps ahead is 1 % faster than everything at once)
+int hp_event_create(void** out) {
+  if (!out) return merr("hp_event_create: null argument");
+  hipEvent_t e = nullptr;
+  const hipError_t rc = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+  if (rc != hipSuccess) return merr(std::string("hp_event_create: ") + hipGetErrorString(rc));
+  *out = e;
+  return 0;
+}
+int hp_event_record(void* event, void* stream) {
+  const hipError_t rc = hipEventRecord((hipEvent_t)event, (hipStream_t)stream);
+  if (rc != hipSuccess) return merr(std::string("hp_event_record: ") + hipGetErrorString(rc));
+  return 0;
+}
+int hp_event_synchronize(void* event) {
+  const hipError_t rc = hipEventSynchronize((hipEvent_t)event);
+  if (rc != hipSuccess) return merr(std::string("hp_event_synchronize: ") + hipGetErrorString(rc));
+  return 0;
+}
+int hp_event_destroy(void* event) {
+  if (!event) return 0;
+  const hipError_t rc = hipEventDestroy((hipEvent_t)event);
+  if (rc != hipSuccess) return merr(std::string("hp_event_destroy: ") + hipGetErrorString(rc));
+  return 0;
+}
+
 int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float accept, void** stream_a, void** stream_b, float report[3]) {
   if (!a || !b || !stream_a || !stream_b) return merr("hp_pick_concurrent_streams: null argument");
   if (!a->on_device || !b->on_device) return merr("hp_pick_concurrent_streams: a model was loaded with HP_MODEL_NO_DEVICE");

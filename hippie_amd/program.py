@@ -151,7 +151,8 @@ EXPORTS = ("hp_model_save", "hp_abi_version", "hp_last_error", "hp_device_info",
            "hp_model_load", "hp_model_destroy", "hp_model_config", "hp_model_tensor_count", "hp_model_tensor_info", "hp_model_find",
            "hp_model_arena", "hp_model_program", "hp_model_segment", "hp_model_run", "hp_model_forward", "hp_model_backward",
            "hp_model_optimizer_step", "hp_model_train_step", "hp_model_train_step_staged", "hp_model_set_optimizer", "hp_model_batches_tracked", "hp_model_write", "hp_model_read",
-           "hp_model_synchronize", "hp_stream_create", "hp_stream_destroy", "hp_pick_concurrent_streams")
+           "hp_model_synchronize", "hp_stream_create", "hp_stream_destroy", "hp_pick_concurrent_streams",
+           "hp_event_create", "hp_event_record", "hp_event_synchronize", "hp_event_destroy")
 
 
 class HipEngineError(RuntimeError):
@@ -210,6 +211,10 @@ def load_library():
     lib.hp_model_synchronize.argtypes = [vp, vp]
     lib.hp_stream_create.argtypes = [ctypes.POINTER(vp)]
     lib.hp_stream_destroy.argtypes = [vp]
+    lib.hp_event_create.argtypes = [ctypes.POINTER(vp)]
+    lib.hp_event_record.argtypes = [vp, vp]
+    lib.hp_event_synchronize.argtypes = [vp]
+    lib.hp_event_destroy.argtypes = [vp]
     lib.hp_pick_concurrent_streams.argtypes = [vp, vp, ctypes.c_int, ctypes.c_float, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_float)]
     if lib.hp_abi_version() != ABI_VERSION:
         raise HipEngineError("libhippie_hip.so ABI version mismatch")

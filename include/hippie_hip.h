@@ -427,6 +427,12 @@ int hp_model_synchronize(HpModel* m, void* stream);
 int hp_stream_create(void** out);
 int hp_stream_destroy(void* stream);
 int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float accept, void** stream_a, void** stream_b, float report[3]);
+/* Events (hipEvent_t as void*, timing disabled): record on a stream after step i, synchronize on the event of step i - 2 before queueing step
+ * i — a host that stays two steps ahead of the GPU instead of queueing a whole epoch is ~1 % faster. */
+int hp_event_create(void** out);
+int hp_event_record(void* event, void* stream);
+int hp_event_synchronize(void* event);
+int hp_event_destroy(void* event);
 
 #ifdef __cplusplus
 }

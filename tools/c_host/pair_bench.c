@@ -70,11 +70,24 @@ int main(int argc, char** argv) {
   for (int k = 0; k < warmup; ++k)
     for (int j = 0; j < 2; ++j) CHECK(hp_model_train_step_staged(m[j], 1, s[j]));
   for (int j = 0; j < 2; ++j) CHECK(hp_model_synchronize(m[j], s[j]));
+  /* the host stays RUN_AHEAD steps ahead of the slower stream (events), as bench.py does: queueing everything at once is ~1 % slower */
+  enum { RUN_AHEAD = 2 };
+  void* ev[2][RUN_AHEAD];
+  for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < RUN_AHEAD; ++r) CHECK(hp_event_create(&ev[j][r]));
   const double t0 = now();
-  for (int k = 0; k < steps; ++k)
-    for (int j = 0; j < 2; ++j) CHECK(hp_model_train_step_staged(m[j], 1, s[j]));
+  for (int k = 0; k < steps; ++k) {
+    if (k >= RUN_AHEAD)
+      for (int j = 0; j < 2; ++j) CHECK(hp_event_synchronize(ev[j][k % RUN_AHEAD]));
+    for (int j = 0; j < 2; ++j) {
+      CHECK(hp_model_train_step_staged(m[j], 1, s[j]));
+      CHECK(hp_event_record(ev[j][k % RUN_AHEAD], s[j]));
+    }
+  }
   for (int j = 0; j < 2; ++j) CHECK(hp_model_synchronize(m[j], s[j]));
   const double dt = now() - t0;
+  for (int j = 0; j < 2; ++j)
+    for (int r = 0; r < RUN_AHEAD; ++r) CHECK(hp_event_destroy(ev[j][r]));
   float sc[2][4];
   for (int j = 0; j < 2; ++j) CHECK(hp_model_read(m[j], "scalars", sc[j], 16, 0, s[j]));
   printf("{\"host\": \"C99 over include/hippie_hip.h\", \"samples_per_s\": %.1f, \"ms_per_step\": %.4f, \"steps\": %d, \"warmup\": %d, \"batch\": %d, "
