@@ -10,15 +10,17 @@ cd $R
 timeout -k 10 400 python bench.py --steps 300 --warmup 30 --per-op > $O/${T}_bench.json 2> $O/${T}_per_op.txt
 echo "bench done: $(cut -c1-160 $O/${T}_bench.json)"
 cd /tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $T -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe --no-pick-streams > $O/${T}_bench_under_rocprof.json 2> $O/${T}_rocprof.err
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o $T -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe --no-pick-streams --run-ahead 0 > $O/${T}_bench_under_rocprof.json 2> $O/${T}_rocprof.err
 find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/${T}_kernel_stats.csv \;
 find $O/prof -name "*kernel_trace.csv" -exec python3 $R/tools/timeline.py {} 50 5 \; > $O/${T}_timeline.txt 2>&1 || true
 echo "rocprof done: $(head -3 $O/${T}_timeline.txt | tail -1)"
+# (--run-ahead 0 in the traced runs: under the tracer a graph launch costs the host milliseconds, and a host that also waits for step i - 2 before
+# launching step i leaves the GPU idle 6 % of the time — an artefact of tracing, not of the schedule)
 # (--no-pick-streams in the profiler runs: the stream-pair measurement replays the models' EVAL-forward graphs, whose conv launches — same kernel
 # names, different epilogue, partly on badly overlapping stream pairs — would be counted into rocprof's per-kernel averages and PMC means)
 # the same trace with ONE model stepping alone (its kernels never share the GPU: durations are the kernel's own)
 for m in 0 1; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_m$m -o $T -- python3 $R/bench.py --only-model $m --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe --no-profile > $O/${T}_bench_only_model$m.json 2> /dev/null
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_m$m -o $T -- python3 $R/bench.py --only-model $m --steps 50 --warmup 5 --no-cpu-baseline --no-trainer --no-dp-probe --no-profile --run-ahead 0 > $O/${T}_bench_only_model$m.json 2> /dev/null
   find $O/prof_m$m -name "*kernel_trace.csv" -exec python3 $R/tools/timeline.py {} 50 5 1 \; > $O/${T}_timeline_only_model$m.txt 2>&1 || true
   rm -rf $O/prof_m$m
 done
