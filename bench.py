@@ -398,7 +398,7 @@ class HbmLoader:
         return _Pass()
 
 
-def trainer_rate(device, data, epochs=2):
+def trainer_rate(device, data, epochs=4):
     """Throughput of the REFERENCE-API path (what scripts/pretrain_pipeline.py runs): hippieUnimodalCVAE +
     hippieUnimodalEmbeddingModelCVAE driven by Trainer.fit over the synthetic pretrain pool at batch 512 — the wave model (no
     clipping) and the time model (clip 1.0) of scripts/train_model_with_multimodal.py:200-224, fitted CONCURRENTLY on two HIP
