@@ -1,6 +1,6 @@
 """Where does a SHORT timed region (the driver's --steps 20 --warmup 5) lose time against the steady state?  Per-step completion
 times of both model streams (events), for the bench's own Pair.
-python tools/micro/short_run_probe.py [steps] [warmup]"""
+python tools/micro/short_run_probe.py [steps] [warmup] [run-ahead]"""
 import os
 import sys
 import time
@@ -11,6 +11,7 @@ import bench
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+D = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # host run-ahead bound (0 = unbounded)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
 data = bench.synth_dataset(bench.N_UNITS, dev, lw=50, lt=100)
@@ -32,6 +33,9 @@ for rep in range(3):
     pair.fork()
     host = []
     for i in range(K):
+        if D and i >= D:
+            for k in range(len(pair.streams)):
+                ev[k][i - D].synchronize()
         pair.step(data, None, True)
         for k, s in enumerate(pair.streams):
             ev[k][i].record(s)
