@@ -166,6 +166,66 @@ class _Net:
     def load_state_dict(self, sd, strict=True, prefix=""):
         return self._any_engine().load_state_dict(sd, strict=strict, prefix=prefix)
 
+    # -- the embedding tables as attributes (scripts/train_model_with_multimodal.py:378-379 REPLACES one) -----------------
+    class _Embedding:
+        """What `model.class_embedding` / `model.source_embedding` reads as: weight (a view into the parameter arena),
+        num_embeddings, embedding_dim — the attributes of the reference's nn.Embedding that its scripts touch."""
+
+        def __init__(self, net, key):
+            self._net, self._key = net, key
+
+        @property
+        def weight(self):
+            eng = self._net._any_engine()
+            return eng.param_view(self._key + ".weight", eng.params)
+
+        @property
+        def num_embeddings(self):
+            return int(self.weight.shape[0])
+
+        @property
+        def embedding_dim(self):
+            return int(self.weight.shape[1])
+
+    @property
+    def source_embedding(self):
+        return _Net._Embedding(self, "source_embedding")
+
+    @property
+    def class_embedding(self):
+        return _Net._Embedding(self, "class_embedding")
+
+    @class_embedding.setter
+    def class_embedding(self, module):
+        """`model.class_embedding = nn.Embedding(n, class_hidden_dim)` (the reference's supervised stage, scripts/...:378-379): a
+        NEW class table of n rows with the given weights; every other parameter, the BatchNorm buffers and — for the tensors whose
+        shape is unchanged — the AdamW moments are kept.  The network is re-lowered for the new table size on its next use."""
+        w = module.weight if hasattr(module, "weight") else module
+        w = torch.as_tensor(w).detach().float()
+        H = self.cfg.class_hidden_dim
+        if w.ndim != 2 or w.shape[1] != H:
+            raise ValueError(f"class_embedding must be [num_classes, {H}], got {tuple(w.shape)}")
+        self.check_deferred_errors()
+        if self._root is not None:
+            eng = self._root
+            sd = {k: v.detach().clone() for k, v in eng.state_dict().items()}
+            moments = {k: (eng.param_view(k, eng.m).detach().clone(), eng.param_view(k, eng.v).detach().clone()) for k in eng.plan.params}
+            step = eng.adam_step
+        else:
+            sd, moments, step = dict(self._pending_sd), None, 0
+        sd["class_embedding.weight"] = w.clone()
+        self.cfg = replace(self.cfg, num_classes=int(w.shape[0]))
+        self._engines, self._root = {}, None
+        self._pending_sd = sd
+        self._generation += 1
+        if moments is not None:
+            eng = self._any_engine()                     # lowered for the new table; parameters from `sd`
+            for k, (m_, v_) in moments.items():
+                if k in eng.plan.params and tuple(m_.shape) == tuple(eng.plan.params[k].shape):
+                    eng.param_view(k, eng.m).copy_(m_)
+                    eng.param_view(k, eng.v).copy_(v_)
+            eng.io("adam_step").fill_(step)
+
     def parameters(self):
         """Handle for optimisers (hippie_amd.optimizers.AdamWScheduleFree(model.parameters(), ...))."""
         from .optimizers import ParamHandle

@@ -346,3 +346,62 @@ def test_label_checks_are_immediate_again_after_fit():
     with pytest.raises(IndexError):
         mod.set_gradient_clip(0.5)
     net.label_check = "sync"
+
+
+def test_class_embedding_reassignment_keeps_everything_else():
+    """`model.class_embedding = nn.Embedding(n, class_hidden_dim)` as the reference's supervised stage does
+    (scripts/train_model_with_multimodal.py:378-379): a new class table, all other parameters / buffers / AdamW moments kept."""
+    z, L, B = 10, 50, 16
+    net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+    om = O.OracleModel("unimodal", z, L, salt=9)
+    net.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-4, weight_decay=0.01)
+    x, src, cls, eps = O.synth_inputs(B, L, z, salt=9)
+    net.set_eps_source(lambda eng: eps.cuda())
+    labels = torch.stack([cls % 3, src], 1).cuda()
+    for i in range(2):
+        mod.optimizer.zero_grad()
+        loss = mod.training_step((x.cuda().view(B, 1, L), labels), i)
+        loss.backward()
+        mod.optimizer.step()
+    assert net.class_embedding.num_embeddings == 5 and net.class_embedding.embedding_dim == 5 and net.source_embedding.num_embeddings == 5
+    before = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    opt_before = mod.optimizer.state_dict()
+    torch.manual_seed(123)
+    new = torch.nn.Embedding(3, net.class_hidden_dim)
+    net.class_embedding = new
+    assert net.class_embedding.num_embeddings == 3
+    after = net.state_dict()
+    for k, v in before.items():
+        if k == "class_embedding.weight":
+            np.testing.assert_array_equal(after[k].cpu().numpy(), new.weight.detach().numpy())
+        else:
+            assert torch.equal(after[k].cpu(), v), k
+    opt_after = mod.optimizer.state_dict()
+    names = opt_after["param_names"]
+    for i, k in enumerate(names):
+        a, b = opt_after["state"][i], opt_before["state"][opt_before["param_names"].index(k)]
+        if k == "class_embedding.weight":
+            assert tuple(a["exp_avg"].shape) == (3, 5) and float(a["exp_avg"].abs().sum()) == 0.0
+        else:
+            assert torch.equal(a["exp_avg"].cpu(), b["exp_avg"].cpu()) and torch.equal(a["exp_avg_sq"].cpu(), b["exp_avg_sq"].cpu()), k
+        assert float(a["step"]) == 2.0
+    # the re-lowered network computes what a freshly built 3-class network with the same weights computes, and keeps training
+    ref = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=3)
+    ref.load_state_dict({k: v.detach() for k, v in after.items()})
+    ref.set_eps_source(lambda eng: eps.cuda())
+    net.eval(), ref.eval()
+    a = net(x.cuda().view(B, 1, L), source_labels=src.cuda(), class_labels=(cls % 3).cuda())
+    b = ref(x.cuda().view(B, 1, L), source_labels=src.cuda(), class_labels=(cls % 3).cuda())
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    with pytest.raises(IndexError):
+        net(x.cuda().view(B, 1, L), source_labels=src.cuda(), class_labels=torch.full((B,), 4, device="cuda"))
+    net.train()
+    mod.optimizer.zero_grad()
+    loss = mod.training_step((x.cuda().view(B, 1, L), labels), 2)
+    loss.backward()
+    mod.optimizer.step()
+    assert np.isfinite(float(loss.item())) and mod.optimizer.state_dict()["state"][0]["step"] == 3.0
+    with pytest.raises(ValueError):
+        net.class_embedding = torch.nn.Embedding(3, 7)
