@@ -5,22 +5,61 @@ import numpy as np
 import torch
 
 
+def _side_streams(wave_model, time_model, wave, label_wave, time, label_time):
+    """Two HIP streams on which the two modules' encoder passes overlap (hippie_amd.streams: measured, cached per device), or None
+    when the modules are not this package's GPU modules."""
+    try:
+        if not (wave.is_cuda and time.is_cuda and hasattr(wave_model, "embed") and hasattr(time_model, "embed")):
+            return None
+        from .streams import pick_concurrent_streams
+        engs = [m.model.engine(int(x.shape[0]), lab.ndim == 2) for m, x, lab in ((wave_model, wave, label_wave), (time_model, time, label_time))]
+        return pick_concurrent_streams(engs, wave.device)
+    except Exception:              # any surprise: the sequential path below is always correct
+        return None
+
+
 def get_embeddings(dataloader_wave, dataloader_time, wave_model, time_model):
     """zip the two loaders, forward both modules, keep `enc` (output[0]), row-standardise with the
-    unbiased std (torch.std, ddof=1), concatenate wave | time.  Returns three numpy arrays."""
+    unbiased std (torch.std, ddof=1), concatenate wave | time.  Returns three numpy arrays.
+    The two modules are independent: on the GPU their encoder passes run side by side on two streams (same numbers; the
+    reference runs them one after the other)."""
     emb_w, emb_t = [], []
+    streams = None
+    first = True
     for (wave, label_wave), (time, label_time) in zip(dataloader_wave, dataloader_time):
         assert (label_wave == label_time).all()
-        # only output[0] is used (scripts/utils.py:84-85): modules that offer it run the encoder half alone
-        e_wave = (wave_model.embed((wave, label_wave)) if hasattr(wave_model, "embed") else wave_model((wave, label_wave))[0]).clone()
-        e_time = (time_model.embed((time, label_time)) if hasattr(time_model, "embed") else time_model((time, label_time))[0]).clone()
-        e_wave = (e_wave - e_wave.mean(dim=1)[:, None]) / e_wave.std(dim=1)[:, None]
-        e_time = (e_time - e_time.mean(dim=1)[:, None]) / e_time.std(dim=1)[:, None]
-        emb_w.append(e_wave)
-        emb_t.append(e_time)
+        if first:
+            streams, first = _side_streams(wave_model, time_model, wave, label_wave, time, label_time), False
+        outs = []
+        cur = torch.cuda.current_stream(wave.device) if streams else None
+        for k, (model, x, lab) in enumerate(((wave_model, wave, label_wave), (time_model, time, label_time))):
+            if streams:
+                streams[k].wait_stream(cur)                 # the batch was produced on the caller's stream
+                x.record_stream(streams[k]), lab.record_stream(streams[k])
+            with (torch.cuda.stream(streams[k]) if streams else _null()):
+                # only output[0] is used (scripts/utils.py:84-85): modules that offer it run the encoder half alone
+                e = (model.embed((x, lab)) if hasattr(model, "embed") else model((x, lab))[0]).clone()
+                e = (e - e.mean(dim=1)[:, None]) / e.std(dim=1)[:, None]
+            outs.append(e)
+        emb_w.append(outs[0])
+        emb_t.append(outs[1])
+    if streams:
+        cur = torch.cuda.current_stream(emb_w[0].device)
+        for s_ in streams:
+            cur.wait_stream(s_)
+        for t in emb_w + emb_t:
+            t.record_stream(cur)                            # allocated on a side stream, consumed (and freed) on the caller's
     ew = torch.cat(emb_w, dim=0).detach().cpu().numpy()
     et = torch.cat(emb_t, dim=0).detach().cpu().numpy()
     return ew, et, np.concatenate([ew, et], axis=1)
+
+
+class _null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
 
 
 def get_embeddings_multimodal(loader, model):

@@ -405,3 +405,37 @@ def test_class_embedding_reassignment_keeps_everything_else():
     assert np.isfinite(float(loss.item())) and mod.optimizer.state_dict()["state"][0]["step"] == 3.0
     with pytest.raises(ValueError):
         net.class_embedding = torch.nn.Embedding(3, 7)
+
+
+def test_get_embeddings_two_streams_equal_one_stream(monkeypatch):
+    """the wave and time encoder passes of get_embeddings run side by side on two streams: the same bits as one after the other, over
+    several batches with a ragged last one (inputs handed over from the caller's stream, results consumed on it)."""
+    from hippie_amd import utils
+    z, B, N = 10, 64, 64 * 5 + 23
+    mods, loaders = [], []
+    g = torch.Generator().manual_seed(11)
+    labels = torch.randint(1, 5, (N,), generator=g).cuda()
+    for L, salt in ((50, 3), (100, 4)):
+        net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+        om = O.OracleModel("unimodal", z, L, salt=salt)
+        net.load_state_dict({k: v.detach() for k, v in om.state.items()})
+        mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-4, weight_decay=0.01)
+        mod.eval()
+        mods.append(mod)
+        x = torch.randn(N, 1, L, generator=g).cuda()
+        loaders.append([(x[i: i + B], labels[i: i + B]) for i in range(0, N, B)])
+    seen = []
+    real = utils._side_streams
+
+    def spy(*a):
+        seen.append(real(*a))
+        return seen[-1]
+    monkeypatch.setattr(utils, "_side_streams", spy)
+    two = [utils.get_embeddings(loaders[0], loaders[1], mods[0], mods[1]) for _ in range(3)]
+    assert seen and all(s is not None and len(s) == 2 and s[0] != s[1] for s in seen)
+    monkeypatch.setattr(utils, "_side_streams", lambda *a: None)
+    one = utils.get_embeddings(loaders[0], loaders[1], mods[0], mods[1])
+    for run in two:
+        for a, b in zip(run, one):
+            assert a.shape == b.shape and a.shape[0] == N
+            np.testing.assert_array_equal(a, b)
