@@ -1,3 +1,5 @@
+"""scripts/pretrain_pipeline.py on a synthetic data root over a set of flag combinations (unimodal / multimodal, bf16, sequential fits,
+limited batches, early stopping, z 32, another target): prints OK / FAIL per combination.  python tools/pipeline_combo_smoke.py"""
 import os, sys, tempfile, pathlib, traceback
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "scripts"); sys.path.insert(0, "tests")
