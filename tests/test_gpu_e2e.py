@@ -614,3 +614,16 @@ def test_staged_step_is_one_graph_and_equals_the_host_staged_step():
             H.assert_adam_close(n(a[k]), n(b[k]), 1e-5, k, steps=spe + 2, frac=2e-2)
     with pytest.raises(Exception):
         plain.train_step_staged()
+
+
+def test_long_run_loss_curves_track_the_oracle():
+    """160 optimisation steps of the wave cVAE on the same batches and noise in the engine and in the CPU oracle: single trajectories
+    diverge chaotically, the loss CURVES must not (loss and mse within a factor of two at every checkpoint, plateau within 25 %).
+    Guards what single-step parity cannot see: bias correction at large step counts, weight decay, the KL weight, running statistics
+    (tools/long_run_vs_oracle.py; at 1 500 steps the plateaus agree to 1 %)."""
+    from tools import long_run_vs_oracle as lr
+    rows = lr.run(steps=160, B=128, verbose=False)
+    bad, tail_e, tail_o = lr.check(rows)
+    assert not bad, bad
+    assert 0.75 <= tail_e / tail_o <= 1.33, (tail_e, tail_o)
+    assert rows[-1][1][0] < 0.05 * rows[0][1][0]          # and the loss really fell (8.6 -> < 0.1)

@@ -1,0 +1,62 @@
+"""Long-run sanity: the engine and the CPU oracle (torch fp32 restatement, pinned by the reference fixtures) train the SAME model on the SAME
+batches and noise for many steps.  Individual trajectories diverge chaotically after a few dozen steps (leaky-ReLU branches, Adam), so
+the check is on the loss CURVES: both must fall the same way (mse, KL and total at every checkpoint within a factor, final plateau
+within 25 %).  Guards against errors that single-step parity cannot see (bias correction at large step counts, weight decay, the
+KL weight, running statistics).        python tools/long_run_vs_oracle.py [steps] [batch]"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from hippie_amd import planner
+from hippie_amd.engine import Engine
+from oracle import cvae_oracle as O
+
+
+
+def run(steps=240, B=128, z=10, L=50, lr=1e-3, pool=2048, verbose=True):
+    """-> [(step, engine (loss, mse1, mse2, kl), oracle (loss, mse, kl))] at ~12 checkpoints"""
+    torch.set_num_threads(min(16, os.cpu_count() or 8))
+    wave, _, labels = bench.synth_dataset(pool, "cpu", lw=L)
+    om = O.OracleModel("unimodal", z, L, salt=1)
+    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=0.0))
+    eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
+    g = torch.Generator().manual_seed(5)
+    rows = []
+    t0 = time.time()
+    for i in range(steps):
+        idx = torch.randperm(pool, generator=g)[:B]
+        x, src = wave[idx].view(B, 1, L), labels[idx]
+        eps = torch.randn(B, z, generator=g)
+        eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+        eng.train_step(True)
+        outs, ls, _ = om.train_step((x, src, None), eps, lr, weight_decay=0.01, beta=1.0)
+        if i % max(1, steps // 12) == 0 or i == steps - 1:
+            e = eng.scalars()
+            o = [float(v.detach()) for v in ls]
+            rows.append((i, e, o))
+            if verbose:
+                print(f"step {i:4d}  engine loss {e[0]:.5f} mse {e[1]:.5f} kl {e[3]:.5f}   oracle loss {o[0]:.5f} mse {o[1]:.5f} kl {o[-1]:.5f}   ({time.time() - t0:.0f} s)", flush=True)
+    return rows
+
+
+def check(rows):
+    """loss and mse within a factor of two of the oracle's at every checkpoint; the plateau (mean of the last three) within 25 %"""
+    bad = []
+    for i, e, o in rows:
+        for name, a, b in (("loss", e[0], o[0]), ("mse", e[1], o[1])):
+            if not (0.5 * b - 1e-5 <= a <= 2.0 * b + 1e-5):
+                bad.append((i, name, a, b))
+    tail_e = sum(r[1][0] for r in rows[-3:]) / 3
+    tail_o = sum(r[2][0] for r in rows[-3:]) / 3
+    return bad, tail_e, tail_o
+
+
+if __name__ == "__main__":
+    rows = run(int(sys.argv[1]) if len(sys.argv) > 1 else 240, int(sys.argv[2]) if len(sys.argv) > 2 else 128)
+    bad, tail_e, tail_o = check(rows)
+    print(f"plateau (last three checkpoints): engine {tail_e:.5f}, oracle {tail_o:.5f}, ratio {tail_e / tail_o:.3f}")
+    assert not bad, bad
+    assert 0.75 <= tail_e / tail_o <= 1.33
+    print("long run ok")

@@ -9,6 +9,7 @@ dev = torch.device("cuda", 0)
 data = bench.synth_dataset(bench.N_UNITS, dev)
 pair = bench.Pair(dev, 1)
 g = torch.Generator().manual_seed(1)
+pair.load_tables(data, torch.randperm(bench.N_UNITS, generator=g).to(dev))      # (staged mode trains on the RESIDENT tables; without this they are zeros)
 hist = []
 pair.fork()
 for i in range(steps):
@@ -24,4 +25,6 @@ pair.join(); torch.cuda.synchronize()
 ok = all(torch.isfinite(e.params).all().item() for e in pair.eng)
 print("finite parameters:", ok, " adam steps:", [e.adam_step for e in pair.eng])
 assert ok and hist[-1][1][0][0] < 0.5 * hist[0][1][0][0] and hist[-1][1][1][0] < 0.5 * hist[0][1][1][0]
+# the wave model's reconstruction error settles at the conditional-mean floor of the synthetic pool (~0.011: posterior collapse, KL -> 0), not at zero
+assert 0.004 < hist[-1][1][0][1] < 0.03, hist[-1][1][0]
 print("soak ok")
