@@ -616,14 +616,15 @@ def test_staged_step_is_one_graph_and_equals_the_host_staged_step():
         plain.train_step_staged()
 
 
-def test_long_run_loss_curves_track_the_oracle():
+@pytest.mark.parametrize("L,clip,steps", [(50, None, 160), (100, 1.0, 120)])
+def test_long_run_loss_curves_track_the_oracle(L, clip, steps):
     """160 optimisation steps of the wave cVAE on the same batches and noise in the engine and in the CPU oracle: single trajectories
-    diverge chaotically, the loss CURVES must not (loss and mse within a factor of two at every checkpoint, plateau within 25 %).
+    diverge chaotically, the loss CURVES must not (mse within a factor of 2.5 and loss within 3 at every checkpoint, plateau within [0.6, 1.67]).
     Guards what single-step parity cannot see: bias correction at large step counts, weight decay, the KL weight, running statistics
     (tools/long_run_vs_oracle.py; at 1 500 steps the plateaus agree to 1 %)."""
     from tools import long_run_vs_oracle as lr
-    rows = lr.run(steps=160, B=128, verbose=False)
+    rows = lr.run(steps=steps, B=128, L=L, clip=clip, verbose=False)      # (the second case: the time model's shape, with gradient clipping)
     bad, tail_e, tail_o = lr.check(rows)
     assert not bad, bad
-    assert 0.75 <= tail_e / tail_o <= 1.33, (tail_e, tail_o)
-    assert rows[-1][1][0] < 0.05 * rows[0][1][0]          # and the loss really fell (8.6 -> < 0.1)
+    assert 0.6 <= tail_e / tail_o <= 1.67, (tail_e, tail_o)
+    assert rows[-1][1][0] < 0.05 * rows[0][1][0]          # and the loss really fell (wave: 8.6 -> < 0.1)
