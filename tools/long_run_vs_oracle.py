@@ -2,7 +2,7 @@
 batches and noise for many steps.  Individual trajectories diverge chaotically after a few dozen steps (leaky-ReLU branches, Adam), so
 the check is on the loss CURVES: both must fall the same way (reconstruction error and total loss at every checkpoint within a factor,
 the final plateau within [0.6, 1.67]).  Guards against errors that single-step parity cannot see (bias correction at large step counts, weight decay, the
-KL weight, running statistics).        python tools/long_run_vs_oracle.py [steps] [batch] [L] [clip | 0] [f32 | bf16]"""
+KL weight, running statistics).        python tools/long_run_vs_oracle.py [steps] [batch] [L] [clip | 0] [f32 | bf16] [multimodal]"""
 import os
 import sys
 import time
@@ -15,14 +15,16 @@ from oracle import cvae_oracle as O
 
 
 
-def run(steps=240, B=128, z=10, L=50, lr=1e-3, pool=2048, verbose=True, clip=None, mfma_dtype="f32"):
+def run(steps=240, B=128, z=10, L=50, lr=1e-3, pool=2048, verbose=True, clip=None, mfma_dtype="f32", multimodal=False):
     """-> [(step, engine (loss, mse1, mse2, kl), oracle (loss, mse, kl))] at ~12 checkpoints"""
     torch.set_num_threads(min(16, os.cpu_count() or 8))
-    wave, isi, labels = bench.synth_dataset(pool, "cpu", lw=L, lt=L)
-    if clip:                       # the time model of the pipeline: spike-timing histograms, gradient clipping (scripts/...:222)
+    L2 = 100
+    wave, isi, labels = bench.synth_dataset(pool, "cpu", lw=L, lt=L2 if multimodal else L)
+    if clip and not multimodal:    # the time model of the pipeline: spike-timing histograms, gradient clipping (scripts/...:222)
         wave = isi
-    om = O.OracleModel("unimodal", z, L, salt=1)
-    eng = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=clip or 0.0, mfma_dtype=mfma_dtype))
+    kind = "multimodal" if multimodal else "unimodal"
+    om = O.OracleModel(kind, z, L, output_size2=L2 if multimodal else None, salt=1)
+    eng = Engine(planner.ModelCfg(kind, z, L, L2), B, planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=clip or 0.0, mfma_dtype=mfma_dtype))
     eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
     g = torch.Generator().manual_seed(5)
     rows = []
@@ -31,9 +33,10 @@ def run(steps=240, B=128, z=10, L=50, lr=1e-3, pool=2048, verbose=True, clip=Non
         idx = torch.randperm(pool, generator=g)[:B]
         x, src = wave[idx].view(B, 1, L), labels[idx]
         eps = torch.randn(B, z, generator=g)
-        eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda())
+        x2 = isi[idx].view(B, 1, L2) if multimodal else None
+        eng.set_inputs(x.cuda(), src.cuda(), None, eps.cuda(), x2=x2.cuda() if multimodal else None)
         eng.train_step(True)
-        outs, ls, _ = om.train_step((x, src, None), eps, lr, weight_decay=0.01, beta=1.0, clip=clip)
+        outs, ls, _ = om.train_step((x, x2, src, None) if multimodal else (x, src, None), eps, lr, weight_decay=0.01, beta=1.0, clip=clip)
         if i % max(1, steps // 12) == 0 or i == steps - 1:
             e = eng.scalars()
             o = [float(v.detach()) for v in ls]
@@ -59,7 +62,7 @@ def check(rows):
 if __name__ == "__main__":
     rows = run(int(sys.argv[1]) if len(sys.argv) > 1 else 240, int(sys.argv[2]) if len(sys.argv) > 2 else 128,
                L=int(sys.argv[3]) if len(sys.argv) > 3 else 50, clip=(float(sys.argv[4]) or None) if len(sys.argv) > 4 else None,
-               mfma_dtype=sys.argv[5] if len(sys.argv) > 5 else "f32")
+               mfma_dtype=sys.argv[5] if len(sys.argv) > 5 else "f32", multimodal=len(sys.argv) > 6 and sys.argv[6] == "multimodal")
     bad, tail_e, tail_o = check(rows)
     print(f"plateau (last four checkpoints): engine {tail_e:.5f}, oracle {tail_o:.5f}, ratio {tail_e / tail_o:.3f}")
     assert not bad, bad
