@@ -13,7 +13,6 @@ from __future__ import annotations
 from collections import OrderedDict
 from dataclasses import replace
 
-import torch
 
 from . import program as P
 
