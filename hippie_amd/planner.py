@@ -69,6 +69,7 @@ class TrainCfg:
     deterministic_wgrad: bool = False   # True: per-split slabs + ordered reduce instead of fp32 atomics
     grouped_wgrad: bool = True          # one launch for all weight-gradient GEMMs of a backward pass
     intra_pair: bool = True             # HP_OP_PAIR for independent ops inside one model (conv1 + shortcut, ...)
+    zip_towers: bool = True             # multimodal: the two towers' same-shaped launches as HP_OP_PAIR units (Builder.zip_towers)
     fold_eval_bn: bool = True           # eval forward: BatchNorm (+residual, +leaky_relu) folded into the producing conv's epilogue
     fuse_bn: bool = True                # training: a block's inner BatchNorm + leaky_relu is evaluated in its consumers' operand
                                         # loaders (HP_CONV_IN_BN: the activation tensor is never written) and the BatchNorm-backward
@@ -354,6 +355,88 @@ class Lowering:
         ra["flags"] = int(ra["flags"]) | P.FLAG_MEMBER
         rb["flags"] = int(rb["flags"]) | P.FLAG_MEMBER
         self.o.add(P.PAIR, 0, i=[a, b], note=note)
+
+    def zip_towers(self, i0, i1):
+        """Multimodal model: recs[i0:i1] and recs[i1:] are the SAME sub-network emitted for the two modality towers (encoder_mod1 /
+        encoder_mod2, decoder_mod1 / decoder_mod2; hippie/model.py:352-432), independent of each other.  One after the other they
+        are one latency-bound chain twice as long; interleaved, every pair of same-kind launches that HP_OP_PAIR can run together
+        (convs, BatchNorm apply / backward reduce / backward apply) becomes ONE launch with both towers' workgroups — at batch 512 a
+        single tower's layer does not fill the chip.  Launches that are already intra-tower pairs, and kinds HP_OP_PAIR does not
+        take, stay single, tower 1's before tower 2's (the one cross-tower dependence — decoder_fc.0's input gradients accumulate
+        into one buffer — keeps its order that way)."""
+        if not (self.train.zip_towers and self.train.intra_pair) or P.debug_knob("HIPPIE_NO_ZIP_TOWERS") == "1":     # (the knob: A/B runs of unmodified callers)
+            return
+        recs, notes = self.o.recs, self.o.notes
+        i2 = len(recs)
+        # the ordered-slab weight gradients (deterministic_wgrad) are emitted in line and share ONE slab buffer: [wgrad -> slab, slab ->
+        # gradient] of tower 1 must not be interleaved with tower 2's.  (The default path defers all weight gradients to one grouped
+        # launch at the end of the pass; every other buffer inside the two ranges is the tower's own.)
+        if any(int(r["op"]) in (P.SLAB_REDUCE, P.WGRAD_TAPS) for r in recs[i0:i2]):
+            return
+
+        def units(lo, hi):
+            out, k = [], lo
+            while k < hi:
+                if int(recs[k]["op"]) != P.PAIR and int(recs[k]["flags"]) & P.FLAG_MEMBER:
+                    j = k
+                    while int(recs[j]["op"]) != P.PAIR:
+                        j += 1
+                        if j >= hi:
+                            return None                       # a member without its launch record inside the range: leave everything alone
+                    out.append(list(range(k, j + 1)))
+                    k = j + 1
+                else:
+                    out.append([k])
+                    k += 1
+            return out
+
+        U1, U2 = units(i0, i1), units(i1, i2)
+        if U1 is None or U2 is None or len(U1) != len(U2):
+            return
+        pairable = (P.CONV_TAPS, P.BN_APPLY, P.BN_BWD_REDUCE, P.BN_BWD_APPLY)
+
+        def can_pair(a, b):
+            ra, rb = recs[a], recs[b]
+            op = int(ra["op"])
+            if op != int(rb["op"]) or op not in pairable:
+                return False
+            fa, fb = int(ra["flags"]), int(rb["flags"])
+            if op == P.CONV_TAPS:
+                return (fa & 1) == (fb & 1) and (fa & P.CONV_BF16) == (fb & P.CONV_BF16)
+            return (int(ra["i"][1]) % 4 == 0) == (int(rb["i"][1]) % 4 == 0)       # both on the same vector width (C % 4)
+
+        order = []                                           # ("o", old index) | ("p", old a, old b)
+        for u1, u2 in zip(U1, U2):
+            if len(u1) == 1 and len(u2) == 1 and can_pair(u1[0], u2[0]):
+                order += [("o", u1[0]), ("o", u2[0]), ("p", u1[0], u2[0])]
+            else:
+                order += [("o", k) for k in u1] + [("o", k) for k in u2]
+        remap, new_recs, new_notes = {}, [], []
+        for item in order:
+            if item[0] == "o":
+                remap[item[1]] = i0 + len(new_recs)
+                new_recs.append(recs[item[1]])
+                new_notes.append(notes[item[1]])
+            else:
+                a, b = item[1], item[2]
+                for k in (a, b):
+                    recs[k]["flags"] = int(recs[k]["flags"]) | P.FLAG_MEMBER
+                r = np.zeros((), dtype=P.OP_DTYPE)
+                r["op"] = P.PAIR
+                r["buf"][:] = P.NULL
+                r["i"][0], r["i"][1] = -1 - a, -1 - b         # old indices, marked: resolved below
+                new_recs.append(r)
+                new_notes.append("pair " + notes[a] + " | " + notes[b])
+        for r in new_recs:
+            if int(r["op"]) == P.PAIR:
+                for q in (0, 1):
+                    v = int(r["i"][q])
+                    r["i"][q] = remap[-1 - v] if v < 0 else remap[v]
+        recs[i0:i2] = new_recs
+        notes[i0:i2] = new_notes
+        for key, k in list(self.conv_rec_of.items()):
+            if k in remap:
+                self.conv_rec_of[key] = remap[k]
 
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note="", coef=None):
         """coef: x is the raw input of a BatchNorm whose activation was never stored (HP_CONV_IN_BN on the forward
@@ -953,7 +1036,13 @@ class Lowering:
             self.count_flops = training
             self.o.begin("fwd_" + mode)
             zero_idx = self.o.add(P.ZERO, 0, i=[0, 0], buf=[Ref(P.WS, pl.stats_base)], note="zero statistics")
-            pooled = [self.encoder_fwd(e, x, L, training) for e, x, L in zip(enc, xs, lens)]
+            marks = [len(self.o.recs)]
+            pooled = []
+            for e, x, L in zip(enc, xs, lens):
+                pooled.append(self.encoder_fwd(e, x, L, training))
+                marks.append(len(self.o.recs))
+            if multi:
+                self.zip_towers(marks[0], marks[1])
             ncat = (2 * z) * len(enc) + 2 * H
             c0 = pl.f32(B * ncat)
             hsegs = []
@@ -992,6 +1081,7 @@ class Lowering:
             self.concat(c1, ncat1, [(0, z, z, zz, None)] + self.emb_segs(), "cat(z, source_emb, class_emb)")
             heads = []
             recs = []
+            marks = [len(self.o.recs)]
             for k, (fc, dd) in enumerate(zip(dfc, decs)):
                 fcname = names[k][0]
                 u3 = pl.f32(B * 2 * z)
@@ -1009,6 +1099,9 @@ class Lowering:
                 self.o.add(P.MSE_FWD_BWD, 0, i=[n, 1 + k], f=[w if multi else 1.0], buf=[xs[k], rec, drec, loss], note="mse")
                 heads.append(dict(u3=u3, u4=u4, dv=dv, drec=drec))
                 recs.append(rec)
+                marks.append(len(self.o.recs))
+            if multi:
+                self.zip_towers(marks[0], marks[1])
             n1 = B * lens[0]
             n2 = B * lens[1] if multi else 0
             self.o.add(P.LOSS_FINALIZE, 0, i=[B, n1, n2], f=[self.train.beta, self.train.w1 if multi else 1.0,
@@ -1030,6 +1123,7 @@ class Lowering:
             nb = pl.n_param_floats * 4
             self.o.add(P.ZERO, 0, i=[nb & 0xFFFFFFFF, nb >> 32], buf=[Ref(P.GRAD, 0)], note="zero gradients")
             dc1 = pl.f32(B * ncat1)
+            marks = [len(self.o.recs)]
             for k, (fc, dd, hd) in enumerate(zip(dfc, decs, heads)):
                 ddv = pl.f32(B * 2 * z)
                 self.decoder_bwd(dd, hd["drec"], ddv)
@@ -1037,6 +1131,9 @@ class Lowering:
                 du3 = pl.f32(B * 2 * z)
                 self.linear_bwd(B, fc["f2"], du4, 2 * z, hd["u3"], 2 * z, du3, 2 * z, mask=hd["u3"], ldmask=2 * z, note="decoder_fc.2")
                 self.linear_bwd(B, fc["f0"], du3, 2 * z, c1, ncat1, dc1, ncat1, accumulate=(k > 0), note="decoder_fc.0")
+                marks.append(len(self.o.recs))
+            if multi:
+                self.zip_towers(marks[0], marks[1])
             self.emb_bwd(dc1, ncat1, z)
             dmulv = pl.f32(B * 2 * z)
             self.o.add(P.REPARAM_KL_BWD, 0, i=[B, z, ncat1], f=[self.train.beta], buf=[mulv, eps, dc1, dmulv], note="reparameterize + KL bwd")
@@ -1052,12 +1149,16 @@ class Lowering:
             dc0 = pl.f32(B * ncat)
             self.linear_bwd(B, fc0, du1, 2 * z, c0, ncat, dc0, ncat, note="encoder_fc.0")
             self.emb_bwd(dc0, ncat, 2 * z * len(enc))
+            marks = [len(self.o.recs)]
             for k, e in enumerate(enc):
                 dpooled = pl.f32(B * 512)
                 lin = dict(w=e["lin_w"], b=e["lin_b"], N=2 * z, K=512)
                 dh = dc0 + 4 * (2 * z * k)      # column window of dc0, leading dimension ncat
                 self.linear_bwd(B, lin, dh, ncat, e["pooled"], 512, dpooled, 512, note=e["prefix"] + "linear")
                 self.encoder_bwd(e, dpooled)
+                marks.append(len(self.o.recs))
+            if multi:
+                self.zip_towers(marks[0], marks[1])
             self.flush_wgrads()
             self.o.end()
 
