@@ -254,3 +254,46 @@ def test_philox_known_answers_and_moments():
     x = interp.philox_normal(1234, 7, 1 << 20).astype(np.float64)
     assert abs(x.mean()) < 5e-3 and abs(x.std() - 1) < 5e-3 and abs((x ** 3).mean()) < 1e-2 and abs((x ** 4).mean() - 3) < 3e-2
     assert not np.array_equal(interp.philox_normal(1234, 8, 64), interp.philox_normal(1234, 7, 64))
+
+
+def test_multimodal_towers_are_zipped_into_pairs(tmp_path):
+    """planner.Builder.zip_towers: the two towers' same-kind launches become HP_OP_PAIR units (fewer launches, same records otherwise), the
+    zipped program validates in the library, and the ordered-slab weight gradients (one slab shared by both towers) stay unzipped."""
+    import ctypes
+    from hippie_amd import export
+    cfg = planner.ModelCfg("multimodal", 10, 50, 100)
+
+    def launches(plan):
+        ops = plan.ops.array()
+        return sum(1 for r in ops if not int(r["flags"]) & P.FLAG_MEMBER), sum(1 for r in ops if int(r["op"]) == P.PAIR), ops
+
+    on = planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, clip=1.0))
+    off = planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, clip=1.0, zip_towers=False))
+    (l_on, p_on, ops_on), (l_off, p_off, ops_off) = launches(on), launches(off)
+    assert l_on < 0.75 * l_off and p_on > p_off + 60
+    # the same work: every non-PAIR record of the unzipped program is in the zipped one (flags aside: members are marked)
+    key = lambda r: (int(r["op"]), tuple(int(v) for v in r["i"]), tuple(int(b) for b in r["buf"]))      # noqa: E731
+    non_pair = lambda ops: sorted(key(r) for r in ops if int(r["op"]) not in (P.PAIR, P.WGRAD_GROUP))     # noqa: E731  (those two hold record indices)
+    # (workspace offsets differ after liveness packing, so compare with packing off)
+    a = planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, clip=1.0, reuse_workspace=False)).ops.array()
+    b = planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, clip=1.0, reuse_workspace=False, zip_towers=False)).ops.array()
+    assert non_pair(a) == non_pair(b)
+    for k, r in enumerate(ops_on):
+        if int(r["op"]) == P.PAIR:
+            i, j = int(r["i"][0]), int(r["i"][1])
+            assert i < k and j < k and i != j and int(ops_on[i]["op"]) == int(ops_on[j]["op"])
+            assert int(ops_on[i]["flags"]) & P.FLAG_MEMBER and int(ops_on[j]["flags"]) & P.FLAG_MEMBER
+    path = str(tmp_path / "mm.hpm")
+    export.save_model(on, path)
+    lib = P.load_library()
+    m = ctypes.c_void_p()
+    assert lib.hp_model_load(path.encode(), export.NO_DEVICE, ctypes.byref(m)) == 0, lib.hp_last_error()
+    lib.hp_model_destroy(m)
+    det_on = launches(planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, clip=1.0, deterministic_wgrad=True)))
+    det_off = launches(planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, clip=1.0, deterministic_wgrad=True, zip_towers=False)))
+    bwd = lambda plan: plan.ops.segments["bwd"]                                                            # noqa: E731
+    assert det_on[1] > det_off[1]            # forward towers are still zipped ...
+    ops = det_on[2]
+    f, c = bwd(planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, clip=1.0, deterministic_wgrad=True)))
+    slab_users = [k for k in range(f, f + c) if int(ops[k]["op"]) in (P.WGRAD_TAPS, P.SLAB_REDUCE)]
+    assert slab_users and all(int(ops[slab_users[q + 1]]["op"]) == P.SLAB_REDUCE for q in range(0, len(slab_users) - 1, 2) if int(ops[slab_users[q]]["op"]) == P.WGRAD_TAPS)
