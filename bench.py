@@ -16,6 +16,9 @@ gradients are mean-all-reduced over RCCL between backward and AdamW.
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the f32-MFMA implicit-GEMM
 convolution `conv_taps_kernel`), timed with HIP events per launch in an untimed pass right after the
 timed region; `cpu_baseline` times the torch-CPU oracle on a bounded sample on this host's cores.
+Secondary figures on the same line (N = 1): `trainer_samples_per_s` (the reference-API path: Trainer.fit of both modules,
+concurrently), `inference_path` (get_embeddings over the pool), `dp_overhead_1rank` (the step with a 1-rank RCCL all-reduce in it);
+`config.stream_pair` / `config.run_ahead` say how the two model streams were scheduled.
 """
 import argparse
 import json
