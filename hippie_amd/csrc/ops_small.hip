@@ -7,6 +7,7 @@
 // per-channel coefficients live in registers and per-channel sums need one LDS fold and
 // one fp64 atomic per block.  Consecutive lanes touch consecutive channels (coalesced).
 #include "hp_common.h"
+#include "linear_mfma.h"
 
 #include <algorithm>
 #include <vector>
@@ -848,6 +849,17 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(LinArgs p, int rows_p
   linear_bwd_w_body(p, rows_per_z, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// ---- Linear on the matrix cores (linear_mfma.h): the same three ops once the batch makes them GEMMs -----------------------------
+template <bool B_KN>
+__global__ __launch_bounds__(kLinMMThreads) void lin_mm_kernel(LinMM p) {
+  __shared__ __attribute__((aligned(16))) float smem[kLinMMLds];
+  lin_mm_body<B_KN>(p, blockIdx.x, smem);
+}
+__global__ __launch_bounds__(256) void lin_wgrad_kernel(LinWg p, int ntiles) {
+  __shared__ __attribute__((aligned(16))) float smem[kLinWgLds];
+  lin_wgrad_body(p, blockIdx.x % ntiles, blockIdx.x / ntiles, smem);
+}
+
 // ---- reparameterisation / losses ---------------------------------------------------
 __device__ __forceinline__ void block_atomic_f64(double v, double* dst) {
   __shared__ double red[4];
@@ -1287,6 +1299,35 @@ __global__ void step_inc_kernel(int64_t* step) { if (threadIdx.x == 0 && blockId
 
 inline int blocks_for(int64_t n, int per = 256) { return (int)((n + per - 1) / per); }
 
+// The Linear ops take the matrix-core kernels from this many rows on (below it a launch is floor-bound either way and the scalar
+// forms, sized for the 512-row heads, stay).  (the knob: tools/micro/linear_sweep.py and the ragged unit-test shapes)
+inline int lin_mfma_min_rows() {
+  static const int forced = debug_knob_int("HIPPIE_LIN_MFMA_MIN_M");
+  return forced > 0 ? forced : 1024;
+}
+// alignment class of the 4-float pieces `base + row*ld + 4*j`: 4 = 16 bytes, 2 = 8 bytes, 1 = 4 bytes (linear_mfma.h)
+inline int lin_align(const void* base, int ld) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+  if ((a & 15) == 0 && (ld & 3) == 0) return 4;
+  if ((a & 7) == 0 && (ld & 1) == 0) return 2;
+  return 1;
+}
+// rows per M-split of the matrix-core weight gradient: 16 splits of >= 256 rows (a 64x64 tile's 4096 atomics per split stay small
+// next to its MFMA work); flags & 1 (deterministic_wgrad): one split, no cross-workgroup atomics
+inline int lin_wgrad_rows(int M, bool one_split) {
+  if (one_split) return hp::cdiv(M, 32) * 32;
+  return min(1024, max(256, hp::cdiv(hp::cdiv(M, 16), 32) * 32));
+}
+LinWg lin_wgrad_args(const HpOp& op, void* const* bases) {
+  using hp::ptr;
+  LinWg a;
+  a.DY = ptr<const float>(op, 0, bases); a.X = ptr<const float>(op, 1, bases); a.DW = ptr<float>(op, 2, bases); a.DB = ptr<float>(op, 3, bases);
+  a.M = op.i[0]; a.N = op.i[1]; a.K = op.i[2]; a.ldy = op.i[3]; a.ldx = op.i[4];
+  a.alY = lin_align(a.DY, a.ldy); a.alX = lin_align(a.X, a.ldx);
+  a.rows_per_split = lin_wgrad_rows(a.M, op.flags & 1);
+  return a;
+}
+
 // M-slices of HP_OP_LINEAR_BWD_W: every slice ends in one fp32 atomic per (n, k).  Rows per slice = 16 per row lane of the
 // workgroup (256 / min(K, 256) lanes), within [32, 128]: two batches of 8 row loads per thread.  Measured per launch in a
 // graph at M = 512 (tools/micro/linear_sweep.py): the former "1024 workgroups, 16 rows each" took 8.7-8.9 us on the
@@ -1342,10 +1383,10 @@ BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
 // ---- argument records of the small ops that are launched from a table (the small-leaf group) or share their argument
 // decoding with it --------------------------------------------------------------------------------------------------
 struct SmallEntry {
-  int op, variant;          // HP_OP_* ; variant: BatchNorm family vector width (4 / 1)
+  int op, variant;          // HP_OP_* ; variant: LINEAR_BWD_W: 1 = matrix-core form (a.wg; gx = tiles, gy = splits)
   int gx, gy, gz;           // virtual grid of 256-thread blocks
   int rows_per_z;           // LINEAR_BWD_W
-  union { LinArgs lin; EmbArgs emb; ReparamArgs rp; MseArgs mse; LossArgs loss; } a;
+  union { LinArgs lin; LinWg wg; EmbArgs emb; ReparamArgs rp; MseArgs mse; LossArgs loss; } a;
 };
 
 // args + grid of one such op; false for any other opcode
@@ -1361,6 +1402,12 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
       return true;
     }
     case HP_OP_LINEAR_BWD_W: {
+      if (I[0] >= lin_mfma_min_rows()) {
+        const LinWg w = lin_wgrad_args(op, bases);
+        e.variant = 1; e.a.wg = w;
+        e.gx = hp::cdiv(w.N, 64) * hp::cdiv(w.K, 64); e.gy = hp::cdiv(w.M, w.rows_per_split);
+        return true;
+      }
       LinArgs a{};
       a.DY = ptr<const float>(op, 0, bases); a.X = ptr<const float>(op, 1, bases); a.DW = ptr<float>(op, 2, bases);
       a.DB = ptr<float>(op, 3, bases);
@@ -1405,15 +1452,27 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
 // member.  Only the leaf reductions the planner groups (hp::groupable) are dispatched here: a kernel carries the LDS of
 // EVERY body it can reach (a first version went through a switch over all small bodies and ran two workgroups per CU: 56-61 us
 // for what ten stand-alone launches do in 31 us).
+template <bool MFMA>
 __global__ __launch_bounds__(256) void small_group_kernel(const SmallEntry* __restrict__ entries, int n) {
+  // (MFMA: some member is a matrix-core weight gradient; the scalar-only instantiation — every group at batch 512 — does not carry its
+  // 16 KB of LDS and its registers)
+  __shared__ __attribute__((aligned(16))) float smem[MFMA ? kLinWgLds : 4];
   int b = blockIdx.x;
   for (int k = 0; k < n; ++k) {
     const SmallEntry& e = entries[k];
     const int nb = e.gx * e.gy * e.gz;
     if (b < nb) {
       const int bx = b % e.gx, by = (b / e.gx) % e.gy, bz = b / (e.gx * e.gy);
-      if (e.op == HP_OP_LINEAR_BWD_W) linear_bwd_w_body(e.a.lin, e.rows_per_z, bx, by, bz);
-      else if (e.op == HP_OP_EMB_BWD) emb_bwd_body(e.a.emb, bx);
+      if (e.op == HP_OP_LINEAR_BWD_W) {
+        if (MFMA && e.variant == 1) {
+          const LinWg w = e.a.wg;      // by value: one scalar load of the record up front
+          lin_wgrad_body(w, bx, by, smem);
+        } else {
+          linear_bwd_w_body(e.a.lin, e.rows_per_z, bx, by, bz);
+        }
+      } else if (e.op == HP_OP_EMB_BWD) {
+        emb_bwd_body(e.a.emb, bx);
+      }
       return;
     }
     b -= nb;
@@ -1541,6 +1600,14 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.X = ptr<const float>(op, 0, bases); a.W = ptr<const float>(op, 1, bases); a.Bv = ptr<const float>(op, 2, bases);
       a.Y = ptr<float>(op, 3, bases); a.stats = I[6] ? ptr<double>(op, 4, bases) : nullptr;
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldx = I[3]; a.ldy = I[4]; a.act = I[5]; a.slope = op.f[0];
+      if (a.M >= lin_mfma_min_rows()) {
+        LinMM g{};
+        g.A = a.X; g.lda = a.ldx; g.B = a.W; g.ldb = a.K; g.C = a.Y; g.ldc = a.ldy;
+        g.M = a.M; g.N = a.N; g.Kc = a.K; g.alA = lin_align(g.A, g.lda); g.alB = lin_align(g.B, g.ldb);
+        g.bias = a.Bv; g.stats = a.stats; g.act = a.act; g.slope = a.slope;
+        hipLaunchKernelGGL(lin_mm_kernel<false>, dim3(hp::cdiv(g.M, 64) * hp::cdiv(g.N, 64)), dim3(kLinMMThreads), 0, s, g);
+        break;
+      }
       if (a.K >= 128) hipLaunchKernelGGL(linear_fwd_wave_kernel, dim3(blocks_for((int64_t)a.M * a.N, 4)), dim3(256), 0, s, a);
       else hipLaunchKernelGGL(linear_fwd_thread_kernel, dim3(blocks_for((int64_t)a.M * a.N)), dim3(256), 0, s, a);
       break;
@@ -1551,6 +1618,15 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       a.ACT = ptr<const float>(op, 3, bases);
       a.M = I[0]; a.N = I[1]; a.K = I[2]; a.ldy = I[3]; a.ldx = I[4]; a.has_mask = I[5]; a.lda = I[6]; a.accumulate = I[7];
       a.slope = op.f[0];
+      if (a.M >= lin_mfma_min_rows()) {
+        // DX[m][k] = sum_n DY[m][n] * W[n][k]: output columns k, contraction over the layer's N, W read as its transpose
+        LinMM g{};
+        g.A = a.DY; g.lda = a.ldy; g.B = a.W; g.ldb = a.K; g.C = a.DX; g.ldc = a.ldx;
+        g.M = a.M; g.N = a.K; g.Kc = a.N; g.alA = lin_align(g.A, g.lda); g.alB = lin_align(g.B, g.ldb);
+        g.mask = a.has_mask ? a.ACT : nullptr; g.ldm = a.lda; g.accumulate = a.accumulate; g.slope = a.slope;
+        hipLaunchKernelGGL(lin_mm_kernel<true>, dim3(hp::cdiv(g.M, 64) * hp::cdiv(g.N, 64)), dim3(kLinMMThreads), 0, s, g);
+        break;
+      }
       if (a.N >= 128 && (int64_t)a.M * a.K <= (1 << 20))
         hipLaunchKernelGGL(linear_bwd_x_wave_kernel, dim3(blocks_for((int64_t)a.M * a.K, 4)), dim3(256), 0, s, a);
       else
@@ -1558,6 +1634,12 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       break;
     }
     case HP_OP_LINEAR_BWD_W: {
+      if (I[0] >= lin_mfma_min_rows()) {
+        const LinWg w = lin_wgrad_args(op, bases);
+        const int ntiles = hp::cdiv(w.N, 64) * hp::cdiv(w.K, 64);
+        hipLaunchKernelGGL(lin_wgrad_kernel, dim3(ntiles * hp::cdiv(w.M, w.rows_per_split)), dim3(256), 0, s, w, ntiles);
+        break;
+      }
       LinArgs a{};
       a.DY = ptr<const float>(op, 0, bases); a.X = ptr<const float>(op, 1, bases); a.DW = ptr<float>(op, 2, bases);
       a.DB = ptr<float>(op, 3, bases);
@@ -1699,12 +1781,15 @@ hipError_t hp::build_small_group(const HpOp* members, int count, void* const* ba
 
 hipError_t hp::launch_small_group(const HpOp* members, const void* d_entries, int count, hipStream_t s) {
   int blocks = 0;
+  bool mfma = false;
   void* const zero_bases[HP_NUM_SPACES] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   for (int j = 0; j < count; ++j) {
     SmallEntry e;
     if (!small_entry(members[j], zero_bases, e)) return hipErrorInvalidValue;      // (grid only: the device table holds the pointers)
     blocks += e.gx * e.gy * e.gz;
+    mfma = mfma || e.variant == 1;
   }
-  hipLaunchKernelGGL(small_group_kernel, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
+  if (mfma) hipLaunchKernelGGL(small_group_kernel<true>, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
+  else hipLaunchKernelGGL(small_group_kernel<false>, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
   return hipGetLastError();
 }

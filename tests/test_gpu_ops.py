@@ -495,6 +495,98 @@ def test_linear_family(M, N, K):
     check(gpu, cpu, db, N, rel=3e-5, what="linear db")
 
 
+# (M >= 1024: the three ops run on the matrix cores, csrc/linear_mfma.h.)  The widths are the heads' and the backbones' Linear layers at
+# BASELINE configs[2] (z = 32) and [4] (z = 64): 2z + 10 = 74 / 138, 4z + 10 = 266, z + 10 = 42 / 74, 512 <-> 2z, 64 -> output_size;
+# pads (+3, +2) give rows that are only 4-byte aligned, (+2, +2) 8-byte, (0, 0) the dense 16-byte case (widths permitting).
+@pytest.mark.parametrize("M,N,K,padx,pady", [
+    (4096, 64, 512, 0, 0), (4096, 512, 64, 0, 0), (8192, 128, 266, 0, 0), (8192, 128, 138, 3, 2), (4096, 64, 74, 2, 2),
+    (8192, 128, 128, 0, 0), (4096, 256, 64, 0, 0), (4096, 32, 64, 3, 2), (1100, 10, 10, 3, 2), (1027, 70, 33, 1, 1), (2048, 20, 15, 0, 0),
+])
+def test_linear_family_matrix_core_path(M, N, K, padx, pady):
+    img = Img(19)
+    ldx, ldy = K + padx, N + pady
+    x, w, bv = img.f32(M * ldx), img.f32(N * K, 0.2), img.f32(N)
+    y = img.f32(M * ldy, zero=True)
+    st = img.f64(R(N) * 2 * N)
+    dy = img.f32(M * ldy)
+    dx = img.f32(M * ldx, zero=True)
+    dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
+    dw1, db1 = img.f32(N * K, zero=True), img.f32(N, zero=True)
+    ol = P.OpList()
+    ol.add(P.LINEAR_FWD, 0, [M, N, K, ldx, ldy, 1, 1], [0.2], [x, w, bv, y, st])
+    ol.add(P.LINEAR_BWD_X, 0, [M, N, K, ldy, ldx, 1, ldx, 0], [0.2], [dy, w, dx, x])
+    ol.add(P.LINEAR_BWD_X, 0, [M, N, K, ldy, ldx, 0, 0, 1], [0.2], [dy, w, dx, None])
+    ol.add(P.LINEAR_BWD_W, 0, [M, N, K, ldy, ldx], (), [dy, x, dw, db])
+    ol.add(P.LINEAR_BWD_W, 1, [M, N, K, ldy, ldx], (), [dy, x, dw1, db1])          # flags & 1: one split per tile, no cross-workgroup atomics
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, y, M * ldy, rel=3e-5, what="linear y")
+    check_stats(gpu, cpu, st, N, what="linear stats")
+    check(gpu, cpu, dx, M * ldx, rel=3e-5, what="linear dx")
+    for a, b in ((dw, db), (dw1, db1)):
+        check(gpu, cpu, a, N * K, rel=3e-5, what="linear dw")
+        check(gpu, cpu, b, N, rel=3e-5, what="linear db")
+    # the padding columns of Y / DX (between N and ldy, K and ldx) belong to other tensors: untouched
+    Y = view(gpu, y, np.float32, M * ldy).reshape(M, ldy)
+    DX = view(gpu, dx, np.float32, M * ldx).reshape(M, ldx)
+    assert not Y[:, N:].any() and not DX[:, K:].any()
+
+
+def test_linear_matrix_core_path_on_column_windows_and_without_bias():
+    """encoder.linear's gradient arrives as a column window of the concatenated head input (planner: `dh = dc0 + 4 * (2z * k)`, leading
+    dimension 4z + 10), decoder_fc.0's input-gradient accumulates into one buffer for both towers; no bias / no statistics / no activation."""
+    M, N, K, ld = 2048, 128, 512, 266
+    img = Img(23)
+    cat = img.f32(M * ld)
+    win = Ref(P.WS, cat.offset + 4 * 128)                     # columns 128 .. 255 of [M][266]
+    x, w = img.f32(M * K), img.f32(N * K, 0.1)
+    y = img.f32(M * ld, zero=True)
+    ywin = Ref(P.WS, y.offset + 4 * 10)
+    dx = img.f32(M * K, zero=True)
+    dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
+    ol = P.OpList()
+    ol.add(P.LINEAR_FWD, 0, [M, N, K, K, ld, 0, 0], [0.2], [x, w, None, ywin, None])
+    ol.add(P.LINEAR_BWD_X, 0, [M, N, K, ld, K, 0, 0, 0], [0.2], [win, w, dx, None])
+    ol.add(P.LINEAR_BWD_W, 0, [M, N, K, ld, K], (), [win, x, dw, None])
+    gpu, cpu = run_both(img, ol.array())
+    check(gpu, cpu, y, M * ld, rel=3e-5, what="windowed y")
+    check(gpu, cpu, dx, M * K, rel=3e-5, what="dx from a window")
+    check(gpu, cpu, dw, N * K, rel=3e-5, what="dw from a window")
+    assert not view(gpu, db, np.float32, N).any()
+
+
+def test_small_leaf_group_with_matrix_core_members():
+    """The small-leaf group at a batch where its Linear members take the matrix-core body (M >= 1024), next to embedding gradients."""
+    Bn, H = 2048, 5
+    img = Img(67)
+    members, outs = [], {}
+    for j, (N, K) in enumerate([(128, 266), (64, 128), (128, 74), (256, 64), (128, 512)]):
+        dy, x = img.f32(Bn * N), img.f32(Bn * K)
+        dw, db = img.f32(N * K, zero=True), img.f32(N, zero=True)
+        members.append((P.LINEAR_BWD_W, 0, [Bn, N, K, N, K], (), [dy, x, dw, db]))
+        outs[f"dw{j}"], outs[f"db{j}"] = (dw, N * K), (db, N)
+    src = img.i64(img.rng.integers(0, 5, Bn))
+    dsemb = img.f32(5 * H, zero=True)
+    dcat = img.f32(Bn * 74)
+    members.append((P.EMB_BWD, 0, [Bn, H, 74, 64, 5], (), [dcat, src, dsemb]))
+    outs["dsemb"] = (dsemb, 5 * H)
+    single, group = P.OpList(), P.OpList()
+    n = len(members)
+    for j, (op, fl, i, f, buf) in enumerate(members):
+        single.add(op, fl, i, f, buf)
+        group.add(op, fl | (P.FLAG_MEMBER if j < n - 1 else ((n - 1) << P.FLAG_GROUP_SHIFT)), i, f, buf)
+    gpu_single, cpu = run_both(img, single.array())
+    image = img.image()
+    dev = torch.from_numpy(image.copy()).cuda()
+    prog = P.DeviceProgram(group.array(), [dev.data_ptr()] * 6, [image.size] + [4] * 5)
+    seg = prog.capture(0, n)
+    prog.replay(seg, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    gpu_group = dev.cpu().numpy()
+    for name, (ref, cnt) in outs.items():
+        check(gpu_group, cpu, ref, cnt, rel=3e-5, what="group vs interpreter: " + name)
+        check(gpu_single, cpu, ref, cnt, rel=3e-5, what="single vs interpreter: " + name)
+
+
 def test_concat_embedding_reparam_mse_loss():
     Bn, z, H = 37, 10, 5
     img = Img(10)
