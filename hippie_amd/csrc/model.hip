@@ -128,7 +128,7 @@ int model_load(const char* path, int flags, HpModel** out) {
     if (!read_exact(f, m->init_m.data(), h.arena_bytes[HP_SPACE_M]) || !read_exact(f, m->init_v.data(), h.arena_bytes[HP_SPACE_V]))
       return bail("short file (optimiser moments)");
   }
-  m->batches_tracked = h.config[13];
+  m->batches_tracked = (int64_t)((uint64_t)(uint32_t)h.config[13] | ((uint64_t)(uint32_t)h.config[14] << 32));
   fclose(f);
   f = nullptr;
   for (auto& s : m->segments) {
@@ -175,9 +175,12 @@ int model_save(HpModel* m, const char* path, int with_optimizer) {
   if (e != hipSuccess) return merr(std::string("hp_model_save: ") + hipGetErrorString(e));
   HpmHeader h = m->hdr;
   h.has_init = 3 | (with_optimizer ? 4 : 0);
-  h.config[13] = (int32_t)m->batches_tracked;
-  FILE* f = fopen(path, "wb");
-  if (!f) return merr(std::string("hp_model_save: cannot open ") + path);
+  h.config[13] = (int32_t)(uint32_t)(m->batches_tracked & 0xFFFFFFFFll);      // int64, as the reference's num_batches_tracked: low / high word
+  h.config[14] = (int32_t)(uint32_t)((uint64_t)m->batches_tracked >> 32);
+  // written beside the target and renamed over it: a failed or interrupted write never destroys the previous checkpoint
+  const std::string tmp = std::string(path) + ".tmp";
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return merr(std::string("hp_model_save: cannot open ") + tmp);
   bool ok = fwrite(&h, sizeof h, 1, f) == 1;
   ok = ok && fwrite(m->ops.data(), sizeof(HpOp), m->ops.size(), f) == m->ops.size();
   ok = ok && (m->segments.empty() || fwrite(m->segments.data(), sizeof(HpmSegment), m->segments.size(), f) == m->segments.size());
@@ -185,7 +188,8 @@ int model_save(HpModel* m, const char* path, int with_optimizer) {
     ok = m->tensors[w].empty() || fwrite(m->tensors[w].data(), sizeof(HpTensorInfo), m->tensors[w].size(), f) == m->tensors[w].size();
   for (int k = 0; k < (with_optimizer ? 4 : 2) && ok; ++k) ok = fwrite(host[k].data(), 1, host[k].size(), f) == host[k].size();
   ok = (fclose(f) == 0) && ok;
-  if (!ok) return merr(std::string("hp_model_save: write failed: ") + path);
+  if (!ok) { remove(tmp.c_str()); return merr(std::string("hp_model_save: write failed: ") + tmp); }
+  if (rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return merr(std::string("hp_model_save: cannot rename onto ") + path); }
   return 0;
 }
 }  // namespace

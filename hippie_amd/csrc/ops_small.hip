@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(256) void stage_batch_kernel(StageArgs p) {
   const long ne = (long)p.B * p.z;
   if (q * 4 < ne) {
     const uint64_t sd = (uint64_t)p.seed[0];
-    const uint4 v = philox4x32_10(make_uint4((uint32_t)cur, (uint32_t)(cur >> 32), (uint32_t)q, 0u), make_uint2((uint32_t)sd, (uint32_t)(sd >> 32)));
+    const uint4 v = philox4x32_10(make_uint4((uint32_t)cur, (uint32_t)(cur >> 32), (uint32_t)q, (uint32_t)p.rank), make_uint2((uint32_t)sd, (uint32_t)(sd >> 32)));
     const float r0 = sqrtf(-2.f * logf(u01(v.x))), r1 = sqrtf(-2.f * logf(u01(v.z)));
     float s0, c0, s1, c1;
     sincosf(6.28318530717958647692f * u01(v.y), &s0, &c0);

@@ -371,7 +371,12 @@ int hp_program_create(const HpOp* ops, int n_ops, void* const bases[HP_NUM_SPACE
 
 int hp_program_destroy(HpProgram* p) {
   if (!p) return 0;
-  (void)hipDeviceSynchronize();      // replays of these graphs (and kernels reading the group tables) may still be in flight on the caller's streams
+  // replays of these graphs (and kernels reading the group tables) may still be in flight on the caller's streams.  Only a program that
+  // has device state of its own waits: one that was only validated (null arenas: HP_MODEL_NO_DEVICE) or never captured / grouped anything
+  // must neither initialise the HIP runtime nor stall other programs' streams.
+  bool device = false;
+  for (int k = 0; k < HP_NUM_SPACES; ++k) device = device || p->bases[k] != nullptr;
+  if (device && (!p->segs.empty() || p->groups_ready || p->capture_stream)) (void)hipDeviceSynchronize();
   for (auto g : p->segs) if (g) hipGraphExecDestroy(g);
   for (auto g : p->graphs) if (g) hipGraphDestroy(g);
   free_groups(p->groups);

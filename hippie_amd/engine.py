@@ -34,6 +34,10 @@ class Engine:
         # pipeline (Trainer.fit, scripts) on a prescribed noise sequence — the pipeline parity test does.  Per engine
         # (the model containers hand their own `eps_source` down): nothing process-wide.
         self.eps_source = None
+        # torch.Generator on this device for the noise drawn here when nothing is handed in (None: torch's global device generator).
+        # Concurrent fits give every network a generator of its own: two threads drawing from the ONE global generator would consume
+        # its Philox offset in a scheduling-dependent order (trainer.fit_concurrently).
+        self.eps_generator = None
         self.plan = planner.lower(cfg, batch, self.train_cfg, with_class)
         self.ops = self.plan.ops.array()
         n = self.plan.n_param_floats
@@ -185,7 +189,7 @@ class Engine:
         if eps is None and self.eps_source is not None:
             eps = self.eps_source(self)
         if eps is None:
-            self.io("eps").normal_()          # torch.randn_like(std), hippie/model.py:48
+            self.io("eps").normal_(generator=self.eps_generator)          # torch.randn_like(std), hippie/model.py:48
         else:
             self.io("eps").copy_(eps, non_blocking=True)
 
@@ -324,7 +328,11 @@ class Engine:
         p = self.io("perm")
         if perm.numel() != p.numel():
             raise ValueError(f"the permutation must list all {p.numel()} resident units")
-        p.copy_(perm.to(torch.int64))
+        perm = perm.to(torch.int64)
+        lo, hi = (int(v) for v in torch.aminmax(perm))
+        if lo < 0 or hi >= p.numel():          # (the kernel would read row 0 for such an entry: never a fault, but never what was meant)
+            raise IndexError(f"permutation entries span [{lo}, {hi}] but there are {p.numel()} resident units")
+        p.copy_(perm)
 
     def train_step_staged(self, use_graph=True):
         """One optimisation step on the next batch of the resident tables: HP_OP_STAGE_BATCH (index gather + Philox eps) +

@@ -167,7 +167,7 @@ def checkpoint_from_file(path):
     sd = OrderedDict()
     for t in d["params"]:
         sd["model." + t["name"].decode()] = _param_tensor(t, d["param_values"])
-    tracked = int(d["config"][13])
+    tracked = (int(d["config"][13]) & 0xFFFFFFFF) | ((int(d["config"][14]) & 0xFFFFFFFF) << 32)          # int64: low / high word
     for t in d["bufs"]:
         k = t["name"].decode()
         o = int(t["offset_bytes"]) // 4

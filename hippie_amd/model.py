@@ -51,6 +51,7 @@ class _Net:
         # callable(engine) -> [B, z] reparameterisation noise for every forward of THIS network that is not handed one
         # (None: torch's device generator); handed down to the engines
         self.eps_source = None
+        self.eps_generator = None          # torch.Generator(device) for that noise (None: the global device generator); see Engine
         # data parallel (set by Trainer.fit for the duration of a fit): replicas per process group, gradient mean between
         # backward and optimizer.step (hippie_amd.parallel), optional sync-BatchNorm; and the MFMA operand precision
         self.dp_world, self.dp_group, self.sync_batchnorm = 1, None, False
@@ -63,6 +64,7 @@ class _Net:
         if eng is None:
             eng = Engine(self.cfg, key[0], self._train_cfg, with_class=key[1], device=self.device, share_params_from=self._root)
             eng.eps_source = self.eps_source
+            eng.eps_generator = self.eps_generator
             eng.sync_group = self.dp_group
             if self._root is None:
                 self._root = eng
@@ -95,6 +97,7 @@ class _Net:
         if keep is not None:
             eng = Engine(self.cfg, keep.B, train_cfg, with_class=keep.with_class, device=self.device, share_params_from=keep)
             eng.eps_source = self.eps_source
+            eng.eps_generator = self.eps_generator
             eng.sync_group = self.dp_group
             if reset_optimizer:
                 eng.reset_optimizer_state()
@@ -140,6 +143,12 @@ class _Net:
         self.eps_source = fn
         for eng in self._engines.values():
             eng.eps_source = fn
+
+    def set_eps_generator(self, gen):
+        """A torch.Generator (on this network's device) for the noise its forwards draw themselves; None = the global device generator."""
+        self.eps_generator = gen
+        for eng in self._engines.values():
+            eng.eps_generator = gen
 
     def _any_engine(self) -> Engine:
         if self._root is None:

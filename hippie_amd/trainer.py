@@ -88,6 +88,19 @@ class Trainer:
         dist.all_reduce(t, group=self.process_group)
         return float(t.item()) / self.world_size
 
+    def _check_deferred(self, module, device):
+        """Raise a pending out-of-range-label error — on EVERY rank when any rank saw one: a rank that raised alone would leave the
+        others waiting in the next collective."""
+        err = None
+        try:
+            module.model.check_deferred_errors()
+        except IndexError as ex:
+            err = ex
+        if self.world_size > 1 and self._reduce_mean(1.0 if err is not None else 0.0, device) > 0.0 and err is None:
+            err = IndexError("another data-parallel rank saw a source / class label out of range")
+        if err is not None:
+            raise err
+
     def _to_device(self, batch, device):
         return tuple(t.to(device, non_blocking=True) if torch.is_tensor(t) else t for t in batch)
 
@@ -106,7 +119,7 @@ class Trainer:
             loss = module.validation_step(self._to_device(batch, self._dev(module)), i)
             losses.append(loss.value)
         module.on_validation_epoch_end()
-        module.model.check_deferred_errors()
+        self._check_deferred(module, self._dev(module))
         module.train()
         val = float(torch.stack(losses).double().mean()) if losses else 0.0
         return self._reduce_mean(val, self._dev(module))
@@ -183,7 +196,7 @@ class Trainer:
                 n += batch[0].shape[0]
             torch.cuda.current_stream(dev).synchronize()      # this fit's stream only: a concurrent fit (fit_concurrently) keeps running
             dt = time.perf_counter() - t0
-            module.model.check_deferred_errors()
+            self._check_deferred(module, dev)
             module.on_train_epoch_end()
             rec = {"epoch": epoch, "train_samples_per_s": n * self.world_size / dt, "world_size": self.world_size}
             rec.update({k: float(v) for k, v in module.logged.items() if k.startswith("train")})
@@ -229,16 +242,22 @@ def _freeze(loader):
 
 
 def fit_concurrently(jobs):
-    """Run several independent fits at the same time, each on its own HIP stream, with the RANDOM DRAWS of the sequential
-    program.  jobs: [(trainer, module, train_loader, val_loader), ...] in the order a sequential script would fit them.
+    """Run several independent fits at the same time, each on its own HIP stream, with the BATCHES of the sequential program.
+    jobs: [(trainer, module, train_loader, val_loader), ...] in the order a sequential script would fit them.
 
     The reference trains the wave cVAE, then the time cVAE (scripts/train_model_with_multimodal.py:208,224): two independent
     models of ~165 small launches per step each, which together fill the GPU far better than one after the other (bench.py:
-    two streams 4.4 ms per pair-step, back to back 5.9 ms).  What couples the two fits in the reference is only torch's global
-    CPU generator: every DataLoader iterator draws a base seed, a shuffling one also its permutation seed, in program order
-    (sanity validation, then per epoch: train pass, validation pass; all of model 1 before model 2).  Here every pass of every
-    job is pre-drawn in exactly that order BEFORE the first step runs (_freeze), then each job's ordinary `Trainer.fit` runs
-    on a thread and stream of its own over its pre-drawn passes: same batches, same numbers, overlapped kernels.
+    two streams 4.4 ms per pair-step, back to back 5.9 ms).  What couples the two fits in the reference is torch's global
+    generators.  The CPU one: every DataLoader iterator draws a base seed, a shuffling one also its permutation seed, in program
+    order (sanity validation, then per epoch: train pass, validation pass; all of model 1 before model 2) — here every pass of
+    every job is pre-drawn in exactly that order BEFORE the first step runs (_freeze), then each job's ordinary `Trainer.fit`
+    runs on a thread and stream of its own over its pre-drawn passes: same batches as the sequential program.  The DEVICE one:
+    the reparameterisation noise (`torch.randn_like`, hippie/model.py:48).  Two threads drawing from the one global device
+    generator would consume it in a scheduling-dependent order, so every network without a prescribed noise source
+    (`set_eps_source`) gets a device generator of its own for the duration of the fit, seeded here — before the threads start, in
+    job order — from the global device generator: a seeded run (`torch.manual_seed`) is reproducible, and with prescribed noise
+    the numbers are the sequential program's (tests/test_gpu_pipeline.py); with self-drawn noise they are NOT the sequential
+    program's draws (that one stream of noise cannot be split over two concurrent consumers), only equally distributed.
 
     Exactness needs the number of passes to be known up front: early stopping cannot trigger when max_epochs <= patience (the
     scripts' defaults: 1 epoch, patience 30).  Otherwise, and for a single job, the fits simply run one after the other."""
@@ -284,6 +303,18 @@ def fit_concurrently(jobs):
     else:
         streams = [torch.cuda.Stream(device=dev) for _ in jobs]
 
+    # a noise generator per network that draws its own (see the docstring): seeds from the global device generator, in job order
+    own_gen = []
+    with torch.cuda.device(dev):
+        seeds = torch.randint(0, 2 ** 62, (len(jobs),), device=dev, dtype=torch.int64).tolist()
+    for (tr, mod, _, _), seed in zip(jobs, seeds):
+        net = mod.model
+        if getattr(net, "eps_source", None) is None and getattr(net, "eps_generator", None) is None and hasattr(net, "set_eps_generator"):
+            g = torch.Generator(device=dev)
+            g.manual_seed(int(seed))
+            net.set_eps_generator(g)
+            own_gen.append(net)
+
     def run(k):
         tr, mod, _, _ = jobs[k]
         try:
@@ -300,6 +331,8 @@ def fit_concurrently(jobs):
         t.join()
     for s_ in streams:
         main.wait_stream(s_)
+    for net in own_gen:
+        net.set_eps_generator(None)
     for ex in errors:
         if ex is not None:
             raise ex

@@ -14,8 +14,17 @@ def _side_streams(wave_model, time_model, wave, label_wave, time, label_time):
         from .streams import pick_concurrent_streams
         engs = [m.model.engine(int(x.shape[0]), lab.ndim == 2) for m, x, lab in ((wave_model, wave, label_wave), (time_model, time, label_time))]
         return pick_concurrent_streams(engs, wave.device)
-    except Exception:              # any surprise: the sequential path below is always correct
+    except Exception as ex:        # the sequential path below is always correct — but ~30 % slower (685 k -> 465 k units/s): say so, once
+        global _WARNED
+        if not _WARNED:
+            _WARNED = True
+            import warnings
+            warnings.warn(f"get_embeddings: could not pick two concurrent streams ({type(ex).__name__}: {ex}); the wave and the time "
+                          "encoder passes run one after the other", RuntimeWarning, stacklevel=3)
         return None
+
+
+_WARNED = False
 
 
 def get_embeddings(dataloader_wave, dataloader_time, wave_model, time_model):

@@ -298,7 +298,9 @@ enum {
    *   j = (CURSOR[0] mod i[4]) * i[5] + i[6]          batch number inside the epoch's permutation (i[5] = world, i[6] = rank:
    *                                                   the DistributedSampler-style interleave of data-parallel ranks)
    *   r = PERM[j*B + b];   X[b][:] = TABLE[r][:]  (and X2[b][:] = TABLE2[r][:]);   SRC[b] = LABELS[r]
-   *   EPS[b*z + k] = standard normal: Philox4x32-10(counter = (CURSOR lo, CURSOR hi, (b*z + k) / 4, 0), key = SEED lo, hi)
+   *   EPS[b*z + k] = standard normal: Philox4x32-10(counter = (CURSOR lo, CURSOR hi, (b*z + k) / 4, rank i[6]), key = SEED lo, hi)
+   *                  (the rank in the counter: data-parallel replicas loaded with one seed still draw independent noise, as the ranks'
+   *                  generators of torch DDP do)
    *                  -> 4 x u32 -> u = ((v >> 8) + 0.5) * 2^-24 -> Box-Muller pairs (sqrt(-2 ln u0) * cos / sin(2 pi u1))
    * The op does NOT advance CURSOR: an HP_OP_STEP_INC on it follows in the program.  A PERM entry outside [0, N) reads row 0.
    * i[0]=B i[1]=L i[2]=L2 (0 = no second table) i[3]=z i[4]=batches per epoch i[5]=world i[6]=rank i[7]=N (table rows)

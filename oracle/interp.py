@@ -31,12 +31,12 @@ def philox4x32_10(c0, c1, c2, c3, k0, k1):
     return [v.astype(np.uint32) for v in (c0, c1, c2, c3)]
 
 
-def philox_normal(seed, cursor, n):
-    """HP_OP_STAGE_BATCH's noise: n standard normals for (seed, cursor) (float32; Box-Muller on 24-bit uniforms)."""
+def philox_normal(seed, cursor, n, rank=0):
+    """HP_OP_STAGE_BATCH's noise: n standard normals for (seed, cursor, data-parallel rank) (float32; Box-Muller on 24-bit uniforms)."""
     nq = (n + 3) // 4
     q = np.arange(nq, dtype=np.uint64)
     seed, cursor = int(seed) & 0xFFFFFFFFFFFFFFFF, int(cursor) & 0xFFFFFFFFFFFFFFFF
-    v = philox4x32_10(np.full(nq, cursor & 0xFFFFFFFF), np.full(nq, cursor >> 32), q, np.zeros(nq), seed & 0xFFFFFFFF, seed >> 32)
+    v = philox4x32_10(np.full(nq, cursor & 0xFFFFFFFF), np.full(nq, cursor >> 32), q, np.full(nq, int(rank) & 0xFFFFFFFF), seed & 0xFFFFFFFF, seed >> 32)
     u = [((w >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(1.0 / 16777216.0) for w in v]
     r0, r1 = np.sqrt(np.float32(-2) * np.log(u[0])), np.sqrt(np.float32(-2) * np.log(u[2]))
     t0, t1 = np.float32(6.28318530717958647692) * u[1], np.float32(6.28318530717958647692) * u[3]
@@ -536,7 +536,7 @@ def run(ops, A: Arenas, first=0, count=None):
             if L2 > 0 and int(b[1]) != NULL:
                 A.f32(b[6], B * L2)[:] = A.f32(b[1], N * L2).reshape(N, L2)[rows].reshape(-1)
             A.i64(b[7], B)[:] = A.i64(b[2], N)[rows]
-            A.f32(b[8], B * z)[:] = philox_normal(int(A.i64(b[9], 1)[0]), cur, B * z)
+            A.f32(b[8], B * z)[:] = philox_normal(int(A.i64(b[9], 1)[0]), cur, B * z, rank)
         elif op in (29, 30):   # WGRAD_GROUP / PAIR: its member WGRAD_TAPS records (just before it) were executed in place
             pass
         else:

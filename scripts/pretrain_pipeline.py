@@ -33,6 +33,7 @@ import sys
 import numpy as np
 import pandas as pd
 import torch
+import torch.distributed as dist
 from torch.utils.data import random_split
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -196,6 +197,16 @@ class _ConcatJoint:
         return _L()
 
 
+def _write_csv_rank0(df, path):
+    """Under torchrun every rank walks the supervised stage (same split, same sampler stream; BatchNorm running statistics are rank-local
+    without --sync-batchnorm, so the ranks' embeddings differ in the last digits): rank 0's file is THE file — like the checkpoints and the
+    pretraining CSVs — and a barrier keeps any rank from reading it half-written."""
+    if not dist.is_initialized() or dist.get_rank() == 0:
+        df.to_csv(path)
+    if dist.is_initialized():
+        dist.barrier()
+
+
 def main_multimodal(args, eps_source, rank0):
     """The multimodal branch of the reference script (scripts/train_model_with_multimodal.py:618-790): ONE MultiModalCVAE over
     (waveform, isi) pairs — pretraining on the pool, label-free fine-tuning on the target at a tenth of the learning rate, joint
@@ -326,12 +337,12 @@ def supervised_stage_multimodal(args, num_sources, joint_path, trainer, eps_sour
     confusion_matrix(label_val, pred)
     out = {"joint_balanced_accuracy": acc}
     out["joint_knn"] = os.path.join(args.output_dir, f"{dataset}_joint_knn.csv")
-    pd.DataFrame({"pred": le.inverse_transform(pred.astype(int)), "true": le.inverse_transform(label_val.astype(int))}).to_csv(out["joint_knn"])
+    _write_csv_rank0(pd.DataFrame({"pred": le.inverse_transform(pred.astype(int)), "true": le.inverse_transform(label_val.astype(int))}), out["joint_knn"])
     e_all = get_embeddings_multimodal(table(list(range(n)), sup_labels).loader(range(n), 128, False), mod)
     df = pd.DataFrame(e_all)
     df["label"] = le.inverse_transform(sup_labels.astype(int))
     out["joint_supervised_embeddings"] = os.path.join(args.output_dir, f"{dataset}_joint_embeddings.csv")
-    df.to_csv(out["joint_supervised_embeddings"])
+    _write_csv_rank0(df, out["joint_supervised_embeddings"])
     return out
 
 
@@ -511,7 +522,7 @@ def supervised_stage(args, num_sources, wave_path, time_path, fit, eps_source=No
         pred = KNeighborsClassifier(n_neighbors=min(best_k, len(e_tr))).fit(e_tr, label_train).predict(e_va)
         confusion_matrix(label_val, pred)
         path = os.path.join(args.output_dir, f"{dataset}_{name}_knn.csv")
-        pd.DataFrame({"pred": le.inverse_transform(pred.astype(int)), "true": le.inverse_transform(label_val.astype(int))}).to_csv(path)
+        _write_csv_rank0(pd.DataFrame({"pred": le.inverse_transform(pred.astype(int)), "true": le.inverse_transform(label_val.astype(int))}), path)
         out[name + "_knn"] = path
         out[name + "_balanced_accuracy"] = acc
     all_wave, all_time = tables(list(range(n)), sup_labels)
@@ -520,7 +531,7 @@ def supervised_stage(args, num_sources, wave_path, time_path, fit, eps_source=No
         df = pd.DataFrame(e)
         df["label"] = le.inverse_transform(sup_labels.astype(int))
         path = os.path.join(args.output_dir, f"{dataset}_{name}_embeddings.csv")
-        df.to_csv(path)
+        _write_csv_rank0(df, path)
         out[name + "_supervised_embeddings"] = path
     return out
 

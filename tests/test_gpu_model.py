@@ -309,6 +309,33 @@ def test_trainer_async_path_equals_per_step_sync_path(tmp_path, deterministic):
             H.assert_adam_close(sd1[k].numpy(), sd0[k].numpy(), 1e-5, k, steps=6, frac=1.0)
 
 
+def test_concurrent_fits_with_self_drawn_noise_are_reproducible():
+    """fit_concurrently with NO prescribed noise source: the wave and the time fit run on two threads; each network draws its
+    reparameterisation noise from a device generator of its own, seeded before the threads start (two threads on the one global
+    device generator consumed it in a scheduling-dependent order).  Two seeded runs end with identical parameters (deterministic=True)."""
+    from hippie_amd.trainer import fit_concurrently
+    z = 10
+    res = []
+    for _ in range(2):
+        torch.manual_seed(321)
+        jobs, nets = [], []
+        for k, L in enumerate((50, 100)):
+            om = O.OracleModel("unimodal", z, L, salt=6 + k)
+            net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)
+            net.load_state_dict({kk: v.detach() for kk, v in om.state.items()})
+            mod = hippieUnimodalEmbeddingModelCVAE(net, learning_rate=1e-4, weight_decay=0.01)
+            tr = Trainer(max_epochs=2, gradient_clip_val=1.0, enable_checkpointing=False, deterministic=True)
+            jobs.append((tr, mod, batches(96, 32, L, z, seed=3 + k), batches(32, 32, L, z, seed=5 + k)))
+            nets.append(net)
+        fit_concurrently(jobs)
+        torch.cuda.synchronize()
+        assert all(n.eps_generator is None for n in nets)                       # handed back after the fit
+        res.append([{k: v.cpu() for k, v in n.state_dict().items()} for n in nets])
+    for sd0, sd1 in zip(*res):
+        for k in sd0:
+            assert torch.equal(sd0[k], sd1[k]), k
+
+
 def test_trainer_reports_bad_labels_at_epoch_end():
     z, L = 10, 50
     net = hippieUnimodalCVAE(z_dim=z, output_size=L, class_hidden_dim=5, num_sources=5, num_classes=5)

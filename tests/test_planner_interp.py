@@ -215,7 +215,7 @@ def test_sync_batchnorm_two_ranks_equal_the_global_batch_oracle(kind):
 def test_staged_step_gathers_the_batch_and_walks_the_permutation():
     """TrainCfg(resident_units=N): HP_OP_STAGE_BATCH + cursor increment in front of the training forward.  Through the
     interpreter: each staged step sees exactly the rows perm[j*B:(j+1)*B] (j = (cursor mod batches) * world + rank), labels
-    follow their rows, eps is the Philox stream of (seed, cursor), and "step_staged" is the contiguous range stage..opt."""
+    follow their rows, eps is the Philox stream of (seed, cursor, rank), and "step_staged" is the contiguous range stage..opt."""
     B, z, L, N = 4, 10, 50, 19
     plan = planner.lower(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(resident_units=N, dp_world=2, dp_rank=1))
     ops = plan.ops.array()
@@ -237,7 +237,8 @@ def test_staged_step_gathers_the_batch_and_walks_the_permutation():
         rows = perm[j * B: (j + 1) * B]
         np.testing.assert_array_equal(H.get_io(plan, A, "x").reshape(B, L), x.numpy().reshape(N, L)[rows])
         np.testing.assert_array_equal(H.get_io(plan, A, "src"), src.numpy()[rows])
-        np.testing.assert_array_equal(H.get_io(plan, A, "eps").reshape(-1), interp.philox_normal(77, step, B * z))
+        np.testing.assert_array_equal(H.get_io(plan, A, "eps").reshape(-1), interp.philox_normal(77, step, B * z, rank=1))
+        assert not np.array_equal(interp.philox_normal(77, step, B * z, rank=1), interp.philox_normal(77, step, B * z, rank=0))      # ranks draw independent noise
         assert int(H.get_io(plan, A, "cursor")[0]) == step + 1
     with pytest.raises(ValueError):
         planner.lower(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(resident_units=3))
