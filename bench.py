@@ -72,13 +72,17 @@ class Pair:
     113.8 k samples/s: nothing hides the launch floors on a single stream — and removed in round 3)"""
 
     def __init__(self, device, world, lr=1e-3, lens=(50, 100), lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True,
-                 model_type="unimodal", staged=True, rank=0):
+                 model_type="unimodal", staged=True, rank=0, bucketed=False):
         self.device, self.world, self.lockstep = device, world, lockstep
         # staged: the synthetic tables are RESIDENT in each engine's workspace and every step's batch gather + eps draw is the first
         # launch of the step's graph (HP_OP_STAGE_BATCH): one graph replay per model-step, no torch kernel inside the timed region.
         # False (--no-staged, A/B): torch index_select / copy_ / normal_ in front of every step, as in rounds 1-2.
         self.staged = staged
         res = dict(resident_units=N_UNITS, dp_world=world, dp_rank=rank) if staged else {}
+        # data parallel: the backward pass in two halves with the decoder-side gradient bucket all-reduced (communicator's stream) while the
+        # encoder-side half runs on the model's own stream (hippie_amd.parallel.backward_allreduce; SURVEY section 8(e))
+        self.bucketed = bucketed
+        res["bucketed_bwd"] = bucketed
         self.only = None          # --only-model: step one of the two models (how much of the pair step is overlap?)
         self.multimodal = model_type == "multimodal"
         if self.multimodal:
@@ -95,7 +99,7 @@ class Pair:
         self.stream_pair = {}
         self.stream_priority = True      # --no-stream-priority (A/B): both model streams at normal priority
         self.run_ahead = 2               # --run-ahead: how many steps the host may queue ahead of the GPU (0 = unbounded)
-        self.groups = None
+        self.groups, self.comm_streams, self.comm_report = None, None, None
         if world > 1 or os.environ.get("HIPPIE_FORCE_DIST"):
             self.use_world_group()
         self.init_params()
@@ -113,6 +117,24 @@ class Pair:
         finishes first anyway); each one overlaps the OTHER model's kernels, which run on their own stream."""
         import torch.distributed as dist
         self.groups = [dist.group.WORLD for _ in self.eng]
+        self.comm_streams = [None for _ in self.eng]
+        if self.bucketed:
+            # the two-bucket form: a communicator and a communication stream PER MODEL — the models' collectives never queue behind each
+            # other, and every side stream is probed not to share a hardware queue with a model stream (pick_comm_streams, after the
+            # model streams are chosen)
+            self.groups = [dist.new_group(list(range(dist.get_world_size()))) for _ in self.eng]
+            for g in self.groups:
+                dist.all_reduce(torch.zeros(1, device=self.device), group=g)
+
+    def pick_comm_streams(self):
+        from hippie_amd.streams import pick_side_stream
+        busy = list(self.streams)
+        self.comm_report = []
+        for k in range(len(self.eng)):
+            rep = {}
+            self.comm_streams[k] = pick_side_stream(busy, self.device, report=rep)
+            busy.append(self.comm_streams[k])
+            self.comm_report.append(rep)
 
     def load_tables(self, data, perm):
         """staged mode: the tables, the shuffle and a noise seed into every engine's workspace (once, before the timed region)"""
@@ -173,7 +195,7 @@ class Pair:
                         e.train_step(use_graph)          # one process: nothing sits between bwd and opt -> one graph per step
                         continue
                     e.forward(True, use_graph)
-                parallel.backward_allreduce(e, self.groups[k], use_graph)
+                parallel.backward_allreduce(e, self.groups[k], use_graph, comm_stream=self.comm_streams[k])
                 e.optimizer_step(use_graph)
         if self.lockstep:
             self.join()
@@ -549,6 +571,10 @@ def main():
                          "a NON-DEFAULT, separately labelled line")
     ap.add_argument("--no-staged", action="store_true", help="A/B: stage every batch with torch kernels (index_select / copy_ / normal_) instead of the "
                     "in-graph HP_OP_STAGE_BATCH over workspace-resident tables")
+    ap.add_argument("--bucketed-bwd", action="store_true",
+                    help="A/B (N > 1 and the 1-rank probe): the backward pass in two halves with the decoder-side gradient bucket all-reduced on a side "
+                         "stream under the encoder-side half, instead of one all-reduce of the whole arena after the pass (the default: measured "
+                         "faster at one rank on this runtime, DESIGN.md section 6)")
     ap.add_argument("--no-dp-probe", action="store_true", help="skip the 1-rank RCCL data-parallel overhead probe (N=1 only)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -590,7 +616,7 @@ def main():
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
     pair = Pair(device, world, lens=(args.wave_len, args.time_len), lockstep=args.lockstep,
                 fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type,
-                staged=not args.no_staged, rank=rank)
+                staged=not args.no_staged, rank=rank, bucketed=(world > 1 or force_dist) and args.bucketed_bwd)
     pair.only = args.only_model
     pair.stream_priority = not args.no_stream_priority
     pair.run_ahead = max(0, args.run_ahead)
@@ -609,6 +635,8 @@ def main():
         dist.all_reduce(torch.zeros(1, device=device))       # the communicator's own stream exists before the model streams are chosen
     if not args.no_pick_streams and pair.only is None:
         pair.pick_streams()
+    if pair.groups is not None and pair.bucketed:
+        pair.pick_comm_streams()
     stream_pair = dict(pair.stream_pair)
     pair.fork()
     pair.run(args.warmup, data, batch_idx, 0, use_graph)
@@ -646,26 +674,41 @@ def main():
         # What the data-parallel structure costs BEFORE any wire time: the same step with a 1-rank RCCL communicator in place —
         # three graphs per model-step instead of one, ncclAllReduce(AVG) of the gradient arena between bwd and opt on the
         # communicator's stream (a copy onto itself at one rank).  N > 1 adds only the transfer time on top of this.
+        main_pair = pair
         try:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
             os.environ["HIPPIE_FORCE_DIST"] = "1"
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+            if args.bucketed_bwd:
+                # the N > 1 lowering (TrainCfg.bucketed_bwd: two backward halves, two gradient buckets) in engines of its own
+                pair = Pair(device, 1, lens=(args.wave_len, args.time_len), lockstep=args.lockstep, fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype,
+                            reuse_ws=not args.no_reuse_ws, model_type=args.model_type, staged=not args.no_staged, rank=0, bucketed=True)
+                pair.stream_priority, pair.run_ahead = main_pair.stream_priority, main_pair.run_ahead
+                if pair.staged:
+                    pair.load_tables(data, perm)
             pair.use_world_group()
             dist.all_reduce(torch.zeros(1, device=device))
             if not args.no_pick_streams:
                 pair.pick_streams()
+            if pair.bucketed:
+                pair.pick_comm_streams()
             timed(args.warmup)
             dt_dp = timed(args.steps)
             dp_probe = {"ms_per_step": dt_dp / args.steps * 1e3, "value": BATCH * args.steps / dt_dp, "ratio_to_value": dt / dt_dp,
-                        "how": "same step with a 1-rank RCCL (nccl) all-reduce of each model's gradient arena between bwd and opt (3 graph "
-                               "replays per model-step); N > 1 adds the xGMI transfer on the communicator's stream, overlapped with the other model"}
+                        "bucketed_bwd": bool(pair.bucketed), "comm_streams": pair.comm_report,
+                        "how": "the N > 1 step at one rank: stage+forward | bwd_dec | async RCCL all-reduce of the decoder-side gradient bucket on the "
+                               "communicator's stream | bwd_enc on the model's own stream | all-reduce of the encoder-side bucket | wait | opt "
+                               "(4 graph replays per model-step); N > 1 adds the xGMI transfer time of the two buckets, the first under bwd_enc"
+                               if pair.bucketed else
+                               "same step with a 1-rank RCCL (nccl) all-reduce of each model's gradient arena between bwd and opt (3 graph replays per model-step)"}
             dist.destroy_process_group()
         except Exception as ex:                 # never lose the line over a secondary figure
             dp_probe = {"error": repr(ex)[:200]}
         finally:
             os.environ.pop("HIPPIE_FORCE_DIST", None)
+            pair = main_pair              # (the probe's own engines are dropped)
             pair.groups = None
 
     METRIC = "pretrain samples/sec (waveform+time cVAE, batch 512) at 1/2/4/8 MI355X"

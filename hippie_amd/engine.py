@@ -340,6 +340,9 @@ class Engine:
         (the caller all-reduces between `backward` and `optimizer_step` itself: see staged_forward)."""
         if "stage" not in self.plan.ops.segments:
             raise HipEngineError("train_step_staged needs TrainCfg(resident_units=N)")
+        if self.train_cfg.dp_world > 1:          # a replica that skipped the gradient all-reduce would silently diverge from the others
+            raise HipEngineError(f"this engine was lowered for {self.train_cfg.dp_world} data-parallel ranks: use staged_forward(), "
+                                 "parallel.backward_allreduce(engine, group), optimizer_step()")
         if use_graph and "step_staged" in self.plan.ops.segments and self.train_cfg.sync_bn_world <= 1:
             self.run("step_staged", True)
         else:

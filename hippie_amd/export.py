@@ -210,6 +210,8 @@ def main(argv=None):
                     "'stage' / 'step_staged' segments (hp_model_train_step_staged: loader + step as one graph)")
     ap.add_argument("--dp-world", type=int, default=1)
     ap.add_argument("--dp-rank", type=int, default=0)
+    ap.add_argument("--bucketed-bwd", action="store_true", help="data parallel: the backward pass as two segments (bwd_dec | bwd_enc) so that "
+                    "hp_model_train_step_dp reduces the decoder-side gradient bucket while the encoder-side half runs")
     ap.add_argument("--seed", type=int, default=None, help="also store the reference constructor's random initialisation under this torch seed")
     ap.add_argument("--from-ckpt", default=None, metavar="FILE.ckpt",
                     help="initial parameters / BatchNorm buffers from a reference-format checkpoint (torch.save'd {'state_dict': {'model.<key>': tensor}}, "
@@ -228,7 +230,7 @@ def main(argv=None):
         ap.error("-o / --output is required")
     cfg = planner.ModelCfg(a.kind, a.z_dim, a.output_size, a.output_size2, 5, a.num_sources, a.num_classes)
     plan = planner.lower(cfg, a.batch, planner.TrainCfg(lr=a.lr, weight_decay=a.weight_decay, beta=a.beta, clip=a.clip, resident_units=a.resident_units,
-                                                        dp_world=a.dp_world, dp_rank=a.dp_rank), with_class=a.with_class)
+                                                        dp_world=a.dp_world, dp_rank=a.dp_rank, bucketed_bwd=a.bucketed_bwd), with_class=a.with_class)
     pv = bv = None
     if a.from_ckpt:
         import torch

@@ -55,6 +55,11 @@ class _Net:
         # data parallel (set by Trainer.fit for the duration of a fit): replicas per process group, gradient mean between
         # backward and optimizer.step (hippie_amd.parallel), optional sync-BatchNorm; and the MFMA operand precision
         self.dp_world, self.dp_group, self.sync_batchnorm = 1, None, False
+        # True: under DDP the backward pass runs as two halves with the decoder-side gradient bucket all-reduced on a side stream under the
+        # encoder-side half (TrainCfg.bucketed_bwd).  Off by default: on this runtime the cross-stream event dependencies between the
+        # graph launches cost more than the transfer they hide (1-rank ratio 0.78 / 0.95 / 0.97 against 0.98 / 0.98 / 1.00 for one
+        # collective after the pass — wave + time pair / multimodal at batch 512 / at batch 8192)
+        self.ddp_bucketed = False
         self.precision = "f32"
 
     # -- engine cache -----------------------------------------------------------------
@@ -88,7 +93,7 @@ class _Net:
         if (self.deterministic or torch.are_deterministic_algorithms_enabled()) and not train_cfg.deterministic_wgrad:
             train_cfg = replace(train_cfg, deterministic_wgrad=True)
         # network-level settings survive every re-lowering of the optimiser constants
-        train_cfg = replace(train_cfg, mfma_dtype=self.precision,
+        train_cfg = replace(train_cfg, mfma_dtype=self.precision, bucketed_bwd=bool(self.ddp_bucketed) and self.dp_world > 1,
                             sync_bn_world=self.dp_world if (self.sync_batchnorm and self.dp_world > 1) else 0)
         self._train_cfg = train_cfg
         keep = self._root
@@ -121,7 +126,8 @@ class _Net:
         sync-BatchNorm markers (torch.nn.SyncBatchNorm semantics, Lightning's sync_batchnorm=True)."""
         world = int(world)
         changed = (bool(sync_batchnorm) and world > 1) != (self._train_cfg.sync_bn_world > 1) or \
-                  (bool(sync_batchnorm) and world > 1 and self._train_cfg.sync_bn_world != world)
+                  (bool(sync_batchnorm) and world > 1 and self._train_cfg.sync_bn_world != world) or \
+                  (bool(self.ddp_bucketed) and world > 1) != bool(self._train_cfg.bucketed_bwd)
         self.dp_world, self.dp_group, self.sync_batchnorm = world, group, bool(sync_batchnorm)
         if changed:
             self.configure_training(self._train_cfg)
@@ -453,12 +459,14 @@ class _Loss:
 
     def backward(self):
         if not self._backward_done:
-            self.eng.backward(self.use_graph)
             if self.dp_world > 1:
                 # DDP: gradient MEAN over the replicas between backward and optimizer.step (Lightning's default strategy on a
-                # multi-GPU host, scripts/train_model_with_multimodal.py:200-207); RCCL over xGMI when the backend is "nccl"
+                # multi-GPU host, scripts/train_model_with_multimodal.py:200-207); RCCL over xGMI when the backend is "nccl".  (With
+                # net.ddp_bucketed the plan holds two backward halves and the decoder-side bucket is reduced under the encoder-side one.)
                 from . import parallel
-                parallel.allreduce_mean_(self.eng.grads[: self.eng.plan.n_active], self.dp_group)
+                parallel.backward_allreduce(self.eng, self.dp_group, self.use_graph)
+            else:
+                self.eng.backward(self.use_graph)
             self._backward_done = True
 
 

@@ -61,16 +61,59 @@ def broadcast_(tensors, src=0, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
-def backward_allreduce(engine, group=None, use_graph=True):
-    """Backward + gradient mean over ranks: the whole active arena in one collective after the backward pass, on the
-    communicator's stream.  What overlaps it is the OTHER model: the wave and the time cVAE step on two HIP streams, so one
-    model's all-reduce runs under the other's kernels (north_star: "overlapped with the backward encoder GEMM").  Round 2
-    also had a two-bucket form that reduced the decoder-side half of ONE model's gradients on a side stream under that model's
-    encoder-side chain; the side stream's grid-filling weight-gradient launch stalls every small kernel of the chain behind
-    its workgroups (linear_bwd_x 6 -> 32 us, profiles/r03_overlap_timeline.txt): 90.7 k vs 115.7 k samples/s.  Removed."""
+def backward_allreduce(engine, group=None, use_graph=True, comm_stream=None):
+    """Backward + gradient mean over ranks.
+
+    Plans lowered with TrainCfg(bucketed_bwd=True) (what Trainer's DDP strategy, bench.py --gpus N and the pipeline under torchrun
+    use): the pass runs as its two halves.  After "bwd_dec" the decoder-side gradient range is complete and its all-reduce is issued
+    on `comm_stream` while "bwd_enc" (heads, encoder input-gradients, the encoder's weight-gradient group) runs on the model's OWN
+    stream; the second bucket follows it, and the model's stream waits for both before the optimiser.  SURVEY section 8(e): "bucket A
+    = decoder + heads, reduced while the encoder backward GEMMs run".  All compute stays on one stream: round 2's form moved the
+    decoder-side weight-gradient group to a side stream, whose grid-filling launch stalled every small kernel of the main chain
+    behind its workgroups (profiles/r03_overlap_timeline.txt, 90.7 k vs 115.7 k samples/s).
+
+    comm_stream: the stream the collectives run on (torch issues a synchronous collective on the CURRENT stream).  None: a side stream
+    probed not to share a hardware queue with the model's stream (streams.pick_side_stream, cached) — on a shared queue the side
+    stream's event waits are barriers in front of the model's own kernels (8.3 instead of 4.3 ms per pair-step at one rank).  Callers
+    that step several models side by side pass one comm stream (and one process group) per model: bench.py.
+
+    Other plans (and sync-BatchNorm runs, which are collective-bound anyway): the whole active arena in one collective after the pass,
+    on the model's stream."""
     e = engine
-    e.backward(use_graph)
-    allreduce_mean_(e.grads[: e.plan.n_active], group)
+    buckets = getattr(e.plan, "grad_buckets", None)
+    forced = bool(os.environ.get("HIPPIE_FORCE_DIST"))     # (the env knob keeps the 1-rank collective for measurements)
+    if buckets is None or (dist.get_world_size(group) == 1 and not forced) or e.train_cfg.sync_bn_world > 1:
+        e.backward(use_graph)
+        allreduce_mean_(e.grads[: e.plan.n_active], group)
+        return
+    if not e.grads.is_cuda:                # (CPU arenas: the numpy interpreter under gloo, tests/test_parallel_gloo.py — same halves, same buckets)
+        for seg, ranges in zip(("bwd_dec", "bwd_enc"), buckets):
+            e.run(seg, use_graph)
+            for lo, hi in ranges:
+                allreduce_mean_(e.grads[lo:hi], group)
+        return
+    cur = torch.cuda.current_stream(e.grads.device)
+    from .program import debug_knob
+    variant = debug_knob("HIPPIE_DP_VARIANT", "")          # (measurement only: which part of the two-bucket form costs what)
+    if variant == "whole":                                  # the split program, one collective after both halves
+        e.run("bwd_dec", use_graph), e.run("bwd_enc", use_graph)
+        allreduce_mean_(e.grads[: e.plan.n_active], group)
+        return
+    if comm_stream is None:
+        from .streams import pick_side_stream
+        comm_stream = pick_side_stream([cur], e.grads.device)
+    if variant == "samestream":
+        comm_stream = cur
+    for seg, ranges in zip(("bwd_dec", "bwd_enc"), buckets):
+        e.run(seg, use_graph)
+        if comm_stream is not cur:
+            comm_stream.wait_stream(cur)
+        with torch.cuda.stream(comm_stream):
+            for lo, hi in ranges:
+                if variant != "nocoll":
+                    allreduce_mean_(e.grads[lo:hi], group)
+    if comm_stream is not cur:
+        cur.wait_stream(comm_stream)
 
 
 class DataParallelEngine:

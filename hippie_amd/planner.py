@@ -90,6 +90,11 @@ class TrainCfg:
                                         # "stage" segment (HP_OP_STAGE_BATCH + cursor increment) gathers each step's batch by index from a
                                         # resident permutation and draws eps with Philox — "step_staged" = stage + fwd_train + bwd + opt is
                                         # then ONE graph per optimisation step with no host work in it (Engine.load_dataset / train_step_staged)
+    bucketed_bwd: bool = False          # data parallel: the backward segment in two halves, "bwd_dec" (decoders + decoder-side heads, incl.
+                                        # THEIR weight-gradient group) and "bwd_enc" (the rest); Plan.grad_buckets lists, per half, the ranges of
+                                        # the gradient arena that are complete when it ends, so that the all-reduce of the decoder-side bucket
+                                        # runs on the communicator's stream under the encoder-side kernels — which stay on the model's ONE
+                                        # stream (hippie_amd.parallel.backward_allreduce).  "bwd" still names the whole pass.
     dp_world: int = 1                   # data-parallel interleave of the staged batches: rank r of `dp_world` takes batch j*world + r
     dp_rank: int = 0
     optimizer: str = "adamw"            # "adamw" (model.py:93) | "schedulefree" (hippie/optimizers.py:18-209)
@@ -149,6 +154,7 @@ class Plan:
         self.act_sites = []                  # leaky-ReLU sites of the training forward (tests read the branches taken back)
         self.slab_need = 0                   # floats
         self.flops_fwd = 0                   # 2*MAC of conv + linear, forward
+        self.grad_buckets = None             # TrainCfg.bucketed_bwd: [[(lo, hi) floats, ...] of "bwd_dec", [...] of "bwd_enc"]
 
     # ---- arenas -------------------------------------------------------------
     def param(self, key, shape, layout="plain", align=4):
@@ -1134,6 +1140,12 @@ class Lowering:
                 marks.append(len(self.o.recs))
             if multi:
                 self.zip_towers(marks[0], marks[1])
+            bwd_split = None
+            if self.train.bucketed_bwd:
+                # everything decoder-side is done: its weight-gradient group and leaf group run HERE, so that the gradient range
+                # [decoder_fc*.0.weight, class_embedding) is complete at the end of "bwd_dec"
+                self.flush_wgrads()
+                bwd_split = len(self.o.recs)
             self.emb_bwd(dc1, ncat1, z)
             dmulv = pl.f32(B * 2 * z)
             self.o.add(P.REPARAM_KL_BWD, 0, i=[B, z, ncat1], f=[self.train.beta], buf=[mulv, eps, dc1, dmulv], note="reparameterize + KL bwd")
@@ -1161,6 +1173,16 @@ class Lowering:
                 self.zip_towers(marks[0], marks[1])
             self.flush_wgrads()
             self.o.end()
+            if bwd_split is not None:
+                b0_, bc_ = self.o.segments["bwd"]
+                self.o.segments["bwd_dec"] = (b0_, bwd_split - b0_)
+                self.o.segments["bwd_enc"] = (bwd_split, b0_ + bc_ - bwd_split)
+                dec_off, cemb_off = dfc[0]["f0"]["w"].offset, self.cemb.offset
+                assert all(q.offset >= dec_off for q in pl.params.values() if q.key.startswith("decoder")) and \
+                    all(q.offset < dec_off or q.offset >= cemb_off for q in pl.params.values() if not q.key.startswith("decoder"))
+                # (float ranges of the gradient arena, per half; the class-embedding table — last in the arena, fed by both halves'
+                #  concatenations — belongs to the second)
+                pl.grad_buckets = [[(dec_off, cemb_off)], [(0, dec_off)] + ([(cemb_off, pl.n_active)] if pl.n_active > cemb_off else [])]
 
             # ---------------- optimiser ----------------
             self.o.begin("opt")

@@ -130,7 +130,7 @@ class OpList:
 
 # ---- shared library ---------------------------------------------------------------
 _LIB = None
-ABI_VERSION = 5          # include/hippie_hip.h: HP_ABI_VERSION
+ABI_VERSION = 6          # include/hippie_hip.h: HP_ABI_VERSION
 
 
 def debug_knob(name, default=None):
@@ -151,8 +151,9 @@ EXPORTS = ("hp_model_save", "hp_abi_version", "hp_last_error", "hp_device_info",
            "hp_model_load", "hp_model_destroy", "hp_model_config", "hp_model_tensor_count", "hp_model_tensor_info", "hp_model_find",
            "hp_model_arena", "hp_model_program", "hp_model_segment", "hp_model_run", "hp_model_forward", "hp_model_backward",
            "hp_model_optimizer_step", "hp_model_train_step", "hp_model_train_step_staged", "hp_model_set_optimizer", "hp_model_batches_tracked", "hp_model_write", "hp_model_read",
-           "hp_model_synchronize", "hp_stream_create", "hp_stream_destroy", "hp_pick_concurrent_streams",
-           "hp_event_create", "hp_event_record", "hp_event_synchronize", "hp_event_destroy")
+           "hp_model_synchronize", "hp_stream_create", "hp_stream_destroy", "hp_pick_concurrent_streams", "hp_pick_side_stream",
+           "hp_event_create", "hp_event_record", "hp_event_synchronize", "hp_event_destroy",
+           "hp_dp_unique_id", "hp_model_allreduce_init", "hp_model_allreduce_destroy", "hp_model_train_step_dp")
 
 
 class HipEngineError(RuntimeError):
@@ -201,8 +202,12 @@ def load_library():
     lib.hp_model_segment.argtypes = [vp, cp, ip, ip]
     lib.hp_model_run.argtypes = [vp, cp, ctypes.c_int, vp]
     lib.hp_model_forward.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp]
-    for fn in (lib.hp_model_backward, lib.hp_model_optimizer_step, lib.hp_model_train_step, lib.hp_model_train_step_staged):
+    for fn in (lib.hp_model_backward, lib.hp_model_optimizer_step, lib.hp_model_train_step, lib.hp_model_train_step_staged, lib.hp_model_train_step_dp):
         fn.argtypes = [vp, ctypes.c_int, vp]
+    lib.hp_pick_side_stream.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_float)]
+    lib.hp_dp_unique_id.argtypes = [vp]
+    lib.hp_model_allreduce_init.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
+    lib.hp_model_allreduce_destroy.argtypes = [vp]
     lib.hp_model_set_optimizer.argtypes = [vp, ctypes.c_float, ctypes.c_float, ctypes.c_int]
     lib.hp_model_batches_tracked.argtypes = [vp]
     lib.hp_model_batches_tracked.restype = i64

@@ -284,7 +284,7 @@ def fit_concurrently(jobs):
         tr.prepare(mod)
         if not mod.model.use_graph:
             continue
-        for passes, segs in ((trains, ("fwd_train", "bwd", "opt")), (vals, ("fwd_eval",))):
+        for passes, segs in ((trains, ("fwd_train", "bwd", "bwd_dec", "bwd_enc", "opt")), (vals, ("fwd_eval",))):
             shapes = set()
             for batch in (passes.passes[0] if passes is not None and passes.passes else ()):
                 shapes.add((int(batch[0].shape[0]), batch[-1].ndim == 2))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 5
+#define HP_ABI_VERSION 6
 
 enum {
   HP_SPACE_WS = 0, HP_SPACE_PARAM = 1, HP_SPACE_GRAD = 2, HP_SPACE_BUF = 3,
@@ -399,8 +399,34 @@ int hp_model_train_step(HpModel* m, int use_graph, void* stream);
  * epoch's shuffle: batch j is perm[j*B .. (j+1)*B)), "seed" int64[1]; "cursor" int64[1] counts the steps taken (write 0 to restart;
  * it wraps over N / (B * world) batches).  config[10..12] of hp_model_config = N, data-parallel world, rank.  Replaces
  * DataLoader(..., batch_size, shuffle=True) + training_step + backward + optimizer.step (scripts/train_model_with_multimodal.py:155-166,
- * 200-224).  Under data parallelism use hp_model_run("stage" | "fwd_train" | "bwd"), the host's all-reduce, then "opt". */
+ * 200-224).  A model exported for more than one data-parallel rank is REFUSED here (a replica that skipped the gradient all-reduce would
+ * silently diverge): use hp_model_train_step_dp, or hp_model_run("stage" | "fwd_train" | "bwd"), the host's all-reduce, then "opt". */
 int hp_model_train_step_staged(HpModel* m, int use_graph, void* stream);
+/* ---- data parallelism for a host without Python (the "allreduce_init(ncclUniqueId, rank, world) / bucket hooks" entry) ----
+ * One process per GPU, replicated parameters, per-rank batches, gradients mean-all-reduced between backward and optimizer.step: what
+ * Lightning's default DDP strategy does to the reference's scripts on a multi-GPU host (scripts/train_model_with_multimodal.py:200-207,
+ * 694-703).  RCCL is bound at run time (dlopen of librccl.so; HIPPIE_RCCL_LIB overrides the name): nothing to link, nothing loaded
+ * on a single-GPU host.
+ *   hp_dp_unique_id            rank 0 draws the 128-byte ncclUniqueId and hands it to the other ranks by whatever channel the host has
+ *                              (file, socket, MPI); one id PER MODEL — a model owns its communicator and the stream its collectives
+ *                              run on, so two models of one process (waveform + timing) never serialise behind each other's all-reduce
+ *   hp_model_allreduce_init    collective over all ranks: ncclCommInitRank.  A model with resident tables must have been exported for
+ *                              this (world, rank): `python -m hippie_amd.export ... --resident-units N --dp-world W --dp-rank R`
+ *   hp_model_train_step_dp     one optimisation step of this replica: [stage +] forward, backward, gradient MEAN over the ranks, AdamW.
+ *                              Models exported with `--bucketed-bwd` hold the backward pass as two segments, "bwd_dec" (decoders +
+ *                              decoder-side heads and THEIR weight gradients) and "bwd_enc": the all-reduce of the decoder-side gradient
+ *                              range [first decoder* parameter, class_embedding) is issued on the communicator's stream as soon as
+ *                              "bwd_dec" is queued and runs under "bwd_enc", which stays on the caller's stream; the second bucket
+ *                              follows; the caller's stream waits for both (events, no host sync) before "opt".  The communicator's
+ *                              stream is picked at the first call (hp_pick_side_stream against `stream`): step a model on ONE stream.  Other models: one
+ *                              all-reduce of the whole active arena after "bwd".  Asynchronous like every other verb.
+ * At world == 1 everything runs (RCCL copies the bucket onto itself): the structure can be timed and tested on one GPU. */
+#define HP_DP_UNIQUE_ID_BYTES 128
+int hp_dp_unique_id(void* out128);
+int hp_model_allreduce_init(HpModel* m, const void* unique_id, int rank, int world);
+int hp_model_allreduce_destroy(HpModel* m);      /* also done by hp_model_destroy */
+int hp_model_train_step_dp(HpModel* m, int use_graph, void* stream);
+
 /* New optimiser constants for the next stage without re-exporting: every HP_OP_ADAMW record gets lr and weight_decay, the executor and
  * the captured graphs are rebuilt.  reset_state != 0 also zeroes both moment arenas and the step counter — what the reference does when it
  * wraps the pretrained network in a NEW train module for fine-tuning at a tenth of the learning rate
@@ -429,6 +455,13 @@ int hp_model_synchronize(HpModel* m, void* stream);
 int hp_stream_create(void** out);
 int hp_stream_destroy(void* stream);
 int hp_pick_concurrent_streams(HpModel* a, HpModel* b, int candidates, float accept, void** stream_a, void** stream_b, float report[3]);
+/* A stream for work that must run BESIDE the `busy` streams (n_busy of them; the gradient all-reduce beside a model's backward pass): the
+ * runtime multiplexes streams onto a few hardware queues, and a side stream that shares its queue with a model stream turns each of its
+ * event waits into a barrier in front of the model's own kernels.  Creates up to `candidates` (1..32) streams and probes each against every
+ * busy stream — a 2 ms single-wave spin kernel on the candidate, a timed empty kernel on the busy stream: on one queue the empty kernel
+ * waits its turn — and returns the first that delays none of them (else the least bad); the others are destroyed.  The busy streams must be
+ * idle.  The stream belongs to the caller (hp_stream_destroy).  report (may be NULL): worst delay of the chosen one (us), candidates tried. */
+int hp_pick_side_stream(void* const* busy, int n_busy, int candidates, void** out, float report[2]);
 /* Events (hipEvent_t as void*, timing disabled): record on a stream after step i, synchronize on the event of step i - 2 before queueing step
  * i — a host that stays two steps ahead of the GPU instead of queueing a whole epoch is ~1 % faster. */
 int hp_event_create(void** out);

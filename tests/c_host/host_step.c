@@ -2,7 +2,10 @@
  * raw binary file and takes optimisation steps through the reference's verbs — forward / backward / optimizer step
  * (hippie/model.py:95-116 under Lightning's automatic optimisation) — using nothing but include/hippie_hip.h.
  *
- *   host_step model.hpm inputs.bin n_steps use_graph
+ *   host_step model.hpm inputs.bin n_steps use_graph [dp]
+ *
+ * dp: data-parallel form at world size 1 — hp_dp_unique_id, hp_model_allreduce_init (RCCL bound at run time) and every step through
+ * hp_model_train_step_dp (Lightning's DDP strategy around the same training_step, scripts/train_model_with_multimodal.py:200-207).
  *
  * inputs.bin: x float32[B*L] | src int64[B] | eps float32[B*z]  (multimodal: x | x2 | src | eps).
  * Prints one line per step:  step k loss mse1 mse2 kl   and finally checksums of `enc_train` and of the parameter arena.
@@ -44,6 +47,7 @@ int main(int argc, char** argv) {
     return 2;
   }
   const int n_steps = atoi(argv[3]), use_graph = atoi(argv[4]);
+  const int dp = argc > 5 && strcmp(argv[5], "dp") == 0;
   HpModel* m = NULL;
   CHECK(hp_model_load(argv[1], 0, &m));
   int32_t cfg[16];
@@ -59,9 +63,18 @@ int main(int argc, char** argv) {
   CHECK(feed(m, "eps", f));
   fclose(f);
 
+  if (dp) {
+    /* a real launcher hands rank 0's id to the other ranks (file, socket, MPI); here the world is this one process */
+    char id[HP_DP_UNIQUE_ID_BYTES];
+    CHECK(hp_dp_unique_id(id));
+    CHECK(hp_model_allreduce_init(m, id, 0, 1));
+    printf("data parallel: rank 0 of 1\n");
+  }
   for (int k = 0; k < n_steps; ++k) {
     /* the three verbs separately on even steps, the one-graph step on odd ones: both routes are exercised */
-    if (k % 2 == 0) {
+    if (dp) {
+      CHECK(hp_model_train_step_dp(m, use_graph, NULL));
+    } else if (k % 2 == 0) {
       CHECK(hp_model_forward(m, 1, use_graph, NULL));
       CHECK(hp_model_backward(m, use_graph, NULL));
       CHECK(hp_model_optimizer_step(m, use_graph, NULL));

@@ -321,10 +321,11 @@ def _rccl_worker(port, q):
     from oracle import cvae_oracle as O
     z, B, steps = 10, 32, 3
     out = {}
-    for name, use_dp in (("plain", False), ("rccl", True)):
+    for name, use_dp, bucketed in (("plain", False, False), ("rccl", True, False), ("rccl_bucketed", True, True)):
         engs, streams = [], []
         for k, (L, clip) in enumerate(((50, 0.0), (100, 1.0))):
-            e = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=clip, deterministic_wgrad=True))
+            e = Engine(planner.ModelCfg("unimodal", z, L), B, planner.TrainCfg(lr=1e-4, clip=clip, deterministic_wgrad=True, bucketed_bwd=bucketed))
+            assert (e.plan.grad_buckets is not None) == bucketed
             om = O.OracleModel("unimodal", z, L, salt=30 + k)
             e.load_state_dict({kk: v.detach() for kk, v in om.state.items()})
             x, src, cls, eps = O.synth_inputs(B, L, z, salt=30 + k)
@@ -353,7 +354,8 @@ def test_rccl_world1_data_parallel_step_equals_plain_step_bit_for_bit():
     """The first RCCL run inside the suite: DataParallelEngine.train_step (hipGraph replay of fwd / bwd / opt with
     ncclAllReduce(AVG) of the gradient arena between bwd and opt) for the wave and the time model on two HIP streams over
     ONE communicator, world size 1 — against the same engines stepping without torch.distributed.  The mean over one rank is
-    the identity and deterministic_wgrad orders every sum, so parameters, gradients and losses must agree BIT FOR BIT."""
+    the identity and deterministic_wgrad orders every sum, so parameters, gradients and losses must agree BIT FOR BIT.  Also in the
+    bucketed form (backward in two halves, the decoder-side bucket reduced asynchronously under the encoder-side half)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
@@ -361,13 +363,14 @@ def test_rccl_world1_data_parallel_step_equals_plain_step_bit_for_bit():
     out, backend, world = q.get(timeout=600)
     p.join(60)
     assert backend == "nccl" and world == 1
-    for k in range(2):
-        pa, ga, sa, ta = out["plain"][k]
-        pb, gb, sb, tb = out["rccl"][k]
-        assert ta == tb == 3
-        np.testing.assert_array_equal(ga, gb, err_msg=f"model {k}: gradients differ")
-        np.testing.assert_array_equal(pa, pb, err_msg=f"model {k}: parameters differ")
-        assert sa == sb, (sa, sb)
+    for variant in ("rccl", "rccl_bucketed"):      # one collective after the pass | two halves, two asynchronous buckets (TrainCfg.bucketed_bwd)
+        for k in range(2):
+            pa, ga, sa, ta = out["plain"][k]
+            pb, gb, sb, tb = out[variant][k]
+            assert ta == tb == 3
+            np.testing.assert_array_equal(ga, gb, err_msg=f"{variant} model {k}: gradients differ")
+            np.testing.assert_array_equal(pa, pb, err_msg=f"{variant} model {k}: parameters differ")
+            assert sa == sb, (variant, sa, sb)
 
 
 def _pipeline_rank(rank, world, port, data_root, out_dir, q, model_type="unimodal"):

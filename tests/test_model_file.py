@@ -26,9 +26,9 @@ class TensorInfo(ctypes.Structure):
 assert ctypes.sizeof(TensorInfo) == export.TENSOR_DT.itemsize == 160
 
 
-def _export(tmp_path, kind="unimodal", z=10, L=50, B=16, L2=100, salt=0, clip=0.0, lr=1e-3):
+def _export(tmp_path, kind="unimodal", z=10, L=50, B=16, L2=100, salt=0, clip=0.0, lr=1e-3, bucketed=False):
     cfg = planner.ModelCfg(kind, z, L, L2)
-    plan = planner.lower(cfg, B, planner.TrainCfg(lr=lr, clip=clip))
+    plan = planner.lower(cfg, B, planner.TrainCfg(lr=lr, clip=clip, bucketed_bwd=bucketed))
     om = O.OracleModel(kind, z, L, output_size2=L2 if kind == "multimodal" else None, salt=salt)
     pv, bv = export.arena_values(plan, {k: v.detach() for k, v in om.state.items()})
     path = str(tmp_path / f"{kind}.hpm")
@@ -103,12 +103,17 @@ def test_damaged_files_are_refused(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,use_graph", [("unimodal", 1), ("unimodal", 0), ("multimodal", 1)])
-def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph):
-    """tests/c_host/host_step.c — C99, only include/hippie_hip.h — against the Python engine on the same file and inputs."""
+@pytest.mark.parametrize("kind,use_graph,dp", [("unimodal", 1, ""), ("unimodal", 0, ""), ("multimodal", 1, ""),
+                                               ("unimodal", 1, "dp"), ("multimodal", 1, "dp-bucketed"), ("unimodal", 0, "dp-bucketed")])
+def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph, dp):
+    """tests/c_host/host_step.c — C99, only include/hippie_hip.h — against the Python engine on the same file and inputs.
+    dp: the host draws an ncclUniqueId, creates a 1-rank RCCL communicator (hp_model_allreduce_init) and takes every step with
+    hp_model_train_step_dp — one all-reduce after the pass, or ("dp-bucketed": a file exported with bucketed_bwd) the two-half / two-bucket
+    form; at one rank the mean over ranks is the identity, so the numbers are the single-process engine's."""
     from hippie_amd.engine import Engine
     z, L, L2, B, lr, clip = 10, 50, 100, 16, 1e-6, 1.0      # (a small lr: Adam turns last-bit gradient differences — atomic sums — into +-lr moves)
-    plan, om, path, pv, bv = _export(tmp_path, kind, z, L, B, L2, salt=4, clip=clip, lr=lr)
+    plan, om, path, pv, bv = _export(tmp_path, kind, z, L, B, L2, salt=4, clip=clip, lr=lr, bucketed=dp == "dp-bucketed")
+    assert ("bwd_dec" in plan.ops.segments) == (dp == "dp-bucketed")
     x, src, cls, eps = O.synth_inputs(B, L, z, salt=4, name="x1" if kind == "multimodal" else "x")
     parts = [x.numpy().astype(np.float32).tobytes()]
     x2 = None
@@ -125,8 +130,9 @@ def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph):
                     os.path.join(ROOT, "tests", "c_host", "host_step.c"), "-o", exe, "-L", libdir, "-lhippie_hip",
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     steps = 3
-    out = subprocess.run([exe, path, inputs, str(steps), str(use_graph)], check=True, capture_output=True, text=True, timeout=300).stdout
+    out = subprocess.run([exe, path, inputs, str(steps), str(use_graph)] + (["dp"] if dp else []), check=True, capture_output=True, text=True, timeout=300).stdout
     lines = out.strip().splitlines()
+    assert ("data parallel: rank 0 of 1" in out) == bool(dp)
     got = np.array([[float(v) for v in ln.split()[2:]] for ln in lines if ln.startswith("step ")])
     assert got.shape == (steps, 4), out
     # the Python engine on the same program and inputs
@@ -208,6 +214,15 @@ def test_staged_model_file_config_and_segments(tmp_path):
     assert lib.hp_model_load(path.encode(), export.NO_DEVICE, ctypes.byref(m)) == 0, lib.hp_last_error()
     out = (ctypes.c_int32 * 16)()
     assert lib.hp_model_config(m, out) == 0 and list(out)[10:13] == [40, 2, 1]
+    # exported for two data-parallel ranks: the fused staged step (which holds no gradient all-reduce) is refused by name
+    assert lib.hp_model_train_step_staged(m, 1, None) != 0 and b"hp_model_train_step_dp" in lib.hp_last_error()
+    assert lib.hp_model_train_step_dp(m, 1, None) != 0 and b"hp_model_allreduce_init" in lib.hp_last_error()
+    uid = (ctypes.c_char * 128)()
+    assert lib.hp_model_allreduce_init(m, uid, 1, 2) != 0 and b"HP_MODEL_NO_DEVICE" in lib.hp_last_error()
+    lib.hp_model_destroy(m)
+    plan1 = planner.lower(cfg, 8, planner.TrainCfg(lr=1e-3, resident_units=40))
+    export.save_model(plan1, path)
+    assert lib.hp_model_load(path.encode(), export.NO_DEVICE, ctypes.byref(m)) == 0, lib.hp_last_error()
     assert lib.hp_model_train_step_staged(m, 1, None) != 0 and b"HP_MODEL_NO_DEVICE" in lib.hp_last_error()
     lib.hp_model_destroy(m)
     # a file without resident tables refuses the staged verb by name
