@@ -30,6 +30,9 @@ hipError_t launch_wgrad_group(int ntaps, bool bf16, const void* d_probs, const v
 bool groupable(const HpOp& op);
 hipError_t build_small_group(const HpOp* members, int count, void* const* bases, void** d_entries);
 hipError_t launch_small_group(const HpOp* members, const void* d_entries, int count, hipStream_t s);
+// fused heads (ops_small.hip / heads_fused.h): members of one HP_OP_HEADS record; check = the host-side pattern match alone
+bool check_heads(const HpOp* members, int count, int kind, const char** why);
+hipError_t launch_heads(const HpOp* members, int count, int kind, void* const* bases, hipStream_t s);
 
 }  // namespace hp
 
@@ -89,15 +92,12 @@ struct BnCoef { float mean, invstd, scale, shift, rm, rv; double var; };
 
 // every global load (gamma, beta, running stats, all statistic replicas) is issued before the first use: one
 // memory round trip instead of one per operand
-__device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* stats, int C, int c, const float* gamma,
-                                          const float* beta, const float* rmean, const float* rvar, float eps) {
+// ... from the two sums themselves (a kernel that holds them already: the fused heads kernel) — the same arithmetic as bn_coef
+__device__ __forceinline__ BnCoef bn_coef_sums(bool training, int M, double s0, double s1, float g, float b, float rm, float rv, float eps) {
   BnCoef k;
-  const float g = gamma[c], b = beta[c];
-  k.rm = rmean[c]; k.rv = rvar[c];
+  k.rm = rm; k.rv = rv;
   double mean, var;
   if (training) {
-    double s0, s1;
-    stat_sum2(stats, C, c, s0, s1);
     mean = s0 / (double)M;
     var = s1 / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -114,6 +114,14 @@ __device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* st
   k.mean = (float)mean; k.invstd = (float)invstd; k.var = var;
   k.scale = (float)sc; k.shift = (float)((double)b - mean * sc);
   return k;
+}
+__device__ __forceinline__ BnCoef bn_coef(bool training, int M, const double* stats, int C, int c, const float* gamma,
+                                          const float* beta, const float* rmean, const float* rvar, float eps) {
+  const float g = gamma[c], b = beta[c];
+  const float rm = rmean[c], rv = rvar[c];
+  double s0 = 0.0, s1 = 0.0;
+  if (training) stat_sum2(stats, C, c, s0, s1);
+  return bn_coef_sums(training, M, s0, s1, g, b, rm, rv, eps);
 }
 
 // training-mode side effects of one channel: saved (mean, invstd) for the backward pass, running statistics

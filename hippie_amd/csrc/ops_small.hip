@@ -8,6 +8,7 @@
 // one fp64 atomic per block.  Consecutive lanes touch consecutive channels (coalesced).
 #include "hp_common.h"
 #include "linear_mfma.h"
+#include "heads_fused.h"
 
 #include <algorithm>
 #include <vector>
@@ -1713,6 +1714,8 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     }
     case HP_OP_STATS_SYNC:
       return hipSuccess;          // marker: the host sums buf[0] over the data-parallel ranks at this point
+    case HP_OP_HEADS:
+      return hipSuccess;          // closing record of a fused chain: executed one by one (hp_run_op), its members did the work
     case HP_OP_SF_SCHEDULE:
       hipLaunchKernelGGL(sf_schedule_kernel, dim3(1), dim3(64), 0, s, ptr<const int64_t>(op, 0, bases), ptr<double>(op, 1, bases),
                          I[0], op.f[0], op.f[1], op.f[2], op.f[3]);
@@ -1792,4 +1795,91 @@ hipError_t hp::launch_small_group(const HpOp* members, const void* d_entries, in
   if (mfma) hipLaunchKernelGGL(small_group_kernel<true>, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
   else hipLaunchKernelGGL(small_group_kernel<false>, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
   return hipGetLastError();
+}
+
+
+// ---- fused heads: host side ---------------------------------------------------------------------------------------------------------
+namespace {
+struct HeadsDims { int B, Z; };
+// The chain the kernels implement, record by record; `why` names the first mismatch.
+bool heads_match(const HpOp* m, int count, int kind, HeadsDims& d, const char** why) {
+  auto bad = [&](const char* w) { if (why) *why = w; return false; };
+  static const int fwd[] = {HP_OP_CONCAT, HP_OP_LINEAR_FWD, HP_OP_BN_APPLY, HP_OP_LINEAR_FWD, HP_OP_BN_APPLY, HP_OP_LINEAR_FWD, HP_OP_REPARAM_KL_FWD,
+                            HP_OP_CONCAT, HP_OP_LINEAR_FWD, HP_OP_LINEAR_FWD, HP_OP_BN_APPLY};
+  const int* pat = fwd;
+  const int n = 11;
+  if (kind != 0) return bad("heads: kind must be 0 (the training forward chain)");
+  if (count != n) return bad("heads: wrong number of member records");
+  for (int k = 0; k < n; ++k) {
+    if (m[k].op != pat[k]) return bad("heads: member opcodes are not the heads chain");
+    if (!(m[k].flags & HP_FLAG_MEMBER)) return bad("heads: a member record lacks HP_FLAG_MEMBER");
+  }
+  constexpr int H = 5;
+  auto lin = [&](const HpOp& o, int M, int N, int K, int ldx, int ldy) { return o.i[0] == M && o.i[1] == N && o.i[2] == K && o.i[3] == ldx && o.i[4] == ldy; };
+  {
+    const int B = m[0].i[0], Z = m[6].i[1], Z2 = 2 * Z, NC0 = Z2 + 2 * H, NC1 = Z + 2 * H;
+    d.B = B; d.Z = Z;
+    if (B < 1 || B > kHeadsThreads || (Z != 5 && Z != 10)) return bad("heads: needs 1 <= batch <= 512 and z_dim 5 or 10");
+    const HpOp& c0 = m[0];
+    const HpOp& c1 = m[7];
+    auto cat_ok = [&](const HpOp& c, int w0, int ldo) {
+      return c.i[0] == B && c.i[1] == 3 && c.i[2] == ldo && c.i[4] == 0 && c.i[5] == w0 && c.i[6] == w0 && c.i[7] == 1 && c.i[8] == H && c.i[9] == H &&
+             (c.i[10] == 1 || c.i[10] == 2) && c.i[11] == H && c.buf[3] != HP_NULL && c.buf[4] != HP_NULL && (c.i[10] == 2 || (c.i[12] == H && c.buf[5] != HP_NULL && c.buf[6] != HP_NULL));
+    };
+    if (!cat_ok(c0, Z2, NC0) || !cat_ok(c1, Z, NC1)) return bad("heads: a CONCAT member is not (dense, source embedding, class embedding | zeros)");
+    if (c0.buf[3] != c1.buf[3] || c0.buf[4] != c1.buf[4] || c0.i[10] != c1.i[10] || c0.buf[5] != c1.buf[5] || c0.buf[6] != c1.buf[6] || c0.i[16 + 1] != c1.i[16 + 1])
+      return bad("heads: the two CONCAT members use different embedding tables / labels");
+    if (!lin(m[1], B, Z2, NC0, NC0, Z2) || !m[1].i[6] || m[1].i[5] || !lin(m[3], B, Z, Z2, Z2, Z) || !m[3].i[6] || m[3].i[5] || !lin(m[5], B, Z2, Z, Z, Z2) || m[5].i[6] ||
+        m[5].i[5] || !lin(m[8], B, Z2, NC1, NC1, Z2) || m[8].i[6] || !m[8].i[5] || !lin(m[9], B, Z2, Z2, Z2, Z2) || !m[9].i[6] || m[9].i[5])
+      return bad("heads: a LINEAR_FWD member has an unexpected shape / flags");
+    auto bn_ok = [&](const HpOp& o, int C) { return o.i[0] == B && o.i[1] == C && o.i[2] == 0 && o.i[3] == 1 && o.i[4] == 1 && o.i[5] <= 1; };
+    if (!bn_ok(m[2], Z2) || !bn_ok(m[4], Z) || !bn_ok(m[10], Z2)) return bad("heads: a BN_APPLY member is not (training, LeakyReLU, no residual, local statistics)");
+    if (m[6].i[0] != B) return bad("heads: REPARAM_KL_FWD batch");
+    // data flow: every member consumes its predecessor's output, statistics slots match
+    const bool flow = m[1].buf[0] == c0.buf[0] && m[2].buf[0] == m[1].buf[3] && m[2].buf[2] == m[1].buf[4] && m[3].buf[0] == m[2].buf[1] &&
+                      m[4].buf[0] == m[3].buf[3] && m[4].buf[2] == m[3].buf[4] && m[5].buf[0] == m[4].buf[1] && m[6].buf[0] == m[5].buf[3] &&
+                      c1.buf[1] == m[6].buf[2] && m[8].buf[0] == c1.buf[0] && m[9].buf[0] == m[8].buf[3] && m[10].buf[0] == m[9].buf[3] && m[10].buf[2] == m[9].buf[4];
+    if (!flow) return bad("heads: the forward members do not feed each other");
+    if (m[2].f[0] != m[4].f[0] || m[2].f[0] != m[10].f[0] || m[2].f[0] != m[8].f[0] || m[2].f[1] != m[4].f[1] || m[2].f[1] != m[10].f[1] || m[2].f[2] != m[4].f[2] || m[2].f[2] != m[10].f[2])
+      return bad("heads: the members disagree on slope / eps / momentum");
+    return true;
+  }
+}
+HeadsBn heads_bn_fwd(const HpOp& o, void* const* bases) {
+  using hp::ptr;
+  return HeadsBn{ptr<const float>(o, 3, bases), ptr<const float>(o, 4, bases), ptr<float>(o, 5, bases), ptr<float>(o, 6, bases), ptr<float>(o, 7, bases)};
+}
+}  // namespace
+
+bool hp::check_heads(const HpOp* members, int count, int kind, const char** why) {
+  HeadsDims d;
+  return heads_match(members, count, kind, d, why);
+}
+
+hipError_t hp::launch_heads(const HpOp* m, int count, int kind, void* const* bases, hipStream_t s) {
+  using hp::ptr;
+  HeadsDims d;
+  if (!heads_match(m, count, kind, d, nullptr)) return hipErrorInvalidValue;
+  {
+    HeadsFwd a{};
+    a.B = d.B; a.n_src = m[0].i[16 + 1]; a.n_cls = m[0].i[10] == 1 ? m[0].i[16 + 2] : 0;
+    a.slope = m[2].f[0]; a.eps = m[2].f[1]; a.momentum = m[2].f[2];
+    a.h = ptr<const float>(m[0], 1, bases);
+    a.semb = ptr<const float>(m[0], 3, bases); a.src = ptr<const int64_t>(m[0], 4, bases);
+    a.cemb = m[0].i[10] == 1 ? ptr<const float>(m[0], 5, bases) : nullptr; a.cls = m[0].i[10] == 1 ? ptr<const int64_t>(m[0], 6, bases) : nullptr;
+    a.c0 = ptr<float>(m[0], 0, bases);
+    a.w0 = ptr<const float>(m[1], 1, bases); a.b0 = ptr<const float>(m[1], 2, bases); a.u1 = ptr<float>(m[1], 3, bases); a.st1 = ptr<double>(m[1], 4, bases);
+    a.bn1 = heads_bn_fwd(m[2], bases); a.a1 = ptr<float>(m[2], 1, bases);
+    a.w3 = ptr<const float>(m[3], 1, bases); a.b3 = ptr<const float>(m[3], 2, bases); a.u2 = ptr<float>(m[3], 3, bases); a.st2 = ptr<double>(m[3], 4, bases);
+    a.bn4 = heads_bn_fwd(m[4], bases); a.encv = ptr<float>(m[4], 1, bases);
+    a.wz = ptr<const float>(m[5], 1, bases); a.bz = ptr<const float>(m[5], 2, bases); a.mulv = ptr<float>(m[5], 3, bases);
+    a.epsn = ptr<const float>(m[6], 1, bases); a.zz = ptr<float>(m[6], 2, bases); a.loss = ptr<double>(m[6], 3, bases);
+    a.c1 = ptr<float>(m[7], 0, bases);
+    a.wf0 = ptr<const float>(m[8], 1, bases); a.bf0 = ptr<const float>(m[8], 2, bases); a.u3 = ptr<float>(m[8], 3, bases);
+    a.wf2 = ptr<const float>(m[9], 1, bases); a.bf2 = ptr<const float>(m[9], 2, bases); a.u4 = ptr<float>(m[9], 3, bases); a.st4 = ptr<double>(m[9], 4, bases);
+    a.bn3 = heads_bn_fwd(m[10], bases); a.dv = ptr<float>(m[10], 1, bases);
+    if (d.Z == 10) hipLaunchKernelGGL((heads_fwd_kernel<10, 5>), dim3(1), dim3(kHeadsThreads), 0, s, a);
+    else hipLaunchKernelGGL((heads_fwd_kernel<5, 5>), dim3(1), dim3(kHeadsThreads), 0, s, a);
+    return hipGetLastError();
+  }
 }

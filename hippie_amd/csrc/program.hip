@@ -82,6 +82,7 @@ int check_range(const HpProgram* p, int first, int count, const char* who) {
     if (ngroup > 0) lo = k - ngroup;
     else if (op.op == HP_OP_WGRAD_GROUP) { lo = op.i[0]; hi = op.i[0] + op.i[1] - 1; }
     else if (op.op == HP_OP_PAIR) { lo = op.i[0] < op.i[1] ? op.i[0] : op.i[1]; hi = op.i[0] < op.i[1] ? op.i[1] : op.i[0]; }
+    else if (op.op == HP_OP_HEADS) { lo = op.i[0]; hi = op.i[0] + op.i[1] - 1; }
     if (lo < first || hi >= last)
       return fail(std::string(who) + ": the range cuts through the launch unit closed by op " + std::to_string(k));
   }
@@ -93,6 +94,7 @@ int check_range(const HpProgram* p, int first, int count, const char* who) {
     if (ngroup > 0) for (int j = k - ngroup; j < k; ++j) covered[j - first] = 1;
     else if (op.op == HP_OP_WGRAD_GROUP) for (int j = op.i[0]; j < op.i[0] + op.i[1]; ++j) covered[j - first] = 1;
     else if (op.op == HP_OP_PAIR) { covered[op.i[0] - first] = 1; covered[op.i[1] - first] = 1; }
+    else if (op.op == HP_OP_HEADS) for (int j = op.i[0]; j < op.i[0] + op.i[1]; ++j) covered[j - first] = 1;
   }
   for (int k = first; k < last; ++k)
     if ((p->ops[k].flags & HP_FLAG_MEMBER) && !covered[k - first])
@@ -124,6 +126,7 @@ hipError_t run_one(HpProgram* p, int k, hipStream_t s) {
     const HpOp& b = p->ops[op.i[1]];
     return a.op == HP_OP_CONV_TAPS ? hp::launch_conv_pair(a, b, p->bases, s) : hp::launch_small_pair(a, b, p->bases, s);
   }
+  if (op.op == HP_OP_HEADS) return hp::launch_heads(&p->ops[op.i[0]], op.i[1], op.i[2], p->bases, s);
   return dispatch(op, p->bases, s);
 }
 
@@ -412,6 +415,12 @@ int hp_program_validate(const HpProgram* p) {
             (j < (int)k && ((m.flags >> HP_FLAG_GROUP_SHIFT) & HP_FLAG_GROUP_MASK)))
           return fail("small-leaf group ending at op " + std::to_string(k) + ": member " + std::to_string(j) + " is not a groupable member record");
       }
+    }
+    if (p->ops[k].op == HP_OP_HEADS) {
+      const HpOp& g = p->ops[k];
+      if (g.i[0] < 0 || g.i[1] <= 0 || g.i[0] + g.i[1] > (int)k) return fail("heads op " + std::to_string(k) + ": member range out of bounds");
+      const char* w = "";
+      if (!hp::check_heads(&p->ops[g.i[0]], g.i[1], g.i[2], &w)) return fail("heads op " + std::to_string(k) + ": " + w);
     }
     if (p->ops[k].op == HP_OP_WGRAD_GROUP) {
       const HpOp& g = p->ops[k];

@@ -90,6 +90,10 @@ class TrainCfg:
                                         # "stage" segment (HP_OP_STAGE_BATCH + cursor increment) gathers each step's batch by index from a
                                         # resident permutation and draws eps with Philox — "step_staged" = stage + fwd_train + bwd + opt is
                                         # then ONE graph per optimisation step with no host work in it (Engine.load_dataset / train_step_staged)
+    fuse_heads: bool = True             # unimodal, z_dim 5 / 10, batch <= 512, training forward: the 11 head ops between the backbones (concat
+                                        # ... decoder_fc BatchNorm) run as ONE single-workgroup launch (HP_OP_HEADS, csrc/heads_fused.h: 30 us
+                                        # against 39 us); the un-fused records stay in the program as its members.  (A backward twin was built,
+                                        # tested and removed: 94 us against 42 us, heads_fused.h.)
     bucketed_bwd: bool = False          # data parallel: the backward segment in two halves, "bwd_dec" (decoders + decoder-side heads, incl.
                                         # THEIR weight-gradient group) and "bwd_enc" (the rest); Plan.grad_buckets lists, per half, the ranges of
                                         # the gradient arena that are complete when it ends, so that the all-reduce of the decoder-side bucket
@@ -937,6 +941,13 @@ class Lowering:
         else:
             self.o.add(op, flags, i=i, f=f, buf=buf, note=note)
 
+    def close_heads(self, first, kind, note):
+        """recs[first:] are the heads chain of one pass: flag them as members and close them with an HP_OP_HEADS record (one launch)."""
+        n = len(self.o.recs) - first
+        for r in self.o.recs[first:]:
+            r["flags"] = int(r["flags"]) | P.FLAG_MEMBER
+        self.o.add(P.HEADS, 0, i=[first, n, kind], note=note)
+
     def flush_wgrads(self):
         """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, then the deferred small leaves as one
         small-leaf group (inside the open segment)."""
@@ -1050,6 +1061,9 @@ class Lowering:
             if multi:
                 self.zip_towers(marks[0], marks[1])
             ncat = (2 * z) * len(enc) + 2 * H
+            fuse_heads = (training and self.train.fuse_heads and not multi and z in (5, 10) and H == 5 and B <= 512 and
+                          self.train.sync_bn_world <= 1 and self.train.group_small_wgrads and
+                          P.debug_knob("HIPPIE_NO_FUSE_HEADS") != "1")     # (the knob: A/B runs of unmodified callers)
             c0 = pl.f32(B * ncat)
             hsegs = []
             hs = []
@@ -1058,6 +1072,7 @@ class Lowering:
                 self.linear_fwd(B, dict(w=e["lin_w"], b=e["lin_b"], N=2 * z, K=512), pz, 512, h, 2 * z, note=e["prefix"] + "linear")
                 hs.append(h)
                 hsegs.append((0, 2 * z, 2 * z, h, None))
+            heads_first = len(self.o.recs)
             self.concat(c0, ncat, hsegs + self.emb_segs(), "cat(enc, source_emb, class_emb)")
             u1 = pl.f32(B * 2 * z)
             st = pl.stat(4 * z) if training else None
@@ -1097,6 +1112,8 @@ class Lowering:
                 self.linear_fwd(B, fc["f2"], u3, 2 * z, u4, 2 * z, stats=st4, note=fcname + ".2")
                 dv = pl.f32(B * 2 * z)
                 self.bn_apply(B, fc["bn3"], u4, dv, st4, training, True, SLOPE_HEADS)
+                if fuse_heads:
+                    self.close_heads(heads_first, 0, "heads forward: cat ... decoder_fc (one workgroup)")
                 rec = self.decoder_fwd(dd, dv, training)
                 pl.io[("rec_" if k == 0 else "rec2_") + mode] = (rec, (B, 1, dd["output_size"]), "f4")
                 drec = pl.f32(B * dd["output_size"])
@@ -1270,7 +1287,7 @@ def pack_workspace(pl):
     at = list(range(len(recs)))
     for g, r in enumerate(recs):
         op = int(r["op"])
-        if op == P.WGRAD_GROUP:
+        if op in (P.WGRAD_GROUP, P.HEADS):
             for k in range(int(r["i"][0]), int(r["i"][0]) + int(r["i"][1])):
                 at[k] = g
         elif op == P.PAIR:

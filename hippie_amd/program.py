@@ -25,7 +25,7 @@ assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
 (CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
  POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
  REPARAM_KL_BWD, MSE_FWD_BWD, TAIL_FWD, TAIL_BWD_X, TAIL_BWD_W, LOSS_FINALIZE, GRADNORM, ADAMW, STEP_INC,
- ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR, SF_SCHEDULE, ADAMW_SF, LERP, STATS_SYNC, STAGE_BATCH) = range(1, 37)
+ ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR, SF_SCHEDULE, ADAMW_SF, LERP, STATS_SYNC, STAGE_BATCH, HEADS) = range(1, 38)
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 

@@ -307,6 +307,14 @@ enum {
    * buf: 0 TABLE[N][L] 1 TABLE2[N][L2] 2 LABELS(int64[N]) 3 PERM(int64[>= i[4]*i[5]*B]) 4 CURSOR(int64[1])
    *      5 X 6 X2 7 SRC(int64[B]) 8 EPS 9 SEED(int64[1]) */
   HP_OP_STAGE_BATCH = 36,
+  /* One launch of ONE workgroup for the heads between the two backbones in the training forward (hippie/model.py:51-72): the i[1]
+   * member records at program indices i[0] .. i[0]+i[1]-1 (all flagged HP_FLAG_MEMBER; hp_run_op and the reference interpreter execute
+   * them one by one) are  CONCAT, LINEAR_FWD+stats, BN_APPLY, LINEAR_FWD+stats, BN_APPLY, LINEAR_FWD (z_mean | z_log_var),
+   * REPARAM_KL_FWD, CONCAT, LINEAR_FWD+act, LINEAR_FWD+stats, BN_APPLY — each consuming its predecessor's output.  Unimodal model, z_dim 5
+   * or 10, class_hidden_dim 5, at most 512 rows; any other chain is refused at program creation.  A thread owns a row and keeps it in
+   * registers from layer to layer; BatchNorm statistics are fp64 column sums in a fixed order (csrc/heads_fused.h).  Every tensor the
+   * members write is written.  i[0]=first i[1]=count i[2]=0 */
+  HP_OP_HEADS = 37,
   HP_OP__COUNT
 };
 

@@ -537,7 +537,7 @@ def run(ops, A: Arenas, first=0, count=None):
                 A.f32(b[6], B * L2)[:] = A.f32(b[1], N * L2).reshape(N, L2)[rows].reshape(-1)
             A.i64(b[7], B)[:] = A.i64(b[2], N)[rows]
             A.f32(b[8], B * z)[:] = philox_normal(int(A.i64(b[9], 1)[0]), cur, B * z, rank)
-        elif op in (29, 30):   # WGRAD_GROUP / PAIR: its member WGRAD_TAPS records (just before it) were executed in place
+        elif op in (29, 30, 37):   # WGRAD_GROUP / PAIR / HEADS: their member records (before them) were executed in place
             pass
         else:
             raise ValueError(f"unknown opcode {op}")

@@ -78,7 +78,7 @@ def test_shared_memory_only_between_disjoint_live_ranges():
     ident = sorted((a[0], a[0] + a[1]) for a in unpacked.allocs)
     at = list(range(len(ru)))
     for g, r in enumerate(ru):
-        if int(r["op"]) == P.WGRAD_GROUP:
+        if int(r["op"]) in (P.WGRAD_GROUP, P.HEADS):
             for k in range(int(r["i"][0]), int(r["i"][0]) + int(r["i"][1])):
                 at[k] = g
         elif int(r["op"]) == P.PAIR:

@@ -1,5 +1,5 @@
 set -e
-O=gpurun_out/r03; mkdir -p $O
+O=gpurun_out/r04; mkdir -p $O
 timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $O/final_tests.log 2>&1 || { tail -30 $O/final_tests.log; exit 1; }
 tail -2 $O/final_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1

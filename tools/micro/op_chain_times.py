@@ -41,7 +41,7 @@ def time_records(recs):
             opc = int(r["op"])
             if opc == P.PAIR:
                 r["i"][0], r["i"][1] = rep * n + (int(recs[j]["i"][0]) - base), rep * n + (int(recs[j]["i"][1]) - base)
-            elif opc == P.WGRAD_GROUP:
+            elif opc in (P.WGRAD_GROUP, P.HEADS):
                 r["i"][0] = rep * n + (int(recs[j]["i"][0]) - base)
             out.append(r)
     prog = DeviceProgram(np.array(out, dtype=P.OP_DTYPE), bases, sizes)
@@ -83,7 +83,7 @@ for seg in ("fwd_train", "bwd", "opt"):
         nchain = (int(r["flags"]) >> P.FLAG_GROUP_SHIFT) & P.FLAG_GROUP_MASK
         if opc == P.PAIR:
             mem = sorted([int(r["i"][0]), int(r["i"][1])])
-        elif opc == P.WGRAD_GROUP:
+        elif opc in (P.WGRAD_GROUP, P.HEADS):
             mem = list(range(int(r["i"][0]), int(r["i"][0]) + int(r["i"][1])))
         elif nchain:
             mem = list(range(gidx - nchain, gidx))          # a chained / grouped launch: the preceding member records + this one
