@@ -27,3 +27,19 @@ def preprocess(waveforms, isi_dists):
     t = np.log(np.asarray(isi_dists, dtype=np.float32) + np.float32(1)).astype(np.float32)
     t = resample_linear(t, 100)
     return w[:, None, :], t[:, None, :]
+
+
+def reference_style_batch(rows, L, log1p, idx):
+    """One DataLoader batch the way the reference builds it, for the CPU baseline's loader-inclusive figure: per ITEM
+    (EphysDatasetLabeled.__getitem__, hippie/dataloading.py:74-101) a float32 tensor, log(x + 1) for the ISI histogram, `F.interpolate(size=L,
+    mode="linear")` on a [1, 1, W] view, a [1, L] result — then the default collate's torch.stack over the batch (DataLoader(batch_size=512),
+    scripts/train_model_with_multimodal.py:155-166, num_workers=0).  rows: [N, W] float array; idx: the batch's indices.  -> [B, 1, L] float32."""
+    import torch
+    import torch.nn.functional as F
+    items = []
+    for i in idx:
+        x = torch.as_tensor(rows[int(i)], dtype=torch.float32)
+        if log1p:
+            x = torch.log(x + 1)
+        items.append(F.interpolate(x.view(1, 1, -1), size=L, mode="linear").view(1, L))
+    return torch.stack(items, 0)

@@ -100,6 +100,12 @@ def relerr(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
+# Every parity() call of the running test: how many tensors were compared and which of them passed ONLY through the second branch
+# (further than `rel` from the float64 oracle, but within `slack` x the reference path's own error).  tests/conftest.py resets this per
+# test, prints it, and holds the count to the test's entry in tests/parity_budget.json (measured on the MI355X box; absent = 0).
+PARITY_TALLY = {"total": 0, "slack": []}
+
+
 def parity(mine, ref32, ref64, msg="", rel=1e-4, slack=3.0):
     """Parity criterion used throughout: `mine` must be within `rel` of the float64 oracle, or — where
     the problem is so ill-conditioned (tiny batch statistics) that the reference's own float32 path is
@@ -108,6 +114,9 @@ def parity(mine, ref32, ref64, msg="", rel=1e-4, slack=3.0):
     e_ref = relerr(ref32, ref64)
     assert np.isfinite(np.asarray(mine, dtype=np.float64)).all(), msg
     assert e_mine <= max(rel, slack * e_ref), f"{msg}: err vs f64 oracle {e_mine:.3e} (reference f32 path: {e_ref:.3e})"
+    PARITY_TALLY["total"] += 1
+    if e_mine > rel:
+        PARITY_TALLY["slack"].append((msg, float(e_mine), float(e_ref)))
     return e_mine, e_ref
 
 
