@@ -162,7 +162,7 @@ def engine_pre_activations(eng):
 
 
 # leaky-ReLU inputs whose sign may differ from the free-running float64 oracle's, as a fraction of all of them.  Measured on
-# MI355X (profiles/r03_flip_budget.txt): 0.7-0.9e-6 at batch 512 (22 / 38 / 69 of 32 / 46 / 78 M), 0-4 per case at batch 8-16
+# MI355X (profiles/r04_flip_budget.txt): 0.7-0.9e-6 at batch 512 (22 / 38 / 69 of 32 / 46 / 78 M), 0-4 per case at batch 8-16
 # — the same rate as torch-float32 on the same inputs (profiles/r03_flips_*_B512.txt): what float32 conv accumulation leaves
 # undecided.  Budget: 3e-6 (and never fewer than 4 elements), i.e. ~3.5x the measured rate.
 FLIP_BUDGET = 3e-6
