@@ -533,6 +533,328 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4,
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Large-batch bf16 body (HP_CONV_BF16 launches with at least two big tiles per CU: BASELINE configs[2] / [4] in their bf16 mode).
+// The 64x64 body above gives a wave ONE v_mfma_f32_32x32x16_bf16 (32 cycles) per K-step and barrier: at batch >= 4096 it runs at
+// 70-300 TFLOP/s, bound by operand staging.  Here: 128 x (64 | 128) output tile per 256-thread workgroup, 4 waves as 2 x 2, each wave
+// 64 rows x (32 | 64) columns = MT x NT = 2 x (1 | 2) MFMA tiles -> 2*MT*NT = 4 | 8 MFMAs per wave and K-step of 32, every A fragment
+// reused NT times and every B fragment MT times; operands are converted to bf16 on their way into LDS as in the small body (same
+// images: [row][32 k] with 80-byte rows, [32 k][cols + 32] for the transposed reads), fp32 accumulation, the same epilogues.
+// Global -> register prefetch one K-step ahead; 2-3 workgroups per CU cover each other's barriers.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int kBigThreads = 256;
+constexpr int big_buf_h(int nt) {                     // bf16 elements of one staging buffer: A image [128][40] + the larger of the two B forms
+  return 128 * kLdaH + (64 * nt * kLdaH > 32 * (64 * nt + 32) ? 64 * nt * kLdaH : 32 * (64 * nt + 32));
+}
+constexpr int big_lds_floats(int nt, int mode) {      // two staging buffers (2 x big_buf_h bf16 = big_buf_h floats) + IN_BN coefficients
+  return big_buf_h(nt) + (mode == 1 ? kConvCoef : 0);
+}
+
+template <bool W_KN, int MODE, int NT>
+__device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, float* smem) {
+  constexpr bool IN_BN = MODE == 1;
+  constexpr int MT = 2, TM = 128, TN = 64 * NT, WN = 32 * NT;
+  constexpr int LDT = TN + 32;                          // [k][n] image row stride (bf16): rows 64 bytes apart mod 256 -> conflict-free tr reads
+  constexpr int A_H = TM * kLdaH;                       // bf16 elements of one A image
+  constexpr int B_H = W_KN ? 32 * LDT : TN * kLdaH;
+  constexpr int BUF_H = big_buf_h(NT);                  // one buffer (A + the larger B form)
+  constexpr int NA = 4;                                 // A rows per thread: 128 rows x 8 four-float pieces / 256 threads
+  constexpr int NB = W_KN ? 2 * NT : 2 * NT;            // B pieces per thread (both forms: TN*32/4/256)
+  (void)B_H;
+  const TapMap& t = p.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int nt_ = (t.N + TN - 1) / TN, mt_ = (t.M + TM - 1) / TM;
+  const int tile = xcd_remap(bid, mt_ * nt_);
+  const int m0 = (tile / nt_) * TM, n0 = (tile % nt_) * TN;
+  const int ar = tid >> 3, aq = (tid & 7) << 2;         // A / [n][k]-B slot: rows ar + 32 j, piece aq
+  const int kr = tid >> 4, nq = (tid & 15) << 2;        // [k][n]-B slot: k rows kr + 16 j, columns nq + 64 jj
+  __bf16* const lds = reinterpret_cast<__bf16*>(smem);
+  const float* s_coef = smem + BUF_H;                   // (behind the two buffers: 2 x BUF_H bf16 = BUF_H floats)
+
+  // row geometry of this thread's four A rows
+  int rbase[NA], rl[NA];
+  bool rvalid[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int m_row = m0 + ar + 32 * j;
+    rvalid[j] = m_row < t.M;
+    const int b_row = m_row / t.Lout;
+    rbase[j] = b_row * t.Lin;
+    rl[j] = t.a * (m_row - b_row * t.Lout);
+  }
+  const int kper = t.K >> 5;
+  const int nsteps = t.ntaps * kper;
+  const size_t wslab = (size_t)t.N * t.K;
+  const float* pa[NA]; const float* pb[NB];
+  int ia[NA], ib[NB];
+  int n_tap = 0, kc = 0;
+  auto set_tap = [&](int tap) {
+    const int to = t.tap_o[tap];
+    const bool second = t.tap_src[tap] != 0;
+    const float* wp = (second ? p.W2 : p.W) + (size_t)t.tap_w[tap] * wslab;
+    const float* ap = second ? p.A2 : p.A;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int pos = rl[j] + to;
+      const bool oa = rvalid[j] && pos >= 0 && pos < t.P;
+      pa[j] = oa ? ap + (size_t)(rbase[j] + (pos >> t.sh)) * t.K + aq : hp_zero16;
+      ia[j] = oa ? 32 : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (!W_KN) {
+        const int n = n0 + ar + 32 * j;
+        const bool ob = n < t.N;
+        pb[j] = ob ? wp + (size_t)n * t.K + aq : hp_zero16;
+        ib[j] = ob ? 32 : 0;
+      } else {
+        const int k = kr + 16 * (j & 1), n = n0 + nq + 64 * (j >> 1);
+        const bool ob = n < t.N;
+        pb[j] = ob ? wp + (size_t)k * t.N + n : hp_zero16;
+        ib[j] = ob ? 32 * t.N : 0;
+      }
+    }
+  };
+  set_tap(0);
+  struct Pref { float4 a[NA]; float4 b[NB]; int kq; };
+  auto fetch = [&]() -> Pref {
+    Pref r;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) r.a[j] = gload4(pa[j]);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) r.b[j] = gload4(pb[j]);
+    r.kq = kc * 32 + aq;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) pa[j] += ia[j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) pb[j] += ib[j];
+    if (++kc == kper) {
+      kc = 0;
+      if (++n_tap < t.ntaps) set_tap(n_tap);
+    }
+    return r;
+  };
+  const bool in_bn = IN_BN && p.in_bn;
+  const float in_slope = p.in_slope;
+  // which of the rows of a fetched set were real (IN_BN: a padded row is a zero of the ACTIVATION): recorded with the set
+  auto stash = [&](int buf, const Pref& r, const unsigned okmask) {
+    __bf16* Ah = lds + buf * BUF_H;
+    __bf16* Bh = Ah + A_H;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (IN_BN && in_bn) {
+      sc = *reinterpret_cast<const float4*>(s_coef + r.kq);
+      sh = *reinterpret_cast<const float4*>(s_coef + t.K + r.kq);
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      float4 v = r.a[j];
+      if (IN_BN && in_bn) {
+        const float keep = (okmask >> j) & 1u ? 1.f : 0.f;
+        const float vx = fmaf(v.x, sc.x, sh.x), vy = fmaf(v.y, sc.y, sh.y), vz = fmaf(v.z, sc.z, sh.z), vw = fmaf(v.w, sc.w, sh.w);
+        v.x = fmaxf(vx, vx * in_slope) * keep; v.y = fmaxf(vy, vy * in_slope) * keep;
+        v.z = fmaxf(vz, vz * in_slope) * keep; v.w = fmaxf(vw, vw * in_slope) * keep;
+      }
+      *reinterpret_cast<bf16x4*>(Ah + (ar + 32 * j) * kLdaH + aq) = to_bf16x4(v);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (!W_KN) *reinterpret_cast<bf16x4*>(Bh + (ar + 32 * j) * kLdaH + aq) = to_bf16x4(r.b[j]);
+      else       *reinterpret_cast<bf16x4*>(Bh + (kr + 16 * (j & 1)) * LDT + nq + 64 * (j >> 1)) = to_bf16x4(r.b[j]);
+    }
+  };
+  auto okbits = [&]() -> unsigned {      // of the set the NEXT fetch() will load
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) m |= (ia[j] ? 1u : 0u) << j;
+    return m;
+  };
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  unsigned ok_cur = okbits();
+  Pref cur = fetch();
+  if (IN_BN && in_bn) {
+    // (scale, shift) of the K input channels, derived exactly as HP_OP_BN_APPLY derives them; workgroup 0 performs the side effects
+    float* sc_w = smem + BUF_H;
+    for (int c = tid; c < t.K; c += kBigThreads) {
+      const BnCoef k = bn_coef(true, p.in_Mstat, p.in_stats, t.K, c, p.gamma, p.beta, p.rmean, p.rvar, p.in_eps);
+      sc_w[c] = k.scale;
+      sc_w[t.K + c] = k.shift;
+      if (bid == 0) bn_side_effects(k, p.in_Mstat, t.K, c, p.in_save, p.rmean, p.rvar, p.in_mom, p.in_coef);
+    }
+    __syncthreads();
+  }
+  stash(0, cur, ok_cur);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < nsteps;
+    unsigned ok_nxt = 0;
+    Pref nxt;
+    if (more) { ok_nxt = okbits(); nxt = fetch(); }      // in flight under this step's MFMAs
+    const __bf16* Ah = lds + buf * BUF_H;
+    const __bf16* Bh = Ah + A_H;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Ah + (wm * 64 + i * 32 + li) * kLdaH + kk * 16 + lh * 8);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (!W_KN) bf[j] = *reinterpret_cast<const bf16x8*>(Bh + (wn * WN + j * 32 + li) * kLdaH + kk * 16 + lh * 8);
+        else       bf[j] = tr_operand(Bh, LDT, kk * 16, wn * WN + j * 32, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) stash(buf ^ 1, nxt, ok_nxt);
+    __syncthreads();
+  }
+
+  // ---- epilogue (the expressions of conv_epilogue; here every wave owns whole accumulator tiles) ----
+  double* sred = reinterpret_cast<double*>(smem);       // [wm][statistic][TN] column partials (the staging buffers are free now)
+  const bool plain_full = t.out_Lfull == 0;
+  const bool has_act = p.e_act != nullptr, has_g2 = p.e_g2 != nullptr, has_2 = p.e_raw2 != nullptr;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * WN + j * 32 + li;
+    const bool nok = n < t.N;
+    double st[3] = {0.0, 0.0, 0.0};
+    float mean = 0.f, invstd = 0.f, mean2 = 0.f, invstd2 = 0.f, csc = 0.f, csh = 0.f, bv = 0.f, esc = 0.f, esh = 0.f;
+    if (nok) {
+      if (p.epi) {
+        mean = p.e_save[n]; invstd = p.e_save[t.N + n];
+        if (has_2) { mean2 = p.e_save2[n]; invstd2 = p.e_save2[t.N + n]; }
+        if (!has_act) { csc = p.e_coef[n]; csh = p.e_coef[t.N + n]; }
+      } else {
+        if (p.bias != nullptr) bv = p.bias[n];
+        if (p.bn_eval) {
+          const double is = 1.0 / sqrt((double)p.rvar[n] + (double)p.eps);
+          const double scd = (double)p.gamma[n] * is;
+          esc = (float)scd;
+          esh = (float)((double)p.beta[n] - (double)p.rmean[n] * scd);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int mrow = m0 + wm * 64 + i * 32 + 4 * lh;
+      int off[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mrow + (r & 3) + 8 * (r >> 2);
+        int o = -1;
+        if (nok && m < t.M) {
+          o = m;
+          if (!plain_full) {
+            const int b = m / t.Lout;
+            o = b * t.out_Lfull + t.out_a * (m - b * t.Lout) + t.out_o;
+          }
+          o = o * t.N + n;
+        }
+        off[r] = o;
+      }
+      if (p.epi) {
+        float xr[16], av[16], g2[16], x2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = off[r] >= 0 ? off[r] : 0;
+          xr[r] = gload1(p.e_raw + o);
+          av[r] = has_act ? gload1(p.e_act + o) : 0.f;
+          g2[r] = has_g2 ? gload1(p.e_g2 + o) : 0.f;
+          x2[r] = has_2 ? gload1(p.e_raw2 + o) : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (off[r] < 0) continue;
+          float gv = acc[i][j][r];
+          if (has_g2) gv += g2[r];
+          const float pre = has_act ? av[r] : fmaf(xr[r], csc, csh);
+          gv *= lrelu_grad(pre, p.e_slope);
+          gstore1(p.out + off[r], gv);
+          st[0] += (double)gv;
+          st[1] += (double)gv * (double)((xr[r] - mean) * invstd);
+          if (has_2) st[2] += (double)gv * (double)((x2[r] - mean2) * invstd2);
+        }
+      } else if (p.bn_eval) {
+        float rs[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rs[r] = p.res != nullptr ? gload1(p.res + (off[r] >= 0 ? off[r] : 0)) : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (off[r] < 0) continue;
+          float v = fmaf(acc[i][j][r] + bv, esc, esh);
+          if (p.res != nullptr) v += rs[r];
+          if (p.act) v = lrelu(v, p.slope);
+          gstore1(p.out + off[r], v);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (off[r] < 0) continue;
+          const float v = acc[i][j][r] + bv;
+          gstore1(p.out + off[r], v);
+          st[0] += (double)v;
+          st[1] += (double)v * (double)v;
+        }
+      }
+    }
+    // column sums: the two lane halves, then the two waves that share these columns (wm = 0, 1), one atomic per column and statistic
+    const bool want = p.epi || (!p.bn_eval && p.stats != nullptr);          // (uniform)
+    if (want) {
+      constexpr int NS = 3;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) st[k] += __shfl_xor(st[k], 32, 64);
+      const int col = wn * WN + j * 32 + li;
+      if (wm == 1 && lane < 32) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) sred[k * TN + col] = st[k];
+      }
+      __syncthreads();
+      if (wm == 0 && lane < 32 && nok) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) st[k] += sred[k * TN + col];
+        if (p.epi) {
+          double* b1 = stat_replica(p.e_bs, t.N, bid);
+          atomic_add_f64(b1 + n, st[0]);
+          atomic_add_f64(b1 + t.N + n, st[1]);
+          if (has_2) {
+            double* b2 = stat_replica(p.e_bs2, t.N, bid);
+            atomic_add_f64(b2 + n, st[0]);
+            atomic_add_f64(b2 + t.N + n, st[2]);
+          }
+        } else {
+          double* sp = stat_replica(p.stats, t.N, bid);
+          atomic_add_f64(sp + n, st[0]);
+          atomic_add_f64(sp + t.N + n, st[1]);
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <bool W_KN, int MODE, int NT>
+__global__ __launch_bounds__(kBigThreads) void conv_big_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, MODE)];
+  conv_big_body<W_KN, MODE, NT>(p, blockIdx.x, smem);
+}
+template <bool W_KN, int MODE, int NT>
+__global__ __launch_bounds__(kBigThreads) void conv_big_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, MODE)];
+  if ((int)blockIdx.x < nblk_a) conv_big_body<W_KN, MODE, NT>(a, blockIdx.x, smem);
+  else conv_big_body<W_KN, MODE, NT>(b, blockIdx.x - nblk_a, smem);
+}
+
 static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   ConvArgs a;
   a.t = tapmap_from(op);
@@ -580,10 +902,48 @@ static int conv_mode(int flags) { return (flags & HP_CONV_IN_BN) ? 1 : 0; }
     else                  { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, false>), __VA_ARGS__); } \
   } while (0)
 
+// Which body runs a bf16 launch: 0 = the 64x64 one, 1 = 128x64 tiles, 2 = 128x128 tiles — the big bodies from two tiles per CU on
+// (below that a layer does not fill the chip with 128-row tiles: batch 512).  (the knob: unit tests force the big bodies onto small shapes)
+static int conv_big_min_tiles() {
+  static const int v = [] {
+    const char* on = getenv("HIPPIE_DEBUG_KNOBS");
+    const char* e = (on && on[0] == '1') ? getenv("HIPPIE_CONV_BIG_MIN_TILES") : nullptr;
+    return e ? atoi(e) : 512;
+  }();
+  return v;
+}
+static int conv_big_nt(const TapMap& t) {
+  const int rows = hp::cdiv(t.M, 128);
+  if (t.N >= 128 && rows * hp::cdiv(t.N, 128) >= conv_big_min_tiles()) return 2;
+  if (rows * hp::cdiv(t.N, 64) >= conv_big_min_tiles()) return 1;
+  return 0;
+}
+#define HP_BIG_DISPATCH(KERNEL, KN, MODE, NT, ...)                                                                                    \
+  do {                                                                                                                                \
+    if (NT == 2) {                                                                                                                    \
+      if (MODE == 1) { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 2>), __VA_ARGS__); } \
+      else           { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, 2>), __VA_ARGS__); } \
+    } else {                                                                                                                          \
+      if (MODE == 1) { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 1>), __VA_ARGS__); } \
+      else           { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, 1>), __VA_ARGS__); } \
+    }                                                                                                                                 \
+  } while (0)
+
 hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* bases, hipStream_t s) {
   if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & HP_CONV_BF16) != (opb.flags & HP_CONV_BF16)) return hipErrorInvalidValue;
   const int ma = conv_mode(opa.flags), mb = conv_mode(opb.flags);
   const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
+  if (opa.flags & HP_CONV_BF16) {
+    const int big = std::min(conv_big_nt(a.t), conv_big_nt(b.t));
+    if (big > 0) {
+      const int tn = 64 * big;
+      const int na = hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, tn), nb = hp::cdiv(b.t.M, 128) * hp::cdiv(b.t.N, tn);
+      const bool kn = opa.flags & 1;
+      const int mode = ma > mb ? ma : mb;
+      HP_BIG_DISPATCH(conv_big_pair_kernel, kn, mode, big, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+      return hipGetLastError();
+    }
+  }
   const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
   const bool kn = opa.flags & 1, bf = opa.flags & HP_CONV_BF16;
   const int mode = ma > mb ? ma : mb;
@@ -594,6 +954,15 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
 
 hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
   const ConvArgs a = conv_args_from(op, bases);
+  if (op.flags & HP_CONV_BF16) {
+    const int big = conv_big_nt(a.t);
+    if (big > 0) {
+      const bool kn = op.flags & 1;
+      const int mode = conv_mode(op.flags);
+      HP_BIG_DISPATCH(conv_big_kernel, kn, mode, big, dim3(hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, 64 * big)), dim3(kBigThreads), 0, s, a);
+      return hipGetLastError();
+    }
+  }
   const dim3 g(hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64)), th(kConvThreads);
   const bool kn = op.flags & 1, bf = op.flags & HP_CONV_BF16;
   const int mode = conv_mode(op.flags);
