@@ -72,7 +72,7 @@ class Pair:
     113.8 k samples/s: nothing hides the launch floors on a single stream — and removed in round 3)"""
 
     def __init__(self, device, world, lr=1e-3, lens=(50, 100), lockstep=False, fuse_bn=True, mfma_dtype="f32", reuse_ws=True,
-                 model_type="unimodal", staged=True, rank=0, bucketed=False):
+                 model_type="unimodal", staged=True, rank=0, bucketed=False, act_dtype="f32"):
         self.device, self.world, self.lockstep = device, world, lockstep
         # staged: the synthetic tables are RESIDENT in each engine's workspace and every step's batch gather + eps draw is the first
         # launch of the step's graph (HP_OP_STAGE_BATCH): one graph replay per model-step, no torch kernel inside the timed region.
@@ -83,6 +83,7 @@ class Pair:
         # encoder-side half runs on the model's own stream (hippie_amd.parallel.backward_allreduce)
         self.bucketed = bucketed
         res["bucketed_bwd"] = bucketed
+        res["act_dtype"] = act_dtype          # "bf16": the backbones' activations stored as bfloat16 (only with mfma_dtype="bf16")
         self.only = None          # --only-model: step one of the two models (how much of the pair step is overlap?)
         self.multimodal = model_type == "multimodal"
         if self.multimodal:
@@ -226,12 +227,13 @@ def _nbuf(r, slots):
 def op_bytes(r):
     """Algorithmic HBM bytes of one HBM/latency-bound op record (every operand read once, every result written once)."""
     opc, I = int(r["op"]), r["i"]
+    es = 2 if int(r["flags"]) & P.FLAG_ACT_BF16 else 4          # bytes per stored activation element
     if opc == P.BN_APPLY:                 # raw (+ residual tensor / second raw) -> out
-        return 4 * int(I[0]) * int(I[1]) * (2 + (1 if int(I[2]) else 0))
+        return es * int(I[0]) * int(I[1]) * (2 + (1 if int(I[2]) else 0))
     if opc == P.BN_BWD_REDUCE:            # g1 (+g2) (+act) + raw (+raw2) -> g
-        return 4 * int(I[0]) * int(I[1]) * (1 + _nbuf(r, (0, 1, 2, 4, 7)))
+        return es * int(I[0]) * int(I[1]) * (1 + _nbuf(r, (0, 1, 2, 4, 7)))
     if opc == P.BN_BWD_APPLY:             # g, raw -> dr
-        return 4 * int(I[0]) * int(I[1]) * 3
+        return es * int(I[0]) * int(I[1]) * 3
     if opc == P.ADAMW:
         return 28 * int(I[0])
     if opc == P.GRADNORM:
@@ -581,6 +583,9 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the headline: the reference's arithmetic) | bf16: BASELINE config 2's reduced-precision mode "
                          "(bf16 MFMA operands, fp32 accumulation / statistics / master weights): a separately labelled line, never the headline")
+    ap.add_argument("--bf16-storage", action="store_true",
+                    help="with --dtype bf16: the backbones' activations and their gradients are also STORED as bfloat16 (TrainCfg.act_dtype): a third less "
+                         "workspace; slower than fp32 storage as the kernels stand (2-byte accesses per lane: profiles/r04_bf16_storage.txt)")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: one launch per BatchNorm pass instead of the fused loaders / epilogues")
     # non-default shapes (BASELINE configs[2]: --batch 4096 --z-dim 32 --wave-len 256 --time-len 32); the headline
     # metric is always quoted on the defaults
@@ -640,7 +645,8 @@ def main():
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
     pair = Pair(device, world, lens=(args.wave_len, args.time_len), lockstep=args.lockstep,
                 fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type,
-                staged=not args.no_staged, rank=rank, bucketed=(world > 1 or force_dist) and args.bucketed_bwd)
+                staged=not args.no_staged, rank=rank, bucketed=(world > 1 or force_dist) and args.bucketed_bwd,
+                act_dtype="bf16" if (args.dtype == "bf16" and args.bf16_storage) else "f32")
     pair.only = args.only_model
     pair.stream_priority = not args.no_stream_priority
     pair.run_ahead = max(0, args.run_ahead)
@@ -708,7 +714,8 @@ def main():
             if args.bucketed_bwd:
                 # the N > 1 lowering (TrainCfg.bucketed_bwd: two backward halves, two gradient buckets) in engines of its own
                 pair = Pair(device, 1, lens=(args.wave_len, args.time_len), lockstep=args.lockstep, fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype,
-                            reuse_ws=not args.no_reuse_ws, model_type=args.model_type, staged=not args.no_staged, rank=0, bucketed=True)
+                            reuse_ws=not args.no_reuse_ws, model_type=args.model_type, staged=not args.no_staged, rank=0, bucketed=True,
+                            act_dtype="bf16" if (args.dtype == "bf16" and args.bf16_storage) else "f32")
                 pair.stream_priority, pair.run_ahead = main_pair.stream_priority, main_pair.run_ahead
                 if pair.staged:
                     pair.load_tables(data, perm)
@@ -776,6 +783,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            **({"activation_storage": "bf16" if args.bf16_storage else "fp32"} if args.dtype == "bf16" else {}),
             "config": {"workload": ("REDUCED-PRECISION MODE (bf16 MFMA operands, fp32 accumulate; NOT the headline; tolerance: tests/test_gpu_bf16.py) — " if args.dtype == "bf16" else "") +
                                    ("BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
                                     "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "

@@ -107,6 +107,7 @@ constexpr int kConvThreads = 512;
 #else
 #define HP_TS(k)
 #endif
+template <bool ABF>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[2], float* smem, const int bid, const int m0, const int n0) {
   const TapMap& t = p.t;
   if ((HP_ABL & 1) && t.M >= 0) return;
@@ -176,10 +177,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
 #pragma unroll
     for (int j = 0; j < 8; ++j) {          // all loads in flight before the first use
       const int o = off[j] >= 0 ? off[j] : 0;          // clamped, unconditional
-      xr[j] = gload1(p.e_raw + o);
-      av[j] = has_act ? gload1(p.e_act + o) : 0.f;
-      g2[j] = has_g2 ? gload1(p.e_g2 + o) : 0.f;
-      x2[j] = has_2 ? gload1(p.e_raw2 + o) : 0.f;
+      xr[j] = aload1<ABF>(p.e_raw, o);
+      av[j] = has_act ? aload1<ABF>(p.e_act, o) : 0.f;
+      g2[j] = has_g2 ? aload1<ABF>(p.e_g2, o) : 0.f;
+      x2[j] = has_2 ? aload1<ABF>(p.e_raw2, o) : 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -189,7 +190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
       if (has_g2) gv += g2[j];
       const float pre = has_act ? av[j] : fmaf(xr[j], csc, csh);
       gv *= lrelu_grad(pre, p.e_slope);
-      gstore1(p.out + off[j], gv);
+      astore1<ABF>(p.out, off[j], gv);
       s[0] += (double)gv;
       s[1] += (double)gv * (double)((xr[j] - mean) * invstd);
       if (has_2) s[2] += (double)gv * (double)((x2[j] - mean2) * invstd2);
@@ -222,14 +223,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
     }
     float rs[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) rs[j] = p.res != nullptr ? gload1(p.res + (off[j] >= 0 ? off[j] : 0)) : 0.f;
+    for (int j = 0; j < 8; ++j) rs[j] = p.res != nullptr ? aload1<ABF>(p.res, off[j] >= 0 ? off[j] : 0) : 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (!full && off[j] < 0) continue;
       float v = fmaf(own[j] + bv, sc, sh);
       if (p.res != nullptr) v += rs[j];
       if (p.act) v = lrelu(v, p.slope);
-      gstore1(p.out + off[j], v);
+      astore1<ABF>(p.out, off[j], v);
     }
     return;
   }
@@ -238,7 +239,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
   for (int j = 0; j < 8; ++j) {
     if (!full && off[j] < 0) continue;
     const float v = own[j] + bv;
-    if (!((HP_ABL & 4) && t.M >= 0)) gstore1(p.out + off[j], v);
+    if (!((HP_ABL & 4) && t.M >= 0)) astore1<ABF>(p.out, off[j], v);
     s[0] += (double)v;
     s[1] += (double)v * (double)v;
   }
@@ -268,8 +269,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
 // of LDS — is no faster at K = 512 (38.1 us either way) and slower at K = 64 (17-18.6 vs 13.4 us: twice the prologue):
 // the per-slice barrier is not what limits the loop.)
 // MODE: 0 = the A operand is a stored tensor; 1 = HP_CONV_IN_BN
-template <bool W_KN, int MODE, bool BF16 = false>
+template <bool W_KN, int MODE, bool BF16 = false, bool ABF = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
+  constexpr int ES = ABF ? 2 : 4;      // bytes per stored activation element (HP_FLAG_ACT_BF16; only with BF16)
   constexpr bool IN_BN = MODE == 1;
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
   constexpr int LDBK = 68;   // [k][n] image row stride
@@ -304,7 +306,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   // zeros of the ACTIVATION, not of the raw tensor it is computed from)
   struct Pref { float4 a, b; int kq; };
   // Per-tap load state: pointers advanced by a constant per K-slice, recomputed only at tap boundaries.
-  const float* pa; const float* pb;
+  const char* pa; const float* pb;
   int ia, ib;
   int n_tap = 0, kc = 0;
   auto set_tap = [&](int tap) {
@@ -314,8 +316,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     const float* ap = second ? p.A2 : p.A;
     const int pos = rl + to;
     const bool oa = rvalid && pos >= 0 && pos < t.P;
-    pa = oa ? ap + (size_t)(rbase + (pos >> t.sh)) * t.K + aq : hp_zero16;
-    ia = oa ? 32 : 0;
+    pa = oa ? reinterpret_cast<const char*>(ap) + ((size_t)(rbase + (pos >> t.sh)) * t.K + aq) * ES : reinterpret_cast<const char*>(hp_zero16);
+    ia = oa ? 32 * ES : 0;
     bool ob;
     if (!W_KN) {
       ob = n0 + ar < t.N && !((HP_ABL & 2) && t.M >= 0);
@@ -337,7 +339,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   };
   auto fetch = [&]() -> Pref {
     Pref r;
-    r.a = gload4(pa);
+    r.a = aload4p<ABF>(pa);
     r.b = gload4(pb);
     r.kq = 0;
     if (IN_BN) r.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;      // a padded row reads (scale, shift) = (0, 0): its activation is exactly 0
@@ -408,7 +410,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     if (!W_KN) bf = *reinterpret_cast<const bf16x8*>(Bh + (wn * 32 + li) * kLdaH + kh * 16 + lh * 8);   \
     else       bf = tr_operand(Bh, kLdtH, kh * 16, wn * 32, lane);                                      \
     if (FETCH) {                                                                                        \
-      LD.a = gload4(pa);                                                                                \
+      LD.a = aload4p<ABF>(pa);                                                                                \
       LD.b = gload4(pb);                                                                                \
       if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -434,7 +436,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     }                                                                                                   \
     if (STASH) load_coef(ST);      /* with the fragment reads: the LDS round trip is over before the store needs it */ \
     if (FETCH) {                                                                                        \
-      LD.a = gload4(pa);                                                                                \
+      LD.a = aload4p<ABF>(pa);                                                                                \
       LD.b = gload4(pb);                                                                                \
       if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                \
@@ -512,24 +514,24 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
 #undef HP_KSTEP_H
 
   HP_TS(2)
-  conv_epilogue(p, acc2, smem, bid, m0, n0);
+  conv_epilogue<ABF>(p, acc2, smem, bid, m0, n0);
 }
 
 // (amdgpu_waves_per_eu(4): two 512-thread workgroups per CU, i.e. at most 128 VGPRs, for every instantiation)
-template <bool W_KN, int MODE, bool BF16 = false>
+template <bool W_KN, int MODE, bool BF16 = false, bool ABF = false>
 __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_taps_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[kConvLds + conv_extra_lds(MODE)];
-  conv_body<W_KN, MODE, BF16>(p, blockIdx.x, smem);
+  conv_body<W_KN, MODE, BF16, ABF>(p, blockIdx.x, smem);
 }
 
 // HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, a block's conv1
 // and its shortcut, or the even / odd output phases of a stride-2 input-gradient) in ONE launch: twice the
 // workgroups per launch at batch 512, where a single layer only fills each CU with one workgroup.
-template <bool W_KN, int MODE, bool BF16 = false>
+template <bool W_KN, int MODE, bool BF16 = false, bool ABF = false>
 __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_taps_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
   __shared__ __attribute__((aligned(16))) float smem[kConvLds + conv_extra_lds(MODE)];
-  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, MODE, BF16>(a, blockIdx.x, smem);
-  else conv_body<W_KN, MODE, BF16>(b, blockIdx.x - nblk_a, smem);
+  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, MODE, BF16, ABF>(a, blockIdx.x, smem);
+  else conv_body<W_KN, MODE, BF16, ABF>(b, blockIdx.x - nblk_a, smem);
 }
 
 
@@ -550,7 +552,7 @@ constexpr int big_lds_floats(int nt, int mode) {      // two staging buffers (2 
   return big_buf_h(nt) + (mode == 1 ? kConvCoef : 0);
 }
 
-template <bool W_KN, int MODE, int NT>
+template <bool W_KN, int MODE, int NT, bool ABF>
 __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr bool IN_BN = MODE == 1;
   constexpr int MT = 2, TM = 128, TN = 64 * NT, WN = 32 * NT;
@@ -586,7 +588,8 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   const int kper = t.K >> 5;
   const int nsteps = t.ntaps * kper;
   const size_t wslab = (size_t)t.N * t.K;
-  const float* pa[NA]; const float* pb[NB];
+  constexpr int ES = ABF ? 2 : 4;                       // bytes per stored activation element (HP_FLAG_ACT_BF16)
+  const char* pa[NA]; const float* pb[NB];
   int ia[NA], ib[NB];
   int n_tap = 0, kc = 0;
   auto set_tap = [&](int tap) {
@@ -598,8 +601,8 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     for (int j = 0; j < NA; ++j) {
       const int pos = rl[j] + to;
       const bool oa = rvalid[j] && pos >= 0 && pos < t.P;
-      pa[j] = oa ? ap + (size_t)(rbase[j] + (pos >> t.sh)) * t.K + aq : hp_zero16;
-      ia[j] = oa ? 32 : 0;
+      pa[j] = oa ? reinterpret_cast<const char*>(ap) + ((size_t)(rbase[j] + (pos >> t.sh)) * t.K + aq) * ES : reinterpret_cast<const char*>(hp_zero16);
+      ia[j] = oa ? 32 * ES : 0;
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -621,7 +624,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   auto fetch = [&]() -> Pref {
     Pref r;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) r.a[j] = gload4(pa[j]);
+    for (int j = 0; j < NA; ++j) r.a[j] = aload4p<ABF>(pa[j]);
 #pragma unroll
     for (int j = 0; j < NB; ++j) r.b[j] = gload4(pb[j]);
     r.kq = kc * 32 + aq;
@@ -768,10 +771,10 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int o = off[r] >= 0 ? off[r] : 0;
-          xr[r] = gload1(p.e_raw + o);
-          av[r] = has_act ? gload1(p.e_act + o) : 0.f;
-          g2[r] = has_g2 ? gload1(p.e_g2 + o) : 0.f;
-          x2[r] = has_2 ? gload1(p.e_raw2 + o) : 0.f;
+          xr[r] = aload1<ABF>(p.e_raw, o);
+          av[r] = has_act ? aload1<ABF>(p.e_act, o) : 0.f;
+          g2[r] = has_g2 ? aload1<ABF>(p.e_g2, o) : 0.f;
+          x2[r] = has_2 ? aload1<ABF>(p.e_raw2, o) : 0.f;
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -780,7 +783,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
           if (has_g2) gv += g2[r];
           const float pre = has_act ? av[r] : fmaf(xr[r], csc, csh);
           gv *= lrelu_grad(pre, p.e_slope);
-          gstore1(p.out + off[r], gv);
+          astore1<ABF>(p.out, off[r], gv);
           st[0] += (double)gv;
           st[1] += (double)gv * (double)((xr[r] - mean) * invstd);
           if (has_2) st[2] += (double)gv * (double)((x2[r] - mean2) * invstd2);
@@ -788,21 +791,21 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
       } else if (p.bn_eval) {
         float rs[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) rs[r] = p.res != nullptr ? gload1(p.res + (off[r] >= 0 ? off[r] : 0)) : 0.f;
+        for (int r = 0; r < 16; ++r) rs[r] = p.res != nullptr ? aload1<ABF>(p.res, off[r] >= 0 ? off[r] : 0) : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (off[r] < 0) continue;
           float v = fmaf(acc[i][j][r] + bv, esc, esh);
           if (p.res != nullptr) v += rs[r];
           if (p.act) v = lrelu(v, p.slope);
-          gstore1(p.out + off[r], v);
+          astore1<ABF>(p.out, off[r], v);
         }
       } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (off[r] < 0) continue;
           const float v = acc[i][j][r] + bv;
-          gstore1(p.out + off[r], v);
+          astore1<ABF>(p.out, off[r], v);
           st[0] += (double)v;
           st[1] += (double)v * (double)v;
         }
@@ -843,16 +846,16 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   }
 }
 
-template <bool W_KN, int MODE, int NT>
+template <bool W_KN, int MODE, int NT, bool ABF>
 __global__ __launch_bounds__(kBigThreads) void conv_big_kernel(ConvArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, MODE)];
-  conv_big_body<W_KN, MODE, NT>(p, blockIdx.x, smem);
+  conv_big_body<W_KN, MODE, NT, ABF>(p, blockIdx.x, smem);
 }
-template <bool W_KN, int MODE, int NT>
+template <bool W_KN, int MODE, int NT, bool ABF>
 __global__ __launch_bounds__(kBigThreads) void conv_big_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
   __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, MODE)];
-  if ((int)blockIdx.x < nblk_a) conv_big_body<W_KN, MODE, NT>(a, blockIdx.x, smem);
-  else conv_big_body<W_KN, MODE, NT>(b, blockIdx.x - nblk_a, smem);
+  if ((int)blockIdx.x < nblk_a) conv_big_body<W_KN, MODE, NT, ABF>(a, blockIdx.x, smem);
+  else conv_big_body<W_KN, MODE, NT, ABF>(b, blockIdx.x - nblk_a, smem);
 }
 
 static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
@@ -895,9 +898,10 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
 // may mix it with plain members), 0 = plain
 static int conv_mode(int flags) { return (flags & HP_CONV_IN_BN) ? 1 : 0; }
 
-#define HP_CONV_DISPATCH(KERNEL, KN, MODE, BF, ...)                                                     \
+#define HP_CONV_DISPATCH(KERNEL, KN, MODE, BF, ABF, ...)                                                \
   do {                                                                                                  \
-    if (BF)               { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, true>), __VA_ARGS__); } \
+    if (BF && ABF)        { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, true, true>), __VA_ARGS__); } \
+    else if (BF)          { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, true>), __VA_ARGS__); } \
     else if (MODE == 1)   { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, false>), __VA_ARGS__); } \
     else                  { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, false>), __VA_ARGS__); } \
   } while (0)
@@ -918,19 +922,22 @@ static int conv_big_nt(const TapMap& t) {
   if (rows * hp::cdiv(t.N, 64) >= conv_big_min_tiles()) return 1;
   return 0;
 }
-#define HP_BIG_DISPATCH(KERNEL, KN, MODE, NT, ...)                                                                                    \
-  do {                                                                                                                                \
-    if (NT == 2) {                                                                                                                    \
-      if (MODE == 1) { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 2>), __VA_ARGS__); } \
-      else           { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, 2>), __VA_ARGS__); } \
-    } else {                                                                                                                          \
-      if (MODE == 1) { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 1>), __VA_ARGS__); } \
-      else           { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, 1>), __VA_ARGS__); } \
-    }                                                                                                                                 \
+#define HP_BIG_DISPATCH4(KERNEL, KN, MODE, NTV, ABFV, ...)                                                                                         \
+  do {                                                                                                                                            \
+    if (MODE == 1) { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, NTV, ABFV>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, NTV, ABFV>), __VA_ARGS__); } \
+    else           { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, NTV, ABFV>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, NTV, ABFV>), __VA_ARGS__); } \
+  } while (0)
+#define HP_BIG_DISPATCH(KERNEL, KN, MODE, NT, ABF, ...)                                              \
+  do {                                                                                               \
+    if (NT == 2) { if (ABF) HP_BIG_DISPATCH4(KERNEL, KN, MODE, 2, true, __VA_ARGS__); else HP_BIG_DISPATCH4(KERNEL, KN, MODE, 2, false, __VA_ARGS__); } \
+    else         { if (ABF) HP_BIG_DISPATCH4(KERNEL, KN, MODE, 1, true, __VA_ARGS__); else HP_BIG_DISPATCH4(KERNEL, KN, MODE, 1, false, __VA_ARGS__); } \
   } while (0)
 
 hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* bases, hipStream_t s) {
-  if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & HP_CONV_BF16) != (opb.flags & HP_CONV_BF16)) return hipErrorInvalidValue;
+  if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & HP_CONV_BF16) != (opb.flags & HP_CONV_BF16) ||
+      (opa.flags & HP_FLAG_ACT_BF16) != (opb.flags & HP_FLAG_ACT_BF16)) return hipErrorInvalidValue;
+  const bool abf = opa.flags & HP_FLAG_ACT_BF16;
+  if (abf && !(opa.flags & HP_CONV_BF16)) return hipErrorInvalidValue;      // bf16-stored activations only with the bf16 matrix path
   const int ma = conv_mode(opa.flags), mb = conv_mode(opb.flags);
   const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
   if (opa.flags & HP_CONV_BF16) {
@@ -940,7 +947,7 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
       const int na = hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, tn), nb = hp::cdiv(b.t.M, 128) * hp::cdiv(b.t.N, tn);
       const bool kn = opa.flags & 1;
       const int mode = ma > mb ? ma : mb;
-      HP_BIG_DISPATCH(conv_big_pair_kernel, kn, mode, big, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+      HP_BIG_DISPATCH(conv_big_pair_kernel, kn, mode, big, abf, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
       return hipGetLastError();
     }
   }
@@ -948,25 +955,27 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
   const bool kn = opa.flags & 1, bf = opa.flags & HP_CONV_BF16;
   const int mode = ma > mb ? ma : mb;
   const dim3 g(na + nb), th(kConvThreads);
-  HP_CONV_DISPATCH(conv_taps_pair_kernel, kn, mode, bf, g, th, 0, s, a, b, na);
+  HP_CONV_DISPATCH(conv_taps_pair_kernel, kn, mode, bf, abf, g, th, 0, s, a, b, na);
   return hipGetLastError();
 }
 
 hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t s) {
   const ConvArgs a = conv_args_from(op, bases);
+  const bool abf = op.flags & HP_FLAG_ACT_BF16;
+  if (abf && !(op.flags & HP_CONV_BF16)) return hipErrorInvalidValue;
   if (op.flags & HP_CONV_BF16) {
     const int big = conv_big_nt(a.t);
     if (big > 0) {
       const bool kn = op.flags & 1;
       const int mode = conv_mode(op.flags);
-      HP_BIG_DISPATCH(conv_big_kernel, kn, mode, big, dim3(hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, 64 * big)), dim3(kBigThreads), 0, s, a);
+      HP_BIG_DISPATCH(conv_big_kernel, kn, mode, big, abf, dim3(hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, 64 * big)), dim3(kBigThreads), 0, s, a);
       return hipGetLastError();
     }
   }
   const dim3 g(hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64)), th(kConvThreads);
   const bool kn = op.flags & 1, bf = op.flags & HP_CONV_BF16;
   const int mode = conv_mode(op.flags);
-  HP_CONV_DISPATCH(conv_taps_kernel, kn, mode, bf, g, th, 0, s, a);
+  HP_CONV_DISPATCH(conv_taps_kernel, kn, mode, bf, abf, g, th, 0, s, a);
   return hipGetLastError();
 }
 #undef HP_CONV_DISPATCH
@@ -986,7 +995,7 @@ struct WgradArgs {
 };
 
 
-template <int NT, bool BF16 = false>
+template <int NT, bool BF16 = false, bool ABF = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, const int split, float* smem) {
   constexpr int T = 32 * 64;   // one [32 rows][64 cols] image
   const TapMap& t = p.t;
@@ -1026,7 +1035,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
       const int m = mb + lr + 16 * j;
       const bool mv = m < mend;
       rdy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (mv && n0 + cq < t.N) rdy[j] = gload4(gDY + (size_t)m * t.N + n0 + cq);
+      if (mv && n0 + cq < t.N) rdy[j] = aload4<ABF>(gDY, (size_t)m * t.N + n0 + cq);
       const int b = rb_[j];
       const int al = t.a * rl_[j];
       rl_[j] += r32; rb_[j] += q32;
@@ -1037,7 +1046,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
         const bool ok = mv && pos >= 0 && pos < t.P && (c0 + cq < t.K);
         rx[tau][j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ok) {
-          rx[tau][j] = gload4(gX + (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
+          rx[tau][j] = aload4<ABF>(gX, (size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + cq);
           okmask |= 1u << (2 * tau + j);
         }
       }
@@ -1142,10 +1151,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
   }
 }
 
-template <int NT, bool BF16 = false>
+template <int NT, bool BF16 = false, bool ABF = false>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64];
-  wgrad_body<NT, BF16>(p, blockIdx.x, blockIdx.y, smem);
+  wgrad_body<NT, BF16, ABF>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // Grouped form: ONE launch runs every weight-gradient GEMM of a backward pass.  They are independent
@@ -1154,7 +1163,7 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
 #ifndef HP_WGRAD_PAD_FLOATS
 #define HP_WGRAD_PAD_FLOATS 0      // experiment (profiles/r03_wgrad_occupancy_ab.txt): extra LDS per workgroup caps the group launch's workgroups per CU
 #endif
-template <int NT, bool BF16 = false>
+template <int NT, bool BF16 = false, bool ABF = false>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __restrict__ probs, const int4* __restrict__ blocks) {
   __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64 + HP_WGRAD_PAD_FLOATS];
   const int4 bi = blocks[blockIdx.x];
@@ -1164,7 +1173,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __res
   // by value: one scalar load of the problem record up front.  Through a reference into global memory the
   // compiler re-loads the fields (s_load + wait) inside every guarded load of the slice loop.
   const WgradArgs p = probs[pj];
-  wgrad_body<NT, BF16>(p, tile, split, smem);
+  wgrad_body<NT, BF16, ABF>(p, tile, split, smem);
 }
 
 static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {
@@ -1212,10 +1221,17 @@ hipError_t hp::build_wgrad_group(const HpOp* members, int count, void* const* ba
   return e;
 }
 
-hipError_t hp::launch_wgrad_group(int ntaps, bool bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s) {
+hipError_t hp::launch_wgrad_group(int ntaps, int bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s) {
+  // bf16: 0 = fp32 matrix path, 1 = bf16 operands from fp32-stored tensors, 2 = from bf16-stored tensors (HP_FLAG_ACT_BF16)
   const dim3 g(nblocks), th(256);
   const WgradArgs* pr = (const WgradArgs*)d_probs;
   const int4* bl = (const int4*)d_blocks;
+  if (bf16 == 2) {
+    if (ntaps == 1)      hipLaunchKernelGGL((wgrad_group_kernel<1, true, true>), g, th, 0, s, pr, bl);
+    else if (ntaps == 3) hipLaunchKernelGGL((wgrad_group_kernel<3, true, true>), g, th, 0, s, pr, bl);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_group_kernel<1, false>), g, th, 0, s, pr, bl);
   else if (ntaps == 1)          hipLaunchKernelGGL((wgrad_group_kernel<1, true>), g, th, 0, s, pr, bl);
   else if (ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_group_kernel<3, false>), g, th, 0, s, pr, bl);
@@ -1228,6 +1244,13 @@ hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t
   WgradArgs a = wgrad_args_from(op, bases);
   dim3 grid(hp::cdiv(a.t.N, 64) * hp::cdiv(a.t.K, 64), a.nsplit);
   const bool bf16 = op.flags & HP_CONV_BF16;
+  if (op.flags & HP_FLAG_ACT_BF16) {
+    if (!bf16) return hipErrorInvalidValue;
+    if (a.t.ntaps == 1)      hipLaunchKernelGGL((wgrad_taps_kernel<1, true, true>), grid, dim3(256), 0, s, a);
+    else if (a.t.ntaps == 3) hipLaunchKernelGGL((wgrad_taps_kernel<3, true, true>), grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
   if (a.t.ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_taps_kernel<1, false>), grid, dim3(256), 0, s, a);
   else if (a.t.ntaps == 1)          hipLaunchKernelGGL((wgrad_taps_kernel<1, true>), grid, dim3(256), 0, s, a);
   else if (a.t.ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_taps_kernel<3, false>), grid, dim3(256), 0, s, a);

@@ -25,7 +25,7 @@ hipError_t launch_small(const HpOp& op, void* const* bases, hipStream_t s);
 hipError_t launch_conv_pair(const HpOp& a, const HpOp& b, void* const* bases, hipStream_t s);
 hipError_t launch_small_pair(const HpOp& a, const HpOp& b, void* const* bases, hipStream_t s);   // BN family
 hipError_t build_wgrad_group(const HpOp* members, int count, void* const* bases, void** d_probs, void** d_blocks, int* nblocks);
-hipError_t launch_wgrad_group(int ntaps, bool bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s);
+hipError_t launch_wgrad_group(int ntaps, int bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s);
 // small-leaf group (ops_small.hip): independent LINEAR_BWD_W / EMB_BWD records in one launch
 bool groupable(const HpOp& op);
 hipError_t build_small_group(const HpOp* members, int count, void* const* bases, void** d_entries);

@@ -30,6 +30,51 @@ __device__ __forceinline__ float2 gload2(const float* p) {
 __device__ __forceinline__ float gload1(const float* p) { return *(const float __attribute__((address_space(1)))*)(p); }
 __device__ __forceinline__ void gstore1(float* p, float v) { *(float __attribute__((address_space(1)))*)(p) = v; }
 
+// ---- activation storage: fp32 or (HP_FLAG_ACT_BF16 on the op record) bfloat16 -------------------------------------------------------
+// H = true: the tensor holds bf16 (2 bytes per element).  bf16 -> fp32 is a shift (exact); fp32 -> bf16 rounds to nearest even
+// (v_cvt_pk_bf16_f32).  Pointers stay `float*` in the argument structs; element offsets are scaled here.
+typedef unsigned hp_v2u __attribute__((ext_vector_type(2)));
+template <bool H>
+__device__ __forceinline__ float4 aload4p(const char* p) {          // p -> four consecutive elements
+  if (H) {
+    const hp_v2u u = *(const hp_v2u __attribute__((address_space(1)))*)(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  }
+  return gload4(reinterpret_cast<const float*>(p));
+}
+template <bool H>
+__device__ __forceinline__ float4 aload4(const float* base, const size_t idx) {
+  return aload4p<H>(reinterpret_cast<const char*>(base) + idx * (H ? 2 : 4));
+}
+template <bool H>
+__device__ __forceinline__ float aload1(const float* base, const size_t idx) {
+  if (H) {
+    const unsigned short b = *(const unsigned short __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(base) + idx * 2);
+    return __uint_as_float((unsigned)b << 16);
+  }
+  return gload1(base + idx);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(const float v) {
+  const __bf16 h = (__bf16)v;
+  return *reinterpret_cast<const unsigned short*>(&h);
+}
+template <bool H>
+__device__ __forceinline__ void astore1(float* base, const size_t idx, const float v) {
+  if (H) *(unsigned short __attribute__((address_space(1)))*)(reinterpret_cast<char*>(base) + idx * 2) = f32_to_bf16_bits(v);
+  else gstore1(base + idx, v);
+}
+template <bool H>
+__device__ __forceinline__ void astore4(float* base, const size_t idx, const float4 v) {
+  if (H) {
+    hp_v2u u;
+    u.x = (unsigned)f32_to_bf16_bits(v.x) | ((unsigned)f32_to_bf16_bits(v.y) << 16);
+    u.y = (unsigned)f32_to_bf16_bits(v.z) | ((unsigned)f32_to_bf16_bits(v.w) << 16);
+    *(hp_v2u __attribute__((address_space(1)))*)(reinterpret_cast<char*>(base) + idx * 2) = u;
+  } else {
+    gstore4(base + idx, v);
+  }
+}
+
 // blockIdx -> tile id such that each XCD (blocks are dealt round-robin over the 8 XCDs)
 // owns one contiguous run of tile ids: the N-tiles that share an A row-panel then hit the
 // same L2.  Bijective for any nblk.  Speed only; correctness never depends on it.

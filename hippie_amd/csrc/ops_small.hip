@@ -70,6 +70,21 @@ template <> struct Vec<1> { using T = float; };
 template <int V> __device__ __forceinline__ float& at(typename Vec<V>::T& v, int j);
 template <> __device__ __forceinline__ float& at<4>(float4& v, int j) { return (&v.x)[j]; }
 template <> __device__ __forceinline__ float& at<1>(float& v, int) { return v; }
+// V consecutive elements of an activation tensor stored fp32 (H = false) or bf16 (H = true: HP_FLAG_ACT_BF16; only V = 4)
+template <int V, bool H> __device__ __forceinline__ typename Vec<V>::T ldv(const float* base, const size_t idx);
+template <> __device__ __forceinline__ float4 ldv<4, false>(const float* base, const size_t idx) { return *reinterpret_cast<const float4*>(base + idx); }
+template <> __device__ __forceinline__ float4 ldv<4, true>(const float* base, const size_t idx) { return aload4<true>(base, idx); }
+template <> __device__ __forceinline__ float ldv<1, false>(const float* base, const size_t idx) { return base[idx]; }
+template <> __device__ __forceinline__ float ldv<1, true>(const float* base, const size_t idx) { return aload1<true>(base, idx); }
+template <int V, bool H> __device__ __forceinline__ void stv(float* base, const size_t idx, const typename Vec<V>::T v);
+template <> __device__ __forceinline__ void stv<4, false>(float* base, const size_t idx, const float4 v) { *reinterpret_cast<float4*>(base + idx) = v; }
+template <> __device__ __forceinline__ void stv<4, true>(float* base, const size_t idx, const float4 v) { astore4<true>(base, idx, v); }
+template <> __device__ __forceinline__ void stv<1, false>(float* base, const size_t idx, const float v) { base[idx] = v; }
+template <> __device__ __forceinline__ void stv<1, true>(float* base, const size_t idx, const float v) { astore1<true>(base, idx, v); }
+// run-time form for the scalar kernels at the backbones' edges (stem, pool, repeat, tail): `h` is uniform
+__device__ __forceinline__ float ald(const float* base, const size_t idx, const int h) { return h ? aload1<true>(base, idx) : base[idx]; }
+__device__ __forceinline__ void ast(float* base, const size_t idx, const float v, const int h) { if (h) astore1<true>(base, idx, v); else base[idx] = v; }
+__device__ __forceinline__ float4 ald4(const float* base, const size_t idx, const int h) { return h ? aload4<true>(base, idx) : *reinterpret_cast<const float4*>(base + idx); }
 
 template <int V>
 __device__ __forceinline__ ColMap colmap_v(int M, int C, int rpl, int bx, int by) {
@@ -136,6 +151,7 @@ struct BnApplyArgs {
   int M, C, res_mode, training, act;
   int Mstat;          // rows behind the statistics: M, or M * world under sync-BatchNorm (HP_OP_STATS_SYNC)
   float slope, eps, momentum;
+  int abf;            // HP_FLAG_ACT_BF16: RAW, OUT, RES hold bf16
 };
 
 #ifdef HP_BN_TS       // timing experiment (tools/micro/bn_phases.py): 100 MHz timestamps of block 0 / the last block into SAVE2
@@ -147,7 +163,7 @@ struct BnApplyArgs {
 // RES (= BnApplyArgs::res_mode) is a template parameter: with the residual forms as run-time branches the compiler
 // re-read the coefficients from LDS for every row and waited for each row's STORE before touching the next row
 // (vmcnt(0) per row: 1.4 us of serialised store latency per launch, tools/micro/bn_phases.py).
-template <int V, int RES>
+template <int V, int RES, bool H>
 __device__ __forceinline__ void bn_apply_impl(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
   BN_TS(0)
@@ -163,8 +179,8 @@ __device__ __forceinline__ void bn_apply_impl(const BnApplyArgs& p, const int bx
     for (int k = 0; k < NR; ++k) {
       const int r = min(m.row + k * m.rstep, p.M - 1);
       const size_t idx = (size_t)r * p.C + cc;
-      xs[k] = *reinterpret_cast<const T*>(p.raw + idx);
-      if (RES != 0) rs[k] = *reinterpret_cast<const T*>(p.res + idx);
+      xs[k] = ldv<V, H>(p.raw, idx);
+      if (RES != 0) rs[k] = ldv<V, H>(p.res, idx);
     }
   }
   // each channel's (replicated) statistics are summed ONCE per block, not once per thread
@@ -214,24 +230,30 @@ __device__ __forceinline__ void bn_apply_impl(const BnApplyArgs& p, const int bx
 #pragma unroll
     for (int k = 0; k < NR; ++k) {
       const int r = m.row + k * m.rstep;
-      if (r < m.rend) *reinterpret_cast<T*>(p.out + (size_t)r * p.C + m.c) = os[k];
+      if (r < m.rend) stv<V, H>(p.out, (size_t)r * p.C + m.c, os[k]);
     }
     BN_TS(3)
     return;
   }
   for (int r = m.row; r < m.rend; r += m.rstep) {
     const size_t idx = (size_t)r * p.C + m.c;
-    T x = *reinterpret_cast<const T*>(p.raw + idx);
+    T x = ldv<V, H>(p.raw, idx);
     T rsd = x;
-    if (RES != 0) rsd = *reinterpret_cast<const T*>(p.res + idx);
-    *reinterpret_cast<T*>(p.out + idx) = value(x, rsd);
+    if (RES != 0) rsd = ldv<V, H>(p.res, idx);
+    stv<V, H>(p.out, idx, value(x, rsd));
   }
 }
 template <int V>
 __device__ __forceinline__ void bn_apply_body(const BnApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
-  if (p.res_mode == 0) bn_apply_impl<V, 0>(p, bx, by, s_coef);
-  else if (p.res_mode == 1) bn_apply_impl<V, 1>(p, bx, by, s_coef);
-  else bn_apply_impl<V, 2>(p, bx, by, s_coef);
+  if (V == 4 && p.abf) {          // (uniform) activations stored as bf16: HP_FLAG_ACT_BF16
+    if (p.res_mode == 0) bn_apply_impl<V, 0, V == 4>(p, bx, by, s_coef);
+    else if (p.res_mode == 1) bn_apply_impl<V, 1, V == 4>(p, bx, by, s_coef);
+    else bn_apply_impl<V, 2, V == 4>(p, bx, by, s_coef);
+    return;
+  }
+  if (p.res_mode == 0) bn_apply_impl<V, 0, false>(p, bx, by, s_coef);
+  else if (p.res_mode == 1) bn_apply_impl<V, 1, false>(p, bx, by, s_coef);
+  else bn_apply_impl<V, 2, false>(p, bx, by, s_coef);
 }
 // single and paired launch forms (HP_OP_PAIR: two independent ops, one launch, flattened 2-D grids)
 #define HP_BN_KERNELS(NAME, ARGS, SHARED_DECL, SHARED_ARG)                                                        \
@@ -256,6 +278,7 @@ struct BnBwdReduceArgs {
   int M, C, has_second;
   int rpl;               // rows per thread (bn_red_rpl): sets the grid and the number of atomic adds per statistics replica
   float slope;
+  int abf;               // HP_FLAG_ACT_BF16: G1, G2, ACT, GOUT, RAW, RAW2 hold bf16
 };
 // Rows per thread of HP_OP_BN_BWD_REDUCE.  Every workgroup ends in one fp64 atomic per column and statistic; with
 // 8 rows per workgroup a [2048][512] tensor sent 128 adds to each replica address (2 replicas at C = 512) and the
@@ -274,8 +297,8 @@ inline int bn_red_rpl(int M, int C) {
   return kBnRows * nb;
 }
 
-template <int V>
-__device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, const int bx, const int by, double* lds) {
+template <int V, bool H>
+__device__ __forceinline__ void bn_bwd_reduce_impl(const BnBwdReduceArgs& p, const int bx, const int by, double* lds) {
   using T = typename Vec<V>::T;
   const ColMap m = colmap_v<V>(p.M, p.C, p.rpl, bx, by);
   double v[3 * V];
@@ -302,7 +325,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
         v[3 * j + 1] += (double)gv * (double)((at<V>(x, j) - mean[j]) * invstd[j]);
         if (p.has_second) v[3 * j + 2] += (double)gv * (double)((at<V>(x2, j) - mean2[j]) * invstd2[j]);
       }
-      *reinterpret_cast<T*>(p.gout + idx) = g;
+      stv<V, H>(p.gout, idx, g);
     };
     if (V == 4) {
       // batches of kBnRows rows per thread (p.rpl / kBnRows of them): all loads of a batch in flight before the first use
@@ -317,20 +340,20 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
 #pragma unroll
         for (int k = 0; k < NR; ++k) {
           idx[k] = (size_t)min(r0 + k * m.rstep, rlast) * p.C + m.c;
-          g[k] = *reinterpret_cast<const T*>(p.g1 + idx[k]);
-          x[k] = *reinterpret_cast<const T*>(p.raw + idx[k]);
+          g[k] = ldv<V, H>(p.g1, idx[k]);
+          x[k] = ldv<V, H>(p.raw, idx[k]);
         }
         if (!from_raw) {
 #pragma unroll
-          for (int k = 0; k < NR; ++k) a[k] = *reinterpret_cast<const T*>(p.act + idx[k]);
+          for (int k = 0; k < NR; ++k) a[k] = ldv<V, H>(p.act, idx[k]);
         }
         if (p.g2 != nullptr) {
 #pragma unroll
-          for (int k = 0; k < NR; ++k) gg[k] = *reinterpret_cast<const T*>(p.g2 + idx[k]);
+          for (int k = 0; k < NR; ++k) gg[k] = ldv<V, H>(p.g2, idx[k]);
         }
         if (p.has_second) {
 #pragma unroll
-          for (int k = 0; k < NR; ++k) x2[k] = *reinterpret_cast<const T*>(p.raw2 + idx[k]);
+          for (int k = 0; k < NR; ++k) x2[k] = ldv<V, H>(p.raw2, idx[k]);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -342,13 +365,13 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
     } else {
       for (int r = m.row; r < m.rend; r += m.rstep) {
         const size_t idx = (size_t)r * p.C + m.c;
-        T g = *reinterpret_cast<const T*>(p.g1 + idx);
-        T x = *reinterpret_cast<const T*>(p.raw + idx);
+        T g = ldv<V, H>(p.g1, idx);
+        T x = ldv<V, H>(p.raw, idx);
         T a = x;
-        if (!from_raw) a = *reinterpret_cast<const T*>(p.act + idx);
+        if (!from_raw) a = ldv<V, H>(p.act, idx);
         T gg = g, x2 = x;
-        if (p.g2 != nullptr) gg = *reinterpret_cast<const T*>(p.g2 + idx);
-        if (p.has_second) x2 = *reinterpret_cast<const T*>(p.raw2 + idx);
+        if (p.g2 != nullptr) gg = ldv<V, H>(p.g2, idx);
+        if (p.has_second) x2 = ldv<V, H>(p.raw2, idx);
         accumulate(g, a, x, gg, x2, idx);
       }
     }
@@ -373,6 +396,11 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, con
   }
 }
 
+template <int V>
+__device__ __forceinline__ void bn_bwd_reduce_body(const BnBwdReduceArgs& p, const int bx, const int by, double* lds) {
+  if (V == 4 && p.abf) bn_bwd_reduce_impl<V, V == 4>(p, bx, by, lds);      // (uniform) HP_FLAG_ACT_BF16
+  else bn_bwd_reduce_impl<V, false>(p, bx, by, lds);
+}
 HP_BN_KERNELS(bn_bwd_reduce, BnBwdReduceArgs, __shared__ double lds[3 * V * 256], lds)
 
 struct BnBwdApplyArgs {
@@ -381,10 +409,11 @@ struct BnBwdApplyArgs {
   int M, C;
   int Mstat;          // M * world under sync-BatchNorm: BS then holds the sums over all ranks
   float gscale;       // 1 / world: dgamma / dbeta are written so that the data-parallel MEAN of the ranks gives the sum
+  int abf;            // HP_FLAG_ACT_BF16: G, RAW, DR hold bf16
 };
 
-template <int V>
-__device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
+template <int V, bool H>
+__device__ __forceinline__ void bn_bwd_apply_impl(const BnBwdApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
   using T = typename Vec<V>::T;
   const ColMap m = colmap_v<V>(p.M, p.C, bn_rows<V>(p.M, p.C), bx, by);
   constexpr int NR = V == 4 ? kBnRows : 1;          // row loads first: overlaps the statistics round trip (see bn_apply_body)
@@ -395,8 +424,8 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
       const int r = m.row + k * m.rstep;
       if (m.active && r < m.rend) {
         const size_t idx = (size_t)r * p.C + m.c;
-        xs[k] = *reinterpret_cast<const T*>(p.raw + idx);
-        gs[k] = *reinterpret_cast<const T*>(p.g + idx);
+        xs[k] = ldv<V, H>(p.raw, idx);
+        gs[k] = ldv<V, H>(p.g, idx);
       }
     }
   }
@@ -420,7 +449,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
     T o;
 #pragma unroll
     for (int j = 0; j < V; ++j) at<V>(o, j) = bn_dr(at<V>(g, j), at<V>(x, j), cA[j], cB[j], cC[j]);
-    *reinterpret_cast<T*>(p.dr + idx) = o;
+    stv<V, H>(p.dr, idx, o);
   };
   if (V == 4) {
 #pragma unroll
@@ -432,14 +461,19 @@ __device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const
   }
   for (int r = m.row; r < m.rend; r += m.rstep) {
     const size_t idx = (size_t)r * p.C + m.c;
-    apply(*reinterpret_cast<const T*>(p.raw + idx), *reinterpret_cast<const T*>(p.g + idx), idx);
+    apply(ldv<V, H>(p.raw, idx), ldv<V, H>(p.g, idx), idx);
   }
 }
 
+template <int V>
+__device__ __forceinline__ void bn_bwd_apply_body(const BnBwdApplyArgs& p, const int bx, const int by, float (*s_coef)[256 * V]) {
+  if (V == 4 && p.abf) bn_bwd_apply_impl<V, V == 4>(p, bx, by, s_coef);      // (uniform) HP_FLAG_ACT_BF16
+  else bn_bwd_apply_impl<V, false>(p, bx, by, s_coef);
+}
 HP_BN_KERNELS(bn_bwd_apply, BnBwdApplyArgs, __shared__ float s_coef[5][256 * V], s_coef)   // mean, invstd, c1, c2, gamma*invstd
 
 // ---- stem conv (C_in = 1) --------------------------------------------------------
-struct StemArgs { const float* x; const float* w; float* out; double* stats; const float* dr; float* dw; int B, Lin, Lout, C; };
+struct StemArgs { const float* x; const float* w; float* out; double* stats; const float* dr; float* dw; int B, Lin, Lout, C; int abf; };
 
 __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs p) {
   __shared__ double lds[2 * 256];
@@ -456,7 +490,7 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(StemArgs p) {
       const float x1 = xb[j + 1];
       const float x2 = (j + 2 < p.Lin) ? xb[j + 2] : 0.f;
       const float o = fmaf(x2, w2, fmaf(x1, w1, x0 * w0));
-      p.out[(size_t)r * p.C + m.c] = o;
+      ast(p.out, (size_t)r * p.C + m.c, o, p.abf);
       v[0] += (double)o;
       v[1] += (double)o * (double)o;
     }
@@ -503,7 +537,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_kernel(StemArgs p, int rows) {
         const int b = rr / p.Lout, l = rr - b * p.Lout;
         const float* xb = p.x + (size_t)b * p.Lin;
         const int j = 2 * l - 1;
-        d[k] = ok ? p.dr[(size_t)rr * p.C + m.c] : 0.f;
+        d[k] = ok ? ald(p.dr, (size_t)rr * p.C + m.c, p.abf) : 0.f;
         x0[k] = j >= 0 ? xb[j] : 0.f;
         x1[k] = xb[j + 1];
         x2[k] = j + 2 < p.Lin ? xb[j + 2] : 0.f;
@@ -548,7 +582,7 @@ __global__ __launch_bounds__(256) void stem_wgrad4_kernel(StemArgs p, int rows) 
         const int b = rr / p.Lout, l = rr - b * p.Lout;
         const float* xb = p.x + (size_t)b * p.Lin;
         const int j = 2 * l - 1;
-        d[k] = *reinterpret_cast<const float4*>(p.dr + (size_t)rr * p.C + m.c);
+        d[k] = ald4(p.dr, (size_t)rr * p.C + m.c, p.abf);
         if (!ok) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         x0[k] = j >= 0 ? xb[j] : 0.f;
         x1[k] = xb[j + 1];
@@ -579,37 +613,37 @@ __global__ __launch_bounds__(256) void stem_wgrad4_kernel(StemArgs p, int rows) 
 }
 
 // ---- pool / repeat ---------------------------------------------------------------
-__global__ void pool_fwd_kernel(const float* in, float* out, int B, int L, int C) {
+__global__ void pool_fwd_kernel(const float* in, float* out, int B, int L, int C, int abf) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * C) return;
   const int b = idx / C, c = idx - b * C;
   float s = 0.f;
-  for (int l = 0; l < L; ++l) s += in[((size_t)b * L + l) * C + c];
+  for (int l = 0; l < L; ++l) s += ald(in, ((size_t)b * L + l) * C + c, abf);
   out[idx] = s / (float)L;
 }
-__global__ void pool_bwd_kernel(const float* d, float* g, int B, int L, int C) {
+__global__ void pool_bwd_kernel(const float* d, float* g, int B, int L, int C, int abf) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * L * C) return;
   const int c = idx % C;
   const int b = (idx / C) / L;
-  g[idx] = d[(size_t)b * C + c] / (float)L;
+  ast(g, idx, d[(size_t)b * C + c] / (float)L, abf);
 }
-__global__ void repeat_fwd_kernel(const float* in, float* out, int B, int R, int C) {
+__global__ void repeat_fwd_kernel(const float* in, float* out, int B, int R, int C, int abf) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)B * R * C) return;
   const int c = idx % C;
   const int b = (idx / C) / R;
-  out[idx] = in[(size_t)b * C + c];
+  ast(out, idx, in[(size_t)b * C + c], abf);
 }
-__global__ void repeat_bwd_kernel(const float* g1, const float* g2, float* d, int B, int R, int C) {
+__global__ void repeat_bwd_kernel(const float* g1, const float* g2, float* d, int B, int R, int C, int abf) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * C) return;
   const int b = idx / C, c = idx - b * C;
   float s = 0.f;
   for (int l = 0; l < R; ++l) {
     const size_t j = ((size_t)b * R + l) * C + c;
-    s += g1[j];
-    if (g2 != nullptr) s += g2[j];
+    s += ald(g1, j, abf);
+    if (g2 != nullptr) s += ald(g2, j, abf);
   }
   d[idx] = s;
 }
@@ -933,7 +967,7 @@ __device__ __forceinline__ void loss_finalize_body(const LossArgs& p) {
 __global__ void loss_finalize_kernel(LossArgs p) { if (blockIdx.x == 0) loss_finalize_body(p); }
 
 // ---- decoder tail (C_out = 1) -----------------------------------------------------
-__global__ void tail_fwd_kernel(const float* act, const float* w, const float* bias, float* out, int B, int Lh, int C) {
+__global__ void tail_fwd_kernel(const float* act, const float* w, const float* bias, float* out, int B, int Lh, int C, int abf) {
   const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
   const int Lo = 2 * Lh;
   if (wid >= B * Lo) return;
@@ -942,13 +976,13 @@ __global__ void tail_fwd_kernel(const float* act, const float* w, const float* b
   for (int t = 0; t < 3; ++t) {
     const int u = pz + t - 1;
     if (u < 0 || u >= Lo) continue;
-    const float* row = act + ((size_t)b * Lh + (u >> 1)) * C;
-    for (int c = lane; c < C; c += 64) s = fmaf(row[c], w[c * 3 + t], s);
+    const size_t row = ((size_t)b * Lh + (u >> 1)) * C;
+    for (int c = lane; c < C; c += 64) s = fmaf(ald(act, row + c, abf), w[c * 3 + t], s);
   }
   s = wave_sum(s);
   if (lane == 0) out[wid] = s + bias[0];
 }
-__global__ void tail_bwd_x_kernel(const float* dt, const float* w, float* dact, int B, int Lh, int C) {
+__global__ void tail_bwd_x_kernel(const float* dt, const float* w, float* dact, int B, int Lh, int C, int abf) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= (size_t)B * Lh * C) return;
   const int c = id % C;
@@ -962,13 +996,13 @@ __global__ void tail_bwd_x_kernel(const float* dt, const float* w, float* dact, 
       const int q = 2 * j + e - t + 1;
       if (q >= 0 && q < Lo) s = fmaf(d[q], w[c * 3 + t], s);
     }
-  dact[id] = s;
+  ast(dact, id, s, abf);
 }
 // dw[c][t] = sum_{b,h} act[b,h,c] * D_t[b,h] with D_t[b,h] = dt[b][2h+1-t] + dt[b][2h+2-t] (in range), db = sum dt.
 // thread = (channel, row lane); kTailRows rows (b,h) per thread, loaded in batches of 8 before use (a per-row
 // load -> use loop is one dependent memory round trip per row); fp32 atomics into zeroed DW/DB.
 constexpr int kTailRows = 32;
-__global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int rows) {
+__global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int rows, int abf) {
   __shared__ double lds[4 * 256];
   const int cw = C < 256 ? C : 256, rl = 256 / cw;
   const int tid = threadIdx.x, rlane = tid / cw;
@@ -988,7 +1022,7 @@ __global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const 
         const int rr = ok[k] ? r : M - 1;
         const int b = rr / Lh, h = rr - b * Lh;
         const float* dtb = dt + (size_t)b * Lo + 2 * h;
-        a[k] = act[(size_t)rr * C + c];
+        a[k] = ald(act, (size_t)rr * C + c, abf);
         d0[k] = h > 0 ? dtb[-1] : 0.f;
         d1[k] = dtb[0];
         d2[k] = dtb[1];
@@ -1023,7 +1057,7 @@ __global__ __launch_bounds__(256) void tail_bwd_w_kernel(const float* dt, const 
 }
 // float4 form of the same reduction (C a multiple of 4): 16 row lanes x 16 rows per thread (see stem_wgrad4_kernel)
 constexpr int kTailRows4 = 16;
-__global__ __launch_bounds__(256) void tail_bwd_w4_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int rows) {
+__global__ __launch_bounds__(256) void tail_bwd_w4_kernel(const float* dt, const float* act, float* dw, float* db, int B, int Lh, int C, int rows, int abf) {
   __shared__ double lds[13 * 256];
   const int M = B * Lh, Lo = 2 * Lh;
   const ColMap m = colmap_v<4>(M, C, rows, blockIdx.x, blockIdx.y);
@@ -1042,7 +1076,7 @@ __global__ __launch_bounds__(256) void tail_bwd_w4_kernel(const float* dt, const
         const int rr = ok[k] ? r : m.rend - 1;
         const int b = rr / Lh, h = rr - b * Lh;
         const float* dtb = dt + (size_t)b * Lo + 2 * h;
-        a[k] = *reinterpret_cast<const float4*>(act + (size_t)rr * C + m.c);
+        a[k] = ald4(act, (size_t)rr * C + m.c, abf);
         d0[k] = h > 0 ? dtb[-1] : 0.f;
         d1[k] = dtb[0];
         d2[k] = dtb[1];
@@ -1353,6 +1387,7 @@ BnApplyArgs bn_apply_args(const HpOp& op, void* const* bases) {
   a.M = I[0]; a.C = I[1]; a.res_mode = I[2]; a.training = I[3]; a.act = I[4];
   a.Mstat = I[0] * (I[5] > 1 ? I[5] : 1);
   a.slope = op.f[0]; a.eps = op.f[1]; a.momentum = op.f[2];
+  a.abf = (op.flags & HP_FLAG_ACT_BF16) ? 1 : 0;
   return a;
 }
 BnBwdReduceArgs bn_bwd_reduce_args(const HpOp& op, void* const* bases) {
@@ -1366,6 +1401,7 @@ BnBwdReduceArgs bn_bwd_reduce_args(const HpOp& op, void* const* bases) {
   a.coef = ptr<const float>(op, 10, bases);
   a.M = I[0]; a.C = I[1]; a.has_second = I[3]; a.slope = op.f[0];
   a.rpl = bn_red_rpl(a.M, a.C);
+  a.abf = (op.flags & HP_FLAG_ACT_BF16) ? 1 : 0;
   return a;
 }
 BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
@@ -1377,6 +1413,7 @@ BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
   a.M = op.i[0]; a.C = op.i[1];
   const int w = op.i[2] > 1 ? op.i[2] : 1;
   a.Mstat = a.M * w; a.gscale = 1.f / (float)w;
+  a.abf = (op.flags & HP_FLAG_ACT_BF16) ? 1 : 0;
   return a;
 }
 
@@ -1517,6 +1554,7 @@ hipError_t hp::launch_small_pair(const HpOp& opa, const HpOp& opb, void* const* 
 hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
   using hp::ptr;
   const int32_t* I = op.i;
+  const int abf = (op.flags & HP_FLAG_ACT_BF16) ? 1 : 0;      // activation-typed buffers hold bf16 (include/hippie_hip.h)
   switch (op.op) {
     case HP_OP_SLAB_REDUCE: {
       const int n = I[0];
@@ -1545,14 +1583,14 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     case HP_OP_STEM_FWD: {
       StemArgs a{};
       a.x = ptr<const float>(op, 0, bases); a.w = ptr<const float>(op, 1, bases); a.out = ptr<float>(op, 2, bases);
-      a.stats = ptr<double>(op, 3, bases); a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3];
+      a.stats = ptr<double>(op, 3, bases); a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3]; a.abf = (op.flags & HP_FLAG_ACT_BF16) ? 1 : 0;
       hipLaunchKernelGGL(stem_fwd_kernel, colgrid(a.B * a.Lout, a.C), dim3(256), 0, s, a);
       break;
     }
     case HP_OP_STEM_WGRAD: {
       StemArgs a{};
       a.dr = ptr<const float>(op, 0, bases); a.x = ptr<const float>(op, 1, bases); a.dw = ptr<float>(op, 2, bases);
-      a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3];
+      a.B = I[0]; a.Lin = I[1]; a.Lout = I[2]; a.C = I[3]; a.abf = (op.flags & HP_FLAG_ACT_BF16) ? 1 : 0;
       if (a.C % 4 == 0) {
         // flags & 1: ONE workgroup per column group walks all rows — no cross-workgroup atomics, bit-reproducible
         const int rows = (op.flags & 1) ? hp::cdiv(hp::cdiv(a.B * a.Lout, 16), 8) * 8 : small_wgrad_rows(kStemRows4);
@@ -1565,20 +1603,20 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     }
     case HP_OP_POOL_FWD:
       hipLaunchKernelGGL(pool_fwd_kernel, dim3(blocks_for((int64_t)I[0] * I[2])), dim3(256), 0, s,
-                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2]);
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2], abf);
       break;
     case HP_OP_POOL_BWD:
       hipLaunchKernelGGL(pool_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1] * I[2])), dim3(256), 0, s,
-                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2]);
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2], abf);
       break;
     case HP_OP_REPEAT_FWD:
       hipLaunchKernelGGL(repeat_fwd_kernel, dim3(blocks_for((int64_t)I[0] * I[1] * I[2])), dim3(256), 0, s,
-                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2]);
+                         ptr<const float>(op, 0, bases), ptr<float>(op, 1, bases), I[0], I[1], I[2], abf);
       break;
     case HP_OP_REPEAT_BWD:
       hipLaunchKernelGGL(repeat_bwd_kernel, dim3(blocks_for((int64_t)I[0] * I[2])), dim3(256), 0, s,
                          ptr<const float>(op, 0, bases), I[3] ? ptr<const float>(op, 1, bases) : nullptr,
-                         ptr<float>(op, 2, bases), I[0], I[1], I[2]);
+                         ptr<float>(op, 2, bases), I[0], I[1], I[2], abf);
       break;
     case HP_OP_CONCAT: {
       ConcatArgs a{};
@@ -1674,24 +1712,24 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
     case HP_OP_TAIL_FWD:
       hipLaunchKernelGGL(tail_fwd_kernel, dim3(blocks_for((int64_t)I[0] * 2 * I[1], 4)), dim3(256), 0, s,
                          ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<const float>(op, 2, bases),
-                         ptr<float>(op, 3, bases), I[0], I[1], I[2]);
+                         ptr<float>(op, 3, bases), I[0], I[1], I[2], abf);
       break;
     case HP_OP_TAIL_BWD_X:
       hipLaunchKernelGGL(tail_bwd_x_kernel, dim3(blocks_for((int64_t)I[0] * I[1] * I[2])), dim3(256), 0, s,
-                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2]);
+                         ptr<const float>(op, 0, bases), ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2], abf);
       break;
     case HP_OP_TAIL_BWD_W: {
       const int cw = I[2] < 256 ? I[2] : 256;
       if (I[2] % 4 == 0) {
         const int rows = (op.flags & 1) ? hp::cdiv(hp::cdiv(I[0] * I[1], 16), 8) * 8 : small_wgrad_rows(kTailRows4);      // flags & 1: see STEM_WGRAD
         hipLaunchKernelGGL(tail_bwd_w4_kernel, colgrid_v<4>(I[0] * I[1], I[2], rows), dim3(256), 0, s, ptr<const float>(op, 0, bases),
-                           ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], rows);
+                           ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], rows, abf);
         break;
       }
       const int rows = small_wgrad_rows(kTailRows);
       const dim3 grid(hp::cdiv(I[0] * I[1], (256 / cw) * rows), hp::cdiv(I[2], cw));
       hipLaunchKernelGGL(tail_bwd_w_kernel, grid, dim3(256), 0, s, ptr<const float>(op, 0, bases),
-                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], rows);
+                         ptr<const float>(op, 1, bases), ptr<float>(op, 2, bases), ptr<float>(op, 3, bases), I[0], I[1], I[2], rows, abf);
       break;
     }
     case HP_OP_LOSS_FINALIZE: {

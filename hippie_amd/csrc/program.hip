@@ -13,7 +13,7 @@ struct HpProgram {
   std::vector<hipGraphExec_t> segs;
   std::vector<hipGraph_t> graphs;
   hipStream_t capture_stream = nullptr;
-  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; bool bf16 = false; void* leaves = nullptr; int n_leaves = 0; };
+  struct Group { void* probs = nullptr; void* blocks = nullptr; int nblocks = 0; int ntaps = 0; int bf16 = 0; void* leaves = nullptr; int n_leaves = 0; };
   std::vector<Group> groups;          // indexed by op index (empty entries for ops without device tables)
   bool groups_ready = false;
 };
@@ -57,7 +57,7 @@ int ensure_groups(HpProgram* p) {
       e = hp::build_small_group(&p->ops[k - ngroup], ngroup + 1, p->bases, &g.leaves);
     } else if (op.op == HP_OP_WGRAD_GROUP) {
       g.ntaps = op.i[2];
-      g.bf16 = (p->ops[op.i[0]].flags & HP_CONV_BF16) != 0;
+      g.bf16 = (p->ops[op.i[0]].flags & HP_CONV_BF16) ? ((p->ops[op.i[0]].flags & HP_FLAG_ACT_BF16) ? 2 : 1) : 0;
       e = hp::build_wgrad_group(&p->ops[op.i[0]], op.i[1], p->bases, &g.probs, &g.blocks, &g.nblocks);
     }
     if (e != hipSuccess) {
@@ -267,6 +267,17 @@ int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
     }
     default: break;
   }
+  if (op.flags & HP_FLAG_ACT_BF16) {
+    // the op's activation-typed buffers hold bf16: half the bytes (which buffers: include/hippie_hip.h, HP_FLAG_ACT_BF16)
+    static const struct { int op; int slots[8]; } kAct[] = {
+      {HP_OP_CONV_TAPS, {0, 10, 2, 9, 15, 16, 17, 21}}, {HP_OP_WGRAD_TAPS, {0, 1, -1}}, {HP_OP_BN_APPLY, {0, 1, 8, -1}},
+      {HP_OP_BN_BWD_REDUCE, {0, 1, 2, 3, 4, 7, -1}}, {HP_OP_BN_BWD_APPLY, {0, 1, 5, -1}}, {HP_OP_STEM_FWD, {2, -1}}, {HP_OP_STEM_WGRAD, {0, -1}},
+      {HP_OP_POOL_FWD, {0, -1}}, {HP_OP_POOL_BWD, {1, -1}}, {HP_OP_REPEAT_FWD, {1, -1}}, {HP_OP_REPEAT_BWD, {0, 1, -1}},
+      {HP_OP_TAIL_FWD, {0, -1}}, {HP_OP_TAIL_BWD_X, {2, -1}}, {HP_OP_TAIL_BWD_W, {1, -1}}};
+    for (const auto& e : kAct)
+      if (e.op == op.op)
+        for (int k = 0; k < 8 && e.slots[k] >= 0; ++k) need[e.slots[k]] /= 2;
+  }
   return 0;
 }
 
@@ -314,6 +325,20 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
            (int64_t)op.i[22] * op.i[23] >= M && (!(op.flags & HP_CONV_IN_BN) || (op.f[0] >= 0.f && op.f[0] <= 1.f));
     if (!ok) {
       snprintf(buf, sizeof buf, "op %d (opcode %d): bad tap-map shape M=%d N=%d K=%d ntaps=%d", index, op.op, M, N, K, nt);
+      why = buf;
+      return 1;
+    }
+  }
+  if (op.flags & HP_FLAG_ACT_BF16) {
+    const int o = op.op;
+    const bool typed = o == HP_OP_CONV_TAPS || o == HP_OP_WGRAD_TAPS || o == HP_OP_BN_APPLY || o == HP_OP_BN_BWD_REDUCE || o == HP_OP_BN_BWD_APPLY ||
+                       o == HP_OP_STEM_FWD || o == HP_OP_STEM_WGRAD || o == HP_OP_POOL_FWD || o == HP_OP_POOL_BWD || o == HP_OP_REPEAT_FWD ||
+                       o == HP_OP_REPEAT_BWD || o == HP_OP_TAIL_FWD || o == HP_OP_TAIL_BWD_X || o == HP_OP_TAIL_BWD_W;
+    const bool bn = o == HP_OP_BN_APPLY || o == HP_OP_BN_BWD_REDUCE || o == HP_OP_BN_BWD_APPLY;
+    const bool mm = o == HP_OP_CONV_TAPS || o == HP_OP_WGRAD_TAPS;
+    if (!typed || (bn && (op.i[1] % 4) != 0) || (mm && !(op.flags & HP_CONV_BF16))) {
+      snprintf(buf, sizeof buf, "op %d (opcode %d): HP_FLAG_ACT_BF16 needs an op with activation-typed buffers (BatchNorm ops: channels %% 4 == 0; "
+               "CONV_TAPS / WGRAD_TAPS: HP_CONV_BF16)", index, op.op);
       why = buf;
       return 1;
     }
@@ -400,6 +425,7 @@ int hp_program_validate(const HpProgram* p) {
       const HpOp& a = p->ops[g.i[0]];
       const HpOp& b = p->ops[g.i[1]];
       const bool kind_ok = a.op == b.op && (a.flags & HP_FLAG_MEMBER) && (b.flags & HP_FLAG_MEMBER) &&
+                           (a.flags & HP_FLAG_ACT_BF16) == (b.flags & HP_FLAG_ACT_BF16) &&
                            ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & HP_CONV_BF16) == (b.flags & HP_CONV_BF16)) ||
                             ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
                              (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
@@ -427,7 +453,7 @@ int hp_program_validate(const HpProgram* p) {
       for (int j = g.i[0]; j < g.i[0] + g.i[1]; ++j) {
         const HpOp& m = p->ops[j];
         if (m.op != HP_OP_WGRAD_TAPS || !(m.flags & HP_FLAG_MEMBER) || !(m.flags & 1) || m.i[9] != g.i[2] ||
-            (m.flags & HP_CONV_BF16) != (p->ops[g.i[0]].flags & HP_CONV_BF16))
+            (m.flags & (HP_CONV_BF16 | HP_FLAG_ACT_BF16)) != (p->ops[g.i[0]].flags & (HP_CONV_BF16 | HP_FLAG_ACT_BF16)))
           return fail("wgrad group member " + std::to_string(j) + " is not an atomic WGRAD_TAPS member with matching taps");
       }
     }

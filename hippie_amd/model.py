@@ -61,6 +61,8 @@ class _Net:
         # collective after the pass — wave + time pair / multimodal at batch 512 / at batch 8192)
         self.ddp_bucketed = False
         self.precision = "f32"
+        self.bf16_storage = False          # precision "bf16": True also STORES the backbones' activations as bf16 (TrainCfg.act_dtype: a third less
+                                           # workspace, slower as the kernels stand); False rounds only the matrix operands
 
     # -- engine cache -----------------------------------------------------------------
     def engine(self, batch, with_class) -> Engine:
@@ -93,7 +95,7 @@ class _Net:
         if (self.deterministic or torch.are_deterministic_algorithms_enabled()) and not train_cfg.deterministic_wgrad:
             train_cfg = replace(train_cfg, deterministic_wgrad=True)
         # network-level settings survive every re-lowering of the optimiser constants
-        train_cfg = replace(train_cfg, mfma_dtype=self.precision, bucketed_bwd=bool(self.ddp_bucketed) and self.dp_world > 1,
+        train_cfg = replace(train_cfg, mfma_dtype=self.precision, act_dtype="bf16" if (self.precision == "bf16" and self.bf16_storage) else "f32", bucketed_bwd=bool(self.ddp_bucketed) and self.dp_world > 1,
                             sync_bn_world=self.dp_world if (self.sync_batchnorm and self.dp_world > 1) else 0)
         self._train_cfg = train_cfg
         keep = self._root

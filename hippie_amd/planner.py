@@ -80,6 +80,11 @@ class TrainCfg:
                                         # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
                                         # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
                                         # weights and AdamW stay fp32.  Own tolerance (tests/test_gpu_bf16.py), own bench line
+    act_dtype: str = "f32"              # "bf16" (needs mfma_dtype="bf16"): the backbones' activation tensors and their gradients — every
+                                        # [rows][channels] tensor between stem and pool, decoder.linear and tail, of the TRAINING passes — are
+                                        # STORED as bfloat16 (HP_FLAG_ACT_BF16 on the ops that touch them); statistics, coefficients, weights,
+                                        # the heads and the evaluation forward stay fp32.  At batch >= 4096 every layer below 512 channels is
+                                        # bound by activation traffic once the products run on the bf16 matrix cores
     group_small_wgrads: bool = True     # the small weight-gradient reductions of a backward pass (the heads' Linear dW/db, the embedding
                                         # tables) are leaves: deferred to the end of the pass and run side by side in ONE launch
                                         # (HP_FLAG_GROUP) instead of ten launches of ~3 us each
@@ -231,6 +236,9 @@ class Lowering:
         if self.train.mfma_dtype not in ("f32", "bf16"):
             raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', not {self.train.mfma_dtype!r}")
         self.mm_flag = P.CONV_BF16 if self.train.mfma_dtype == "bf16" else 0
+        if self.train.act_dtype not in ("f32", "bf16") or (self.train.act_dtype == "bf16" and self.train.mfma_dtype != "bf16"):
+            raise ValueError("act_dtype must be 'f32' or 'bf16', and 'bf16' needs mfma_dtype='bf16'")
+        self.abf = False                     # set per pass by build(): the training passes of an act_dtype="bf16" lowering
         # deterministic_wgrad also covers the small weight-gradient reductions (stem, tail, the heads' linears): flags & 1
         # = one workgroup per output group, no cross-workgroup atomics
         self.det_flag = 1 if self.train.deterministic_wgrad else 0
@@ -314,6 +322,16 @@ class Lowering:
         assert wv.offset == wm.offset + z * z and bv.offset == bm.offset + z
         return dict(w=wm, b=bm, N=2 * z, K=z)
 
+    # ---- activation storage (TrainCfg.act_dtype) ------------------------------------------------
+    @property
+    def aflag(self):
+        """HP_FLAG_ACT_BF16 while the pass being emitted stores its backbone activations as bfloat16"""
+        return P.FLAG_ACT_BF16 if self.abf else 0
+
+    def A(self, n):
+        """workspace for an n-element backbone activation / activation-gradient tensor in the pass's storage type"""
+        return self.pl.ws(2 * n) if self.abf else self.pl.f32(n)
+
     # ---- op emitters --------------------------------------------------------------
     def conv(self, tm: TapMap, a, w: PInfo, out, bias=None, stats=None, w_kn=False, note="", a2=None, w2: PInfo = None,
              in_bn=None, epi=None):
@@ -321,7 +339,7 @@ class Lowering:
         the loader (HP_CONV_IN_BN).  epi = a reduction spec (red_spec): HP_OP_BN_BWD_REDUCE fused into the epilogue,
         `out` must be the spec's g tensor."""
         flags = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias is not None else 0) | (P.CONV_STATS if stats is not None else 0)
-        flags |= self.mm_flag
+        flags |= self.mm_flag | self.aflag
         ii = tm.conv_ints() + [0, 0]
         ff = [0.0] * 6
         bufs = [a, w.ref, out, bias.ref if bias is not None else None, stats] + [None] * 19
@@ -451,7 +469,7 @@ class Lowering:
     def wgrad(self, tm: TapMap, dy, x, w: PInfo, note="", coef=None):
         """coef: x is the raw input of a BatchNorm whose activation was never stored (HP_CONV_IN_BN on the forward
         conv): the kernel re-evaluates leaky_relu(fma(x, scale, shift)) from (scale, shift) = coef."""
-        xf = (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag
+        xf = (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag | self.aflag
         tiles = -(-tm.N // 64) * -(-tm.K // 64)
         if self.train.grouped_wgrad and not self.train.deterministic_wgrad:
             # deferred: all wgrads of the backward pass run in one grouped launch at its end.  With the
@@ -523,7 +541,8 @@ class Lowering:
         self.o.notes[k] += " + " + bn["prefix"] + " (eval BN folded)"
         return True
 
-    def bn_apply(self, M, bn, raw, out, stats, training, act, slope, res_mode=0, res=None, bn2=None, stats2=None):
+    def bn_apply(self, M, bn, raw, out, stats, training, act, slope, res_mode=0, res=None, bn2=None, stats2=None, heads=False):
+        """heads=True: one of the heads' BatchNorms (fp32 tensors whatever the backbones' storage type)"""
         if not training and self.train.fold_eval_bn:
             if res_mode == 2:
                 # the shortcut conv normalises its own output in place, then it is a plain residual tensor
@@ -549,7 +568,7 @@ class Lowering:
                 self.stats_sync(stats2, bn2["C"], bn2["prefix"])
         if training and act:
             self.pl.act_sites.append(dict(key=bn["prefix"], M=M, C=bn["C"], kind="tensor", out=out))
-        self.o.add(P.BN_APPLY, 0, i=[M, bn["C"], res_mode, 1 if training else 0, 1 if act else 0, W],
+        self.o.add(P.BN_APPLY, 0 if heads else self.aflag, i=[M, bn["C"], res_mode, 1 if training else 0, 1 if act else 0, W],
                    f=[slope, BN_EPS, BN_MOMENTUM], buf=bufs, note=bn["prefix"])
 
     def stats_sync(self, slot, C, prefix):
@@ -558,12 +577,13 @@ class Lowering:
 
     # BatchNorm backward = a reduction (mask, sum g, sum g*xhat) + an apply.  The reduction either runs as its own
     # launch (reduce_op) or in the epilogue of the input-gradient conv that produces its operand (conv(epi=spec)).
-    def red_spec(self, M, bn, act, raw, g2=None, bn_b=None, raw_b=None, slope=SLOPE_BACKBONE):
-        """act None: the activation was never stored (HP_CONV_IN_BN consumer); its sign comes from raw + bn["coef"]."""
+    def red_spec(self, M, bn, act, raw, g2=None, bn_b=None, raw_b=None, slope=SLOPE_BACKBONE, heads=False):
+        """act None: the activation was never stored (HP_CONV_IN_BN consumer); its sign comes from raw + bn["coef"].
+        heads: one of the heads' BatchNorms (fp32 tensors whatever the backbones' storage type)."""
         C = bn["C"]
-        return dict(M=M, C=C, bn=bn, act=act, raw=raw, g2=g2, bn_b=bn_b, raw_b=raw_b, slope=slope,
+        return dict(M=M, C=C, bn=bn, act=act, raw=raw, g2=g2, bn_b=bn_b, raw_b=raw_b, slope=slope, heads=heads,
                     coef=bn["coef"] if act is None else None,
-                    g=self.pl.f32(M * C), bs=self.pl.stat(2 * C), bs_b=self.pl.stat(2 * C) if bn_b is not None else None)
+                    g=self.pl.f32(M * C) if heads else self.A(M * C), bs=self.pl.stat(2 * C), bs_b=self.pl.stat(2 * C) if bn_b is not None else None)
 
     def reduce_sync(self, sp):
         if self.train.sync_bn_world > 1:
@@ -575,27 +595,28 @@ class Lowering:
         bn, bn_b = sp["bn"], sp["bn_b"]
         bufs = [g1, sp["g2"], sp["act"], sp["g"], sp["raw"], bn["save"], sp["bs"],
                 sp["raw_b"], bn_b["save"] if bn_b is not None else None, sp["bs_b"], sp["coef"]]
-        self.o.add(P.BN_BWD_REDUCE, 0, i=[sp["M"], sp["C"], 1 if sp["g2"] is not None else 0, 1 if bn_b is not None else 0],
+        self.o.add(P.BN_BWD_REDUCE, 0 if sp["heads"] else self.aflag, i=[sp["M"], sp["C"], 1 if sp["g2"] is not None else 0, 1 if bn_b is not None else 0],
                    f=[sp["slope"]], buf=bufs, note=bn["prefix"] + " bwd-reduce")
         self.reduce_sync(sp)
 
     def apply_op(self, sp):
         """-> (dr, dr_b): gradients of the BatchNorm inputs (conv outputs)."""
         M, C, bn, bn_b, W = sp["M"], sp["C"], sp["bn"], sp["bn_b"], self.train.sync_bn_world
-        dr = self.pl.f32(M * C)
-        self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[sp["g"], sp["raw"], bn["save"], sp["bs"], bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
+        af = 0 if sp["heads"] else self.aflag
+        dr = self.pl.f32(M * C) if sp["heads"] else self.A(M * C)
+        self.o.add(P.BN_BWD_APPLY, af, i=[M, C, W], buf=[sp["g"], sp["raw"], bn["save"], sp["bs"], bn["gamma"].ref, dr, bn["gamma"].gref, bn["beta"].gref],
                    note=bn["prefix"] + " bwd-apply")
         dr_b = None
         if bn_b is not None:
-            dr_b = self.pl.f32(M * C)
-            self.o.add(P.BN_BWD_APPLY, 0, i=[M, C, W], buf=[sp["g"], sp["raw_b"], bn_b["save"], sp["bs_b"], bn_b["gamma"].ref, dr_b,
+            dr_b = self.pl.f32(M * C) if sp["heads"] else self.A(M * C)
+            self.o.add(P.BN_BWD_APPLY, af, i=[M, C, W], buf=[sp["g"], sp["raw_b"], bn_b["save"], sp["bs_b"], bn_b["gamma"].ref, dr_b,
                                                          bn_b["gamma"].gref, bn_b["beta"].gref], note=bn_b["prefix"] + " bwd-apply")
             self.pair_last_two("pair " + bn["prefix"] + " + shortcut bwd-apply")
         return dr, dr_b
 
-    def bn_bwd(self, M, bn, g1, g2, act, raw, slope, bn_b=None, raw_b=None):
+    def bn_bwd(self, M, bn, g1, g2, act, raw, slope, bn_b=None, raw_b=None, heads=False):
         """standalone reduce + apply; returns (g, dr, dr_b): masked upstream gradient and BN input gradients."""
-        sp = self.red_spec(M, bn, act, raw, g2, bn_b, raw_b, slope)
+        sp = self.red_spec(M, bn, act, raw, g2, bn_b, raw_b, slope, heads=heads)
         self.reduce_op(sp, g1)
         dr, dr_b = self.apply_op(sp)
         return sp["g"], dr, dr_b
@@ -606,7 +627,7 @@ class Lowering:
             self.conv(tm, dr, w, sp["g"], w_kn=True, epi=sp, note=note)
             self.reduce_sync(sp)
         else:
-            tmp = self.pl.f32(tm.out_rows * tm.N)
+            tmp = self.A(tm.out_rows * tm.N)
             self.conv(tm, dr, w, tmp, w_kn=True, note=note)
             self.reduce_op(sp, tmp)
 
@@ -663,19 +684,19 @@ class Lowering:
         pl, B = self.pl, self.B
         L1 = (L + 2 - 3) // 2 + 1
         M = B * L1
-        raw0 = pl.f32(M * 64)
+        raw0 = self.A(M * 64)
         st = pl.stat(128) if training else None
-        self.o.add(P.STEM_FWD, 0, i=[B, L, L1, 64], buf=[x, e["conv1"].ref, raw0, st], note=e["prefix"] + "conv1")
+        self.o.add(P.STEM_FWD, self.aflag, i=[B, L, L1, 64], buf=[x, e["conv1"].ref, raw0, st], note=e["prefix"] + "conv1")
         if self.count_flops:
             pl.flops_fwd += 2 * M * 64 * 3
-        a0 = pl.f32(M * 64)
+        a0 = self.A(M * 64)
         self.bn_apply(M, e["bn1"], raw0, a0, st, training, True, SLOPE_BACKBONE)
         e.update(x=x, L=L, L1=L1, raw0=raw0, a0=a0)
         cur, Lc = a0, L1
         for blk in e["blocks"]:
             cur, Lc = self.enc_block_fwd(blk, cur, Lc, training)
         pooled = pl.f32(B * 512)
-        self.o.add(P.POOL_FWD, 0, i=[B, Lc, 512], buf=[cur, pooled], note=e["prefix"] + "avgpool")
+        self.o.add(P.POOL_FWD, self.aflag, i=[B, Lc, 512], buf=[cur, pooled], note=e["prefix"] + "avgpool")
         e.update(pooled=pooled, Llast=Lc, last=cur)
         return pooled
 
@@ -686,27 +707,27 @@ class Lowering:
         cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
         tm1, Lo = self.map_fwd(Lc, cin, cout, s)
         Mo = B * Lo
-        r1 = pl.f32(Mo * cout)
+        r1 = self.A(Mo * cout)
         st1 = pl.stat(2 * cout) if training else None
         self.conv(tm1, cur, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1")
         if s != 1:
             tms, _ = self.map_fwd(Lc, cin, cout, s, k=1)
-            rs = pl.f32(Mo * cout)
+            rs = self.A(Mo * cout)
             sts = pl.stat(2 * cout) if training else None
             self.conv(tms, cur, blk["sc"], rs, stats=sts, note=blk["prefix"] + "shortcut.0")
             self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut.0")
         tm2, _ = self.map_fwd(Lo, cout, cout, 1)
-        r2 = pl.f32(Mo * cout)
+        r2 = self.A(Mo * cout)
         st2 = pl.stat(2 * cout) if training else None
         if training and self.train.fuse_bn:
             # lrelu(bn1(r1)) has exactly one consumer, conv2: evaluated in its operand loader, never stored
             a1 = None
             self.conv(tm2, r1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2", in_bn=dict(bn=blk["bn1"], stats=st1, M=Mo))
         else:
-            a1 = pl.f32(Mo * cout)
+            a1 = self.A(Mo * cout)
             self.bn_apply(Mo, blk["bn1"], r1, a1, st1, training, True, SLOPE_BACKBONE)
             self.conv(tm2, a1, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
-        out = pl.f32(Mo * cout)
+        out = self.A(Mo * cout)
         blk.update(x=cur, Lin=Lc, Lout=Lo, r1=r1, a1=a1, r2=r2, out=out, tm1=tm1, tm2=tm2)
         if s == 1:
             self.bn_apply(Mo, blk["bn2"], r2, out, st2, training, True, SLOPE_BACKBONE, 1, cur)
@@ -731,8 +752,8 @@ class Lowering:
         """dpooled: [B][512] gradient of the pooled features."""
         pl, B = self.pl, self.B
         Lc = e["Llast"]
-        G1 = pl.f32(B * Lc * 512)
-        self.o.add(P.POOL_BWD, 0, i=[B, Lc, 512], buf=[dpooled, G1], note=e["prefix"] + "avgpool bwd")
+        G1 = self.A(B * Lc * 512)
+        self.o.add(P.POOL_BWD, self.aflag, i=[B, Lc, 512], buf=[dpooled, G1], note=e["prefix"] + "avgpool bwd")
         blocks = e["blocks"]
         sp = self.enc_out_spec(e, len(blocks), None)          # the last block's output BatchNorm
         self.reduce_op(sp, G1)
@@ -760,7 +781,7 @@ class Lowering:
                 # and an odd-row op (paired into one launch), each with only the taps that contribute
                 spp = self.enc_out_spec(e, bi, None)
                 fuse = self.train.fuse_bn
-                dst = spp["g"] if fuse else pl.f32(B * Li * cin)
+                dst = spp["g"] if fuse else self.A(B * Li * cin)
                 tms = self.map_dgrad_s2_phases(Li, Lo, cin, cout)
                 for q, tm in enumerate(tms):
                     self.conv(tm, dr1, blk["conv1"], dst, w_kn=True, a2=drs, w2=blk["sc"], epi=spp if fuse else None,
@@ -773,7 +794,7 @@ class Lowering:
                     self.reduce_op(spp, dst)
             sp = spp
         dr0, _ = self.apply_op(sp)
-        self.o.add(P.STEM_WGRAD, self.det_flag, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
+        self.o.add(P.STEM_WGRAD, self.det_flag | self.aflag, i=[B, e["L"], e["L1"], 64], buf=[dr0, e["x"], e["conv1"].gref], note=e["prefix"] + "conv1 wgrad")
 
     # ---- decoder ------------------------------------------------------------------
     def decoder_fwd(self, d, din, training):
@@ -782,15 +803,15 @@ class Lowering:
         lin = dict(w=d["lin_w"], b=d["lin_b"], N=512, K=2 * z)
         y = pl.f32(B * 512)
         self.linear_fwd(B, lin, din, 2 * z, y, 512, note=d["prefix"] + "linear")
-        act0 = pl.f32(B * 4 * 512)
-        self.o.add(P.REPEAT_FWD, 0, i=[B, 4, 512], buf=[y, act0], note=d["prefix"] + "interpolate x4")
+        act0 = self.A(B * 4 * 512)
+        self.o.add(P.REPEAT_FWD, self.aflag, i=[B, 4, 512], buf=[y, act0], note=d["prefix"] + "interpolate x4")
         d.update(din=din, lin=lin, y=y, act0=act0)
         cur, Lc = act0, 4
         for blk in d["blocks"]:
             cur, Lc = self.dec_block_fwd(blk, cur, Lc, training)
         assert Lc == 32
         t = pl.f32(B * 64)
-        self.o.add(P.TAIL_FWD, 0, i=[B, 32, 64], buf=[cur, d["tail_w"].ref, d["tail_b"].ref, t], note=d["prefix"] + "conv1 (resize 64->1)")
+        self.o.add(P.TAIL_FWD, self.aflag, i=[B, 32, 64], buf=[cur, d["tail_w"].ref, d["tail_b"].ref, t], note=d["prefix"] + "conv1 (resize 64->1)")
         if self.count_flops:
             pl.flops_fwd += 2 * B * 64 * 64 * 3
         lo = dict(w=d["out_w"], b=d["out_b"], N=d["output_size"], K=64)
@@ -806,35 +827,35 @@ class Lowering:
         cin, cout, s = blk["cin"], blk["cout"], blk["stride"]
         Mi = B * Lc
         tm2, _ = self.map_fwd(Lc, cin, cin, 1)
-        r2 = pl.f32(Mi * cin)
+        r2 = self.A(Mi * cin)
         st2 = pl.stat(2 * cin) if training else None
         self.conv(tm2, cur, blk["conv2"], r2, stats=st2, note=blk["prefix"] + "conv2")
         if training and self.train.fuse_bn:
             a2, src2 = None, r2                 # lrelu(bn2(r2)) is evaluated in conv1's operand loader
             ib = dict(bn=blk["bn2"], stats=st2, M=Mi)
         else:
-            a2 = src2 = pl.f32(Mi * cin)
+            a2 = src2 = self.A(Mi * cin)
             ib = None
             self.bn_apply(Mi, blk["bn2"], r2, a2, st2, training, True, SLOPE_BACKBONE)
         blk.update(x=cur, Lin=Lc, r2=r2, a2=a2, tm2=tm2)
         if s == 1:
             tm1, Lo = self.map_fwd(Lc, cin, cout, 1)
-            r1 = pl.f32(Mi * cout)
+            r1 = self.A(Mi * cout)
             st1 = pl.stat(2 * cout) if training else None
             self.conv(tm1, src2, blk["conv1"], r1, stats=st1, note=blk["prefix"] + "conv1", in_bn=ib)
-            out = pl.f32(Mi * cout)
+            out = self.A(Mi * cout)
             self.bn_apply(Mi, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 1, cur)
         else:
             tm1, Lo = self.map_fwd_up(Lc, cin, cout)
             Mo = B * Lo
-            r1 = pl.f32(Mo * cout)
+            r1 = self.A(Mo * cout)
             st1 = pl.stat(2 * cout) if training else None
             self.conv(tm1, src2, blk["conv1"], r1, bias=blk["conv1_b"], stats=st1, note=blk["prefix"] + "conv1 (resize)", in_bn=ib)
-            rs = pl.f32(Mo * cout)
+            rs = self.A(Mo * cout)
             sts = pl.stat(2 * cout) if training else None
             self.conv(tm1, cur, blk["sc"], rs, bias=blk["sc_b"], stats=sts, note=blk["prefix"] + "shortcut (resize)")
             self.pair_last_two("pair " + blk["prefix"] + "conv1 + shortcut (resize)")
-            out = pl.f32(Mo * cout)
+            out = self.A(Mo * cout)
             self.bn_apply(Mo, blk["bn1"], r1, out, st1, training, True, SLOPE_BACKBONE, 2, rs, blk["scbn"], sts)
             blk.update(rs=rs)
         blk.update(r1=r1, out=out, tm1=tm1, Lout=Lo)
@@ -845,9 +866,9 @@ class Lowering:
         pl, B, z = self.pl, self.B, self.cfg.z_dim
         dt = pl.f32(B * 64)
         self.linear_bwd(B, d["lo"], drec, d["output_size"], d["t"], 64, dt, 64, note=d["prefix"] + "linear_out")
-        self.o.add(P.TAIL_BWD_W, self.det_flag, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
-        G1 = pl.f32(B * 32 * 64)
-        self.o.add(P.TAIL_BWD_X, 0, i=[B, 32, 64], buf=[dt, d["tail_w"].ref, G1], note=d["prefix"] + "tail dX")
+        self.o.add(P.TAIL_BWD_W, self.det_flag | self.aflag, i=[B, 32, 64], buf=[dt, d["last"], d["tail_w"].gref, d["tail_b"].gref], note=d["prefix"] + "tail dW")
+        G1 = self.A(B * 32 * 64)
+        self.o.add(P.TAIL_BWD_X, self.aflag, i=[B, 32, 64], buf=[dt, d["tail_w"].ref, G1], note=d["prefix"] + "tail dX")
         blocks = d["blocks"]
 
         def out_spec(bi, g2):
@@ -878,10 +899,10 @@ class Lowering:
                 self.wgrad(blk["tm1"], dr1, x1, blk["conv1"], note=p + "conv1 (resize) wgrad", coef=c1)
                 self.wgrad(blk["tm1"], drs, blk["x"], blk["sc"], note=p + "shortcut (resize) wgrad")
                 fuse = self.train.fuse_bn
-                da2 = sp2["g"] if fuse else pl.f32(Mi * cin)
+                da2 = sp2["g"] if fuse else self.A(Mi * cin)
                 self.conv(self.map_dgrad_up(Li, cin, cout), dr1, blk["conv1"], da2, w_kn=True, epi=sp2 if fuse else None,
                           note=p + "conv1 (resize) dgrad")
-                side = pl.f32(Mi * cin)
+                side = self.A(Mi * cin)
                 self.conv(self.map_dgrad_up(Li, cin, cout), drs, blk["sc"], side, w_kn=True, note=p + "shortcut (resize) dgrad")
                 self.pair_last_two("pair " + p + "resize dgrads")
                 if fuse:
@@ -898,11 +919,11 @@ class Lowering:
                 self.dgrad_reduce(tm, dr2, blk["conv2"], spp, p + "conv2 dgrad")
                 sp = spp
             else:
-                G1 = pl.f32(Mi * cin)
+                G1 = self.A(Mi * cin)
                 self.conv(tm, dr2, blk["conv2"], G1, w_kn=True, note=p + "conv2 dgrad")
                 G2 = side
         dy = pl.f32(B * 512)
-        self.o.add(P.REPEAT_BWD, 0, i=[B, 4, 512, 1], buf=[G1, G2, dy], note=d["prefix"] + "interpolate x4 bwd")
+        self.o.add(P.REPEAT_BWD, self.aflag, i=[B, 4, 512, 1], buf=[G1, G2, dy], note=d["prefix"] + "interpolate x4 bwd")
         self.linear_bwd(B, d["lin"], dy, 512, d["din"], 2 * z, ddin, 2 * z, accumulate=accumulate, note=d["prefix"] + "linear")
 
     # ---- heads: shared pieces --------------------------------------------------
@@ -957,7 +978,7 @@ class Lowering:
                 continue
             first = len(self.o.recs)
             for (tm, nsplit, rps, dy, x, w, note, coef) in mem:
-                self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag, i=tm.ints() + [nsplit, rps, w.numel],
+                self.o.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0) | self.mm_flag | self.aflag, i=tm.ints() + [nsplit, rps, w.numel],
                            f=[SLOPE_BACKBONE], buf=[dy, x, w.gref, coef], note=note)
             self.o.add(P.WGRAD_GROUP, 0, i=[first, len(mem), ntaps], note=f"grouped wgrad x{len(mem)} ({ntaps} taps)")
         if self.pending_small:
@@ -1050,6 +1071,7 @@ class Lowering:
         segs = {}
         for mode in ("train", "eval"):
             training = mode == "train"
+            self.abf = training and self.train.act_dtype == "bf16"      # (stays set through the backward pass emitted below)
             self.count_flops = training
             self.o.begin("fwd_" + mode)
             zero_idx = self.o.add(P.ZERO, 0, i=[0, 0], buf=[Ref(P.WS, pl.stats_base)], note="zero statistics")
@@ -1078,13 +1100,13 @@ class Lowering:
             st = pl.stat(4 * z) if training else None
             self.linear_fwd(B, fc0, c0, ncat, u1, 2 * z, stats=st, note="encoder_fc.0")
             a1 = pl.f32(B * 2 * z)
-            self.bn_apply(B, bn_e1, u1, a1, st, training, True, SLOPE_HEADS)
+            self.bn_apply(B, bn_e1, u1, a1, st, training, True, SLOPE_HEADS, heads=True)
             if not multi:
                 u2 = pl.f32(B * z)
                 st2 = pl.stat(2 * z) if training else None
                 self.linear_fwd(B, fc3, a1, 2 * z, u2, z, stats=st2, note="encoder_fc.3")
                 encv = pl.f32(B * z, "enc_" + mode, (B, z))
-                self.bn_apply(B, bn_e4, u2, encv, st2, training, True, SLOPE_HEADS)
+                self.bn_apply(B, bn_e4, u2, encv, st2, training, True, SLOPE_HEADS, heads=True)
             else:
                 u2 = None
                 encv = pl.f32(B * z, "enc_" + mode, (B, z))
@@ -1111,7 +1133,7 @@ class Lowering:
                 st4 = pl.stat(4 * z) if training else None
                 self.linear_fwd(B, fc["f2"], u3, 2 * z, u4, 2 * z, stats=st4, note=fcname + ".2")
                 dv = pl.f32(B * 2 * z)
-                self.bn_apply(B, fc["bn3"], u4, dv, st4, training, True, SLOPE_HEADS)
+                self.bn_apply(B, fc["bn3"], u4, dv, st4, training, True, SLOPE_HEADS, heads=True)
                 if fuse_heads:
                     self.close_heads(heads_first, 0, "heads forward: cat ... decoder_fc (one workgroup)")
                 rec = self.decoder_fwd(dd, dv, training)
@@ -1150,7 +1172,7 @@ class Lowering:
             for k, (fc, dd, hd) in enumerate(zip(dfc, decs, heads)):
                 ddv = pl.f32(B * 2 * z)
                 self.decoder_bwd(dd, hd["drec"], ddv)
-                _, du4, _ = self.bn_bwd(B, fc["bn3"], ddv, None, hd["dv"], hd["u4"], SLOPE_HEADS)
+                _, du4, _ = self.bn_bwd(B, fc["bn3"], ddv, None, hd["dv"], hd["u4"], SLOPE_HEADS, heads=True)
                 du3 = pl.f32(B * 2 * z)
                 self.linear_bwd(B, fc["f2"], du4, 2 * z, hd["u3"], 2 * z, du3, 2 * z, mask=hd["u3"], ldmask=2 * z, note="decoder_fc.2")
                 self.linear_bwd(B, fc["f0"], du3, 2 * z, c1, ncat1, dc1, ncat1, accumulate=(k > 0), note="decoder_fc.0")
@@ -1169,12 +1191,12 @@ class Lowering:
             denc = pl.f32(B * z)
             self.linear_bwd(B, zml, dmulv, 2 * z, encv, z, denc, z, note="z_mean | z_log_var")
             if not multi:
-                _, du2, _ = self.bn_bwd(B, bn_e4, denc, None, encv, u2, SLOPE_HEADS)
+                _, du2, _ = self.bn_bwd(B, bn_e4, denc, None, encv, u2, SLOPE_HEADS, heads=True)
             else:
                 du2 = denc
             da1 = pl.f32(B * 2 * z)
             self.linear_bwd(B, fc3, du2, z, a1, 2 * z, da1, 2 * z, note="encoder_fc.3")
-            _, du1, _ = self.bn_bwd(B, bn_e1, da1, None, a1, u1, SLOPE_HEADS)
+            _, du1, _ = self.bn_bwd(B, bn_e1, da1, None, a1, u1, SLOPE_HEADS, heads=True)
             dc0 = pl.f32(B * ncat)
             self.linear_bwd(B, fc0, du1, 2 * z, c0, ncat, dc0, ncat, note="encoder_fc.0")
             self.emb_bwd(dc0, ncat, 2 * z * len(enc))

@@ -31,6 +31,7 @@ OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k
 
 CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 1, 2, 4, 8, 16, 64, 128, 256
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the small-leaf group it belongs to
+FLAG_ACT_BF16 = 0x400            # the op's activation-typed buffers hold bfloat16 (include/hippie_hip.h)
 FLAG_GROUP_SHIFT, FLAG_GROUP_MASK, GROUP_MAX = 16, 0xFF, 64     # small-leaf group: see include/hippie_hip.h
 STAT_REPL_MAX = 16       # HP_STAT_REPL_MAX
 

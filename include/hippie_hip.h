@@ -69,6 +69,15 @@ static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 10
 /* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op, or of a small-leaf group (below): the
  * program executor skips it (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
 #define HP_FLAG_MEMBER 0x200
+/* Op flag: the op's ACTIVATION-typed buffers — the [rows][channels] tensors between the backbones' layers and their gradients — hold
+ * bfloat16 (2 bytes per element, round-to-nearest-even on store, exact widening on load) instead of float32; arithmetic, statistics,
+ * coefficients, weights, biases and every other buffer stay as documented.  Which buffers these are, per opcode:
+ *   CONV_TAPS A, A2, OUT, RES, E_G2, E_ACT, E_RAW, E_RAW2 (only with HP_CONV_BF16) · WGRAD_TAPS DY, X (only with HP_CONV_BF16) ·
+ *   BN_APPLY RAW, OUT, RES · BN_BWD_REDUCE G1, G2, ACT, GOUT, RAW, RAW2 · BN_BWD_APPLY G, RAW, DR · STEM_FWD OUT · STEM_WGRAD DR ·
+ *   POOL_FWD IN · POOL_BWD G · REPEAT_FWD OUT · REPEAT_BWD G1, G2 · TAIL_FWD ACT · TAIL_BWD_X DACT · TAIL_BWD_W ACT.
+ * The bf16-storage form of BASELINE configs[1] / [2] / [4]'s reduced-precision mode (TrainCfg.act_dtype = "bf16"): at batch >= 4096 every
+ * layer below 512 channels is bound by activation traffic, not by the matrix cores.  Never part of the fp32 parity path. */
+#define HP_FLAG_ACT_BF16 0x400
 /* Small-leaf group: bits 16..23 of `flags` of a record = number n of IMMEDIATELY PRECEDING records (all flagged
  * HP_FLAG_MEMBER) that, together with this record, are INDEPENDENT of each other (no record reads what another writes) and
  * run side by side in ONE launch whose grid is the concatenation of the members' own grids.  Members are

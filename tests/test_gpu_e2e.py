@@ -616,14 +616,16 @@ def test_staged_step_is_one_graph_and_equals_the_host_staged_step():
         plain.train_step_staged()
 
 
-@pytest.mark.parametrize("L,clip,steps", [(50, None, 160), (100, 1.0, 120)])
-def test_long_run_loss_curves_track_the_oracle(L, clip, steps):
+@pytest.mark.parametrize("L,clip,steps,bf16", [(50, None, 160, False), (100, 1.0, 120, False), (50, None, 160, True)])
+def test_long_run_loss_curves_track_the_oracle(L, clip, steps, bf16):
     """160 optimisation steps of the wave cVAE on the same batches and noise in the engine and in the CPU oracle: single trajectories
     diverge chaotically, the loss CURVES must not (mse within a factor of 2.5 and loss within 3 at every checkpoint, plateau within [0.6, 1.67]).
     Guards what single-step parity cannot see: bias correction at large step counts, weight decay, the KL weight, running statistics
     (tools/long_run_vs_oracle.py; at 1 500 steps the plateaus agree to 1 %)."""
     from tools import long_run_vs_oracle as lr
-    rows = lr.run(steps=steps, B=128, L=L, clip=clip, verbose=False)      # (the second case: the time model's shape, with gradient clipping)
+    # (the second case: the time model's shape, with gradient clipping; the third: bf16 matrix path with bf16-STORED activations — the
+    #  mode must train, not merely step: same curve criteria against the fp32 CPU oracle)
+    rows = lr.run(steps=steps, B=128, L=L, clip=clip, verbose=False, **(dict(mfma_dtype="bf16", act_dtype="bf16") if bf16 else {}))
     bad, tail_e, tail_o = lr.check(rows)
     assert not bad, bad
     assert 0.6 <= tail_e / tail_o <= 1.67, (tail_e, tail_o)
