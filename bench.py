@@ -583,9 +583,10 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the headline: the reference's arithmetic) | bf16: BASELINE config 2's reduced-precision mode "
                          "(bf16 MFMA operands, fp32 accumulation / statistics / master weights): a separately labelled line, never the headline")
-    ap.add_argument("--bf16-storage", action="store_true",
-                    help="with --dtype bf16: the backbones' activations and their gradients are also STORED as bfloat16 (TrainCfg.act_dtype): a third less "
-                         "workspace; slower than fp32 storage as the kernels stand (2-byte accesses per lane: profiles/r04_bf16_storage.txt)")
+    ap.add_argument("--bf16-f32-storage", action="store_true",
+                    help="A/B with --dtype bf16: keep the activation tensors in fp32 and round only the matrix operands (round 3's form).  Default with "
+                         "--dtype bf16: the backbones' activations and their gradients are also STORED as bfloat16 (TrainCfg.act_dtype: faster at every "
+                         "batch size measured and a third less workspace; profiles/r04_bf16_storage.txt)")
     ap.add_argument("--no-fuse-bn", action="store_true", help="A/B: one launch per BatchNorm pass instead of the fused loaders / epilogues")
     # non-default shapes (BASELINE configs[2]: --batch 4096 --z-dim 32 --wave-len 256 --time-len 32); the headline
     # metric is always quoted on the defaults
@@ -646,7 +647,7 @@ def main():
     pair = Pair(device, world, lens=(args.wave_len, args.time_len), lockstep=args.lockstep,
                 fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type,
                 staged=not args.no_staged, rank=rank, bucketed=(world > 1 or force_dist) and args.bucketed_bwd,
-                act_dtype="bf16" if (args.dtype == "bf16" and args.bf16_storage) else "f32")
+                act_dtype="bf16" if (args.dtype == "bf16" and not args.bf16_f32_storage) else "f32")
     pair.only = args.only_model
     pair.stream_priority = not args.no_stream_priority
     pair.run_ahead = max(0, args.run_ahead)
@@ -715,7 +716,7 @@ def main():
                 # the N > 1 lowering (TrainCfg.bucketed_bwd: two backward halves, two gradient buckets) in engines of its own
                 pair = Pair(device, 1, lens=(args.wave_len, args.time_len), lockstep=args.lockstep, fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype,
                             reuse_ws=not args.no_reuse_ws, model_type=args.model_type, staged=not args.no_staged, rank=0, bucketed=True,
-                            act_dtype="bf16" if (args.dtype == "bf16" and args.bf16_storage) else "f32")
+                            act_dtype="bf16" if (args.dtype == "bf16" and not args.bf16_f32_storage) else "f32")
                 pair.stream_priority, pair.run_ahead = main_pair.stream_priority, main_pair.run_ahead
                 if pair.staged:
                     pair.load_tables(data, perm)
@@ -783,7 +784,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            **({"activation_storage": "bf16" if args.bf16_storage else "fp32"} if args.dtype == "bf16" else {}),
+            **({"activation_storage": "fp32" if args.bf16_f32_storage else "bf16"} if args.dtype == "bf16" else {}),
             "config": {"workload": ("REDUCED-PRECISION MODE (bf16 MFMA operands, fp32 accumulate; NOT the headline; tolerance: tests/test_gpu_bf16.py) — " if args.dtype == "bf16" else "") +
                                    ("BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
                                     "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "

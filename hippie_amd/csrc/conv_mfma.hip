@@ -548,8 +548,10 @@ constexpr int kBigThreads = 256;
 constexpr int big_buf_h(int nt) {                     // bf16 elements of one staging buffer: A image [128][40] + the larger of the two B forms
   return 128 * kLdaH + (64 * nt * kLdaH > 32 * (64 * nt + 32) ? 64 * nt * kLdaH : 32 * (64 * nt + 32));
 }
-constexpr int big_lds_floats(int nt, int mode) {      // two staging buffers (2 x big_buf_h bf16 = big_buf_h floats) + IN_BN coefficients
-  return big_buf_h(nt) + (mode == 1 ? kConvCoef : 0);
+constexpr int kBigEpiTile = 32 * 36;                  // one 32 x 32 fp32 tile of the transposed epilogue, 144-byte rows
+constexpr int kBigEpiFloats = 4 * 3 * kBigEpiTile;    // per wave: values, xhat, xhat of a second BatchNorm
+constexpr int big_lds_floats(int nt, int mode) {      // two staging buffers (2 x big_buf_h bf16 = big_buf_h floats) + IN_BN coefficients; >= the epilogue's tiles
+  return (big_buf_h(nt) + (mode == 1 ? kConvCoef : 0)) > kBigEpiFloats ? (big_buf_h(nt) + (mode == 1 ? kConvCoef : 0)) : kBigEpiFloats;
 }
 
 template <bool W_KN, int MODE, int NT, bool ABF>
@@ -560,7 +562,10 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   constexpr int A_H = TM * kLdaH;                       // bf16 elements of one A image
   constexpr int B_H = W_KN ? 32 * LDT : TN * kLdaH;
   constexpr int BUF_H = big_buf_h(NT);                  // one buffer (A + the larger B form)
-  constexpr int NA = 4;                                 // A rows per thread: 128 rows x 8 four-float pieces / 256 threads
+  // A pieces per thread: fp32-stored 128 rows x 8 four-float pieces / 256 threads = 4 (16 bytes each); bf16-stored (ABF) 128 rows x 4
+  // eight-element pieces = 2 — 16 bytes per lane either way (8-byte bf16 pieces issue twice the loads per byte)
+  constexpr int NA = ABF ? 2 : 4;
+  constexpr int AROWS = ABF ? 64 : 32;                  // row distance between a thread's A pieces
   constexpr int NB = W_KN ? 2 * NT : 2 * NT;            // B pieces per thread (both forms: TN*32/4/256)
   (void)B_H;
   const TapMap& t = p.t;
@@ -569,7 +574,8 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   const int nt_ = (t.N + TN - 1) / TN, mt_ = (t.M + TM - 1) / TM;
   const int tile = xcd_remap(bid, mt_ * nt_);
   const int m0 = (tile / nt_) * TM, n0 = (tile % nt_) * TN;
-  const int ar = tid >> 3, aq = (tid & 7) << 2;         // A / [n][k]-B slot: rows ar + 32 j, piece aq
+  const int ar = tid >> 3, aq = (tid & 7) << 2;         // [n][k]-B slot (and fp32-stored A): rows ar + 32 j, piece aq
+  const int ara = ABF ? tid >> 2 : ar, aqa = ABF ? (tid & 3) << 3 : aq;      // A slot: rows ara + AROWS j, piece aqa (8 elements when ABF)
   const int kr = tid >> 4, nq = (tid & 15) << 2;        // [k][n]-B slot: k rows kr + 16 j, columns nq + 64 jj
   __bf16* const lds = reinterpret_cast<__bf16*>(smem);
   const float* s_coef = smem + BUF_H;                   // (behind the two buffers: 2 x BUF_H bf16 = BUF_H floats)
@@ -579,7 +585,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   bool rvalid[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
-    const int m_row = m0 + ar + 32 * j;
+    const int m_row = m0 + ara + AROWS * j;
     rvalid[j] = m_row < t.M;
     const int b_row = m_row / t.Lout;
     rbase[j] = b_row * t.Lin;
@@ -601,7 +607,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     for (int j = 0; j < NA; ++j) {
       const int pos = rl[j] + to;
       const bool oa = rvalid[j] && pos >= 0 && pos < t.P;
-      pa[j] = oa ? reinterpret_cast<const char*>(ap) + ((size_t)(rbase[j] + (pos >> t.sh)) * t.K + aq) * ES : reinterpret_cast<const char*>(hp_zero16);
+      pa[j] = oa ? reinterpret_cast<const char*>(ap) + ((size_t)(rbase[j] + (pos >> t.sh)) * t.K + aqa) * ES : reinterpret_cast<const char*>(hp_zero16);
       ia[j] = oa ? 32 * ES : 0;
     }
 #pragma unroll
@@ -620,14 +626,14 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     }
   };
   set_tap(0);
-  struct Pref { float4 a[NA]; float4 b[NB]; int kq; };
+  struct Pref { hp_v4u a[NA]; float4 b[NB]; int kq; };      // a: 16 bytes = 4 fp32 or (ABF) 8 bf16
   auto fetch = [&]() -> Pref {
     Pref r;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) r.a[j] = aload4p<ABF>(pa[j]);
+    for (int j = 0; j < NA; ++j) r.a[j] = *(const hp_v4u __attribute__((address_space(1)))*)(pa[j]);
 #pragma unroll
     for (int j = 0; j < NB; ++j) r.b[j] = gload4(pb[j]);
-    r.kq = kc * 32 + aq;
+    r.kq = kc * 32 + aqa;
 #pragma unroll
     for (int j = 0; j < NA; ++j) pa[j] += ia[j];
 #pragma unroll
@@ -644,6 +650,34 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   auto stash = [&](int buf, const Pref& r, const unsigned okmask) {
     __bf16* Ah = lds + buf * BUF_H;
     __bf16* Bh = Ah + A_H;
+    if (ABF) {
+      // 8 stored bf16 per piece: straight into the image — or, with the input BatchNorm, widened, transformed and rounded again
+      float sc8[8], sh8[8];
+      if (IN_BN && in_bn) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float4 c = *reinterpret_cast<const float4*>(s_coef + r.kq + 4 * q), d = *reinterpret_cast<const float4*>(s_coef + t.K + r.kq + 4 * q);
+          sc8[4 * q] = c.x; sc8[4 * q + 1] = c.y; sc8[4 * q + 2] = c.z; sc8[4 * q + 3] = c.w;
+          sh8[4 * q] = d.x; sh8[4 * q + 1] = d.y; sh8[4 * q + 2] = d.z; sh8[4 * q + 3] = d.w;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        hp_v4u v = r.a[j];
+        if (IN_BN && in_bn) {
+          const float keep = (okmask >> j) & 1u ? 1.f : 0.f;
+          unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float lo = __uint_as_float(w[q] << 16), hi = __uint_as_float(w[q] & 0xffff0000u);
+            const float fl = fmaf(lo, sc8[2 * q], sh8[2 * q]), fh = fmaf(hi, sc8[2 * q + 1], sh8[2 * q + 1]);
+            w[q] = (unsigned)f32_to_bf16_bits(fmaxf(fl, fl * in_slope) * keep) | ((unsigned)f32_to_bf16_bits(fmaxf(fh, fh * in_slope) * keep) << 16);
+          }
+          v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        }
+        *reinterpret_cast<hp_v4u*>(Ah + (ara + AROWS * j) * kLdaH + aqa) = v;
+      }
+    } else {
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (IN_BN && in_bn) {
       sc = *reinterpret_cast<const float4*>(s_coef + r.kq);
@@ -651,7 +685,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      float4 v = r.a[j];
+      float4 v = make_float4(__uint_as_float(r.a[j].x), __uint_as_float(r.a[j].y), __uint_as_float(r.a[j].z), __uint_as_float(r.a[j].w));
       if (IN_BN && in_bn) {
         const float keep = (okmask >> j) & 1u ? 1.f : 0.f;
         const float vx = fmaf(v.x, sc.x, sh.x), vy = fmaf(v.y, sc.y, sh.y), vz = fmaf(v.z, sc.z, sh.z), vw = fmaf(v.w, sc.w, sh.w);
@@ -659,6 +693,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
         v.z = fmaxf(vz, vz * in_slope) * keep; v.w = fmaxf(vw, vw * in_slope) * keep;
       }
       *reinterpret_cast<bf16x4*>(Ah + (ar + 32 * j) * kLdaH + aq) = to_bf16x4(v);
+    }
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -723,101 +758,178 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     __syncthreads();
   }
 
-  // ---- epilogue (the expressions of conv_epilogue; here every wave owns whole accumulator tiles) ----
-  double* sred = reinterpret_cast<double*>(smem);       // [wm][statistic][TN] column partials (the staging buffers are free now)
+  // ---- epilogue (the expressions of conv_epilogue; every wave owns whole accumulator tiles) ------------------------------------------
+  // An accumulator tile leaves the registers through LDS, TRANSPOSED: in the MFMA layout a lane holds one column of 16 rows — 2- or 4-byte
+  // accesses per lane and tensor, 16 of them per tile; after the transpose a lane holds 8 consecutive columns of one row — one 16-byte load
+  // per bf16 operand tensor (two for fp32) and one 16-byte store, 2 per tile.  The fused BatchNorm-backward layers read up to four operand
+  // tensors per output element: below 512 channels they are bound by exactly these accesses.  Column statistics are then summed from
+  // the LDS tiles (value, xhat) by one lane per column, in fp64, with the per-element expressions of conv_epilogue.
+  float* const T0 = smem + wave * 3 * kBigEpiTile;      // this wave's tiles: values | xhat | xhat of the second BatchNorm
+  float* const T1 = T0 + kBigEpiTile;
+  float* const T2 = T1 + kBigEpiTile;
+  double* sred = reinterpret_cast<double*>(smem);       // [statistic][TN] column partials of the wm = 1 waves (used after the tiles are dead)
   const bool plain_full = t.out_Lfull == 0;
   const bool has_act = p.e_act != nullptr, has_g2 = p.e_g2 != nullptr, has_2 = p.e_raw2 != nullptr;
+  const int rr = lane >> 2, cg = (lane & 3) << 3;       // transposed slot: rows rr, rr + 16; columns cg .. cg + 7 of the 32 x 32 tile
+  // 8 consecutive elements of an activation tensor at element offset o (valid: nv of them, the rest zero) / their store
+  auto ld8 = [&](const float* base, const int o, const int nv, float (&v)[8]) {
+    if (ABF) {
+      if (nv >= 8) {
+        const hp_v4u u = *(const hp_v4u __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(base) + (size_t)o * 2);
+        const unsigned w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { v[2 * q] = __uint_as_float(w[q] << 16); v[2 * q + 1] = __uint_as_float(w[q] & 0xffff0000u); }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < nv ? aload1<true>(base, (size_t)o + e) : 0.f;
+      }
+    } else {
+      if (nv >= 8) {
+        const float4 x0 = gload4(base + o), x1 = gload4(base + o + 4);
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = e < nv ? gload1(base + o + e) : 0.f;
+      }
+    }
+  };
+  auto st8 = [&](float* base, const int o, const int nv, const float (&v)[8]) {
+    if (nv >= 8) {
+      astore4<ABF>(base, (size_t)o, make_float4(v[0], v[1], v[2], v[3]));
+      astore4<ABF>(base, (size_t)o + 4, make_float4(v[4], v[5], v[6], v[7]));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (e < nv) astore1<ABF>(base, (size_t)o + e, v[e]);
+    }
+  };
+  const bool want = p.epi || (!p.bn_eval && p.stats != nullptr);          // (uniform) column statistics wanted
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * WN + j * 32 + li;
-    const bool nok = n < t.N;
-    double st[3] = {0.0, 0.0, 0.0};
-    float mean = 0.f, invstd = 0.f, mean2 = 0.f, invstd2 = 0.f, csc = 0.f, csh = 0.f, bv = 0.f, esc = 0.f, esh = 0.f;
-    if (nok) {
+    const int ncol0 = n0 + wn * WN + j * 32;            // first column of this tile
+    const int n8 = ncol0 + cg;                          // this lane's 8 columns in the transposed pass
+    const int nv = min(8, max(0, t.N - n8));
+    // per-column constants of the lane's 8 columns
+    float mean[8], invstd[8], mean2[8], invstd2[8], csc[8], csh[8], bv[8], esc[8], esh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool ok = e < nv;
+      const int n = ok ? n8 + e : 0;
+      mean[e] = invstd[e] = mean2[e] = invstd2[e] = csc[e] = csh[e] = bv[e] = esc[e] = esh[e] = 0.f;
       if (p.epi) {
-        mean = p.e_save[n]; invstd = p.e_save[t.N + n];
-        if (has_2) { mean2 = p.e_save2[n]; invstd2 = p.e_save2[t.N + n]; }
-        if (!has_act) { csc = p.e_coef[n]; csh = p.e_coef[t.N + n]; }
-      } else {
-        if (p.bias != nullptr) bv = p.bias[n];
+        if (ok) {
+          mean[e] = p.e_save[n]; invstd[e] = p.e_save[t.N + n];
+          if (has_2) { mean2[e] = p.e_save2[n]; invstd2[e] = p.e_save2[t.N + n]; }
+          if (!has_act) { csc[e] = p.e_coef[n]; csh[e] = p.e_coef[t.N + n]; }
+        }
+      } else if (ok) {
+        if (p.bias != nullptr) bv[e] = p.bias[n];
         if (p.bn_eval) {
           const double is = 1.0 / sqrt((double)p.rvar[n] + (double)p.eps);
           const double scd = (double)p.gamma[n] * is;
-          esc = (float)scd;
-          esh = (float)((double)p.beta[n] - (double)p.rmean[n] * scd);
+          esc[e] = (float)scd;
+          esh[e] = (float)((double)p.beta[n] - (double)p.rmean[n] * scd);
         }
       }
     }
+    double st[3] = {0.0, 0.0, 0.0};                     // column (ncol0 + lane & 31), rows of this lane half, over the MT tiles
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int mrow = m0 + wm * 64 + i * 32 + 4 * lh;
-      int off[16];
+      const int mtile = m0 + wm * 64 + i * 32;
+      __syncthreads();                                  // (the tiles' previous readers are done; first use: the staging buffers are dead)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mrow + (r & 3) + 8 * (r >> 2);
-        int o = -1;
-        if (nok && m < t.M) {
+      for (int r = 0; r < 16; ++r) T0[((r & 3) + 8 * (r >> 2) + 4 * lh) * 36 + li] = acc[i][j][r];
+      __syncthreads();
+#pragma unroll
+      for (int ps = 0; ps < 2; ++ps) {
+        const int row = rr + 16 * ps, m = mtile + row;
+        const bool rok = m < t.M && nv > 0;
+        int o = 0;
+        if (rok) {
           o = m;
           if (!plain_full) {
-            const int b = m / t.Lout;
-            o = b * t.out_Lfull + t.out_a * (m - b * t.Lout) + t.out_o;
+            const int b_ = m / t.Lout;
+            o = b_ * t.out_Lfull + t.out_a * (m - b_ * t.Lout) + t.out_o;
           }
-          o = o * t.N + n;
+          o = o * t.N + n8;
         }
-        off[r] = o;
+        const int nvr = rok ? nv : 0;
+        float v[8];
+        {
+          const float4 a0 = *reinterpret_cast<const float4*>(T0 + row * 36 + cg), a1 = *reinterpret_cast<const float4*>(T0 + row * 36 + cg + 4);
+          v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+        }
+        float xh[8], xh2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xh[e] = xh2[e] = 0.f;
+        if (p.epi) {
+          float xr[8], av[8], g2[8], x2[8];
+          ld8(p.e_raw, o, nvr, xr);
+          if (has_act) ld8(p.e_act, o, nvr, av);
+          if (has_g2) ld8(p.e_g2, o, nvr, g2);
+          if (has_2) ld8(p.e_raw2, o, nvr, x2);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float gv = v[e];
+            if (has_g2) gv += g2[e];
+            const float pre = has_act ? av[e] : fmaf(xr[e], csc[e], csh[e]);
+            gv *= lrelu_grad(pre, p.e_slope);
+            v[e] = e < nvr ? gv : 0.f;
+            xh[e] = (xr[e] - mean[e]) * invstd[e];
+            if (has_2) xh2[e] = (x2[e] - mean2[e]) * invstd2[e];
+          }
+        } else if (p.bn_eval) {
+          float rs[8];
+          if (p.res != nullptr) ld8(p.res, o, nvr, rs);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float w_ = fmaf(v[e] + bv[e], esc[e], esh[e]);
+            if (p.res != nullptr) w_ += rs[e];
+            v[e] = p.act ? lrelu(w_, p.slope) : w_;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = e < nvr ? v[e] + bv[e] : 0.f;
+        }
+        if (rok) st8(p.out, o, nvr, v);
+        if (want) {                                     // what the column pass sums: the values (zero outside the problem) and xhat
+          *reinterpret_cast<float4*>(T0 + row * 36 + cg) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(T0 + row * 36 + cg + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          if (p.epi) {
+            *reinterpret_cast<float4*>(T1 + row * 36 + cg) = make_float4(xh[0], xh[1], xh[2], xh[3]);
+            *reinterpret_cast<float4*>(T1 + row * 36 + cg + 4) = make_float4(xh[4], xh[5], xh[6], xh[7]);
+            if (has_2) {
+              *reinterpret_cast<float4*>(T2 + row * 36 + cg) = make_float4(xh2[0], xh2[1], xh2[2], xh2[3]);
+              *reinterpret_cast<float4*>(T2 + row * 36 + cg + 4) = make_float4(xh2[4], xh2[5], xh2[6], xh2[7]);
+            }
+          }
+        }
       }
-      if (p.epi) {
-        float xr[16], av[16], g2[16], x2[16];
+      if (want) {
+        __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = off[r] >= 0 ? off[r] : 0;
-          xr[r] = aload1<ABF>(p.e_raw, o);
-          av[r] = has_act ? aload1<ABF>(p.e_act, o) : 0.f;
-          g2[r] = has_g2 ? aload1<ABF>(p.e_g2, o) : 0.f;
-          x2[r] = has_2 ? aload1<ABF>(p.e_raw2, o) : 0.f;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (off[r] < 0) continue;
-          float gv = acc[i][j][r];
-          if (has_g2) gv += g2[r];
-          const float pre = has_act ? av[r] : fmaf(xr[r], csc, csh);
-          gv *= lrelu_grad(pre, p.e_slope);
-          astore1<ABF>(p.out, off[r], gv);
-          st[0] += (double)gv;
-          st[1] += (double)gv * (double)((xr[r] - mean) * invstd);
-          if (has_2) st[2] += (double)gv * (double)((x2[r] - mean2) * invstd2);
-        }
-      } else if (p.bn_eval) {
-        float rs[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) rs[r] = p.res != nullptr ? aload1<ABF>(p.res, off[r] >= 0 ? off[r] : 0) : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (off[r] < 0) continue;
-          float v = fmaf(acc[i][j][r] + bv, esc, esh);
-          if (p.res != nullptr) v += rs[r];
-          if (p.act) v = lrelu(v, p.slope);
-          astore1<ABF>(p.out, off[r], v);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if (off[r] < 0) continue;
-          const float v = acc[i][j][r] + bv;
-          astore1<ABF>(p.out, off[r], v);
-          st[0] += (double)v;
-          st[1] += (double)v * (double)v;
+        for (int q = 0; q < 16; ++q) {
+          const int row = 16 * lh + q;
+          const double gv = (double)T0[row * 36 + li];
+          st[0] += gv;
+          if (p.epi) {
+            st[1] += gv * (double)T1[row * 36 + li];
+            if (has_2) st[2] += gv * (double)T2[row * 36 + li];
+          } else {
+            st[1] += gv * gv;
+          }
         }
       }
     }
     // column sums: the two lane halves, then the two waves that share these columns (wm = 0, 1), one atomic per column and statistic
-    const bool want = p.epi || (!p.bn_eval && p.stats != nullptr);          // (uniform)
     if (want) {
       constexpr int NS = 3;
+      const int n = ncol0 + li;
+      const bool nok = n < t.N;
 #pragma unroll
       for (int k = 0; k < NS; ++k) st[k] += __shfl_xor(st[k], 32, 64);
       const int col = wn * WN + j * 32 + li;
+      __syncthreads();                                  // (every wave is done with its tiles: sred aliases them)
       if (wm == 1 && lane < 32) {
 #pragma unroll
         for (int k = 0; k < NS; ++k) sred[k * TN + col] = st[k];
@@ -841,18 +953,17 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
           atomic_add_f64(sp + t.N + n, st[1]);
         }
       }
-      __syncthreads();
     }
   }
 }
 
 template <bool W_KN, int MODE, int NT, bool ABF>
-__global__ __launch_bounds__(kBigThreads) void conv_big_kernel(ConvArgs p) {
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big_kernel(ConvArgs p) {      // two workgroups per CU: <= 256 registers
   __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, MODE)];
   conv_big_body<W_KN, MODE, NT, ABF>(p, blockIdx.x, smem);
 }
 template <bool W_KN, int MODE, int NT, bool ABF>
-__global__ __launch_bounds__(kBigThreads) void conv_big_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
   __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, MODE)];
   if ((int)blockIdx.x < nblk_a) conv_big_body<W_KN, MODE, NT, ABF>(a, blockIdx.x, smem);
   else conv_big_body<W_KN, MODE, NT, ABF>(b, blockIdx.x - nblk_a, smem);
@@ -1076,6 +1187,67 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
     }
   };
 
+  // ---- bf16-STORED operands (ABF; HP_FLAG_ACT_BF16): a thread holds 8 consecutive bf16 of ONE row per operand — one 16-byte load and one
+  // 16-byte LDS store per operand and slice, no conversion at all unless the input BatchNorm is re-evaluated (the 4-element form above
+  // would issue 8-byte loads and unpack to fp32 only to repack: twice the memory instructions per byte, measured 16.8 against 8.3 ms)
+  const int lr8 = tid >> 3, c8 = (tid & 7) << 3;
+  hp_v4u hdy = {0u, 0u, 0u, 0u}, hx[NT];
+  int rb8 = (mbeg + lr8) / t.Lout, rl8 = (mbeg + lr8) - rb8 * t.Lout;
+  float xsc8[8], xsh8[8];
+  if (ABF) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const bool in = x_bn && c0 + c8 + e < t.K;
+      xsc8[e] = in ? gload1(p.coef + c0 + c8 + e) : 1.f;
+      xsh8[e] = in ? gload1(p.coef + t.K + c0 + c8 + e) : 0.f;
+    }
+  }
+  unsigned ok8 = 0;        // bit tau: hx[tau] holds a real row
+  auto load_regs_h = [&](int mb) {
+    const int m = mb + lr8;
+    const bool mv = m < mend;
+    const hp_v4u zero = {0u, 0u, 0u, 0u};
+    hdy = zero;
+    if (mv && n0 + c8 < t.N) hdy = *(const hp_v4u __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(gDY) + ((size_t)m * t.N + n0 + c8) * 2);
+    const int b = rb8, al = t.a * rl8;
+    rl8 += r32; rb8 += q32;
+    if (rl8 >= t.Lout) { rl8 -= t.Lout; ++rb8; }
+    ok8 = 0;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+      const int pos = al + t.tap_o[tau];
+      const bool ok = mv && pos >= 0 && pos < t.P && (c0 + c8 < t.K);
+      hx[tau] = zero;
+      if (ok) {
+        hx[tau] = *(const hp_v4u __attribute__((address_space(1)))*)(reinterpret_cast<const char*>(gX) + ((size_t)(b * t.Lin + (pos >> t.sh)) * t.K + c0 + c8) * 2);
+        ok8 |= 1u << tau;
+      }
+    }
+  };
+  auto store_lds_h = [&]() {
+    __bf16* dyh = reinterpret_cast<__bf16*>(smem);
+    *reinterpret_cast<hp_v4u*>(dyh + lr8 * kLdtH + c8) = hdy;
+#pragma unroll
+    for (int tau = 0; tau < NT; ++tau) {
+      hp_v4u v = hx[tau];
+      if (x_bn) {
+        const float keep = (ok8 >> tau) & 1u ? 1.f : 0.f;
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float lo = __uint_as_float(w[q] << 16), hi = __uint_as_float(w[q] & 0xffff0000u);
+          const float fl = fmaf(lo, xsc8[2 * q], xsh8[2 * q]), fh = fmaf(hi, xsc8[2 * q + 1], xsh8[2 * q + 1]);
+          const float al_ = fmaxf(fl, fl * xslope) * keep, ah = fmaxf(fh, fh * xslope) * keep;
+          w[q] = (unsigned)f32_to_bf16_bits(al_) | ((unsigned)f32_to_bf16_bits(ah) << 16);
+        }
+        v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+      }
+      *reinterpret_cast<hp_v4u*>(reinterpret_cast<__bf16*>(smem + (1 + tau) * T) + lr8 * kLdtH + c8) = v;
+    }
+  };
+  auto LOAD = [&](int mb) { if constexpr (ABF) load_regs_h(mb); else load_regs(mb); };
+  auto STORE = [&]() { if constexpr (ABF) store_lds_h(); else store_lds(); };
+
   f32x16 acc[NT];
 #pragma unroll
   for (int tau = 0; tau < NT; ++tau)
@@ -1083,12 +1255,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
     for (int r = 0; r < 16; ++r) acc[tau][r] = 0.f;
 
   if (mbeg < mend) {
-    load_regs(mbeg);
-    store_lds();
+    LOAD(mbeg);
+    STORE();
     __syncthreads();
     for (int mb = mbeg; mb < mend; mb += 32) {
       const bool more = mb + 32 < mend;
-      if (more) load_regs(mb + 32);
+      if (more) LOAD(mb + 32);
       if (BF16) {
         // both operands are TRANSPOSES of the row-major [32 rows m][64 columns] bf16 images: hardware transpose reads,
         // two v_mfma_f32_32x32x16_bf16 per tap and slice
@@ -1103,7 +1275,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
         }
         __syncthreads();
         if (more) {
-          store_lds();
+          STORE();
           __syncthreads();
         }
         continue;
@@ -1127,7 +1299,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
       }
       __syncthreads();
       if (more) {
-        store_lds();
+        STORE();
         __syncthreads();
       }
     }

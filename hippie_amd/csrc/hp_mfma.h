@@ -34,6 +34,7 @@ __device__ __forceinline__ void gstore1(float* p, float v) { *(float __attribute
 // H = true: the tensor holds bf16 (2 bytes per element).  bf16 -> fp32 is a shift (exact); fp32 -> bf16 rounds to nearest even
 // (v_cvt_pk_bf16_f32).  Pointers stay `float*` in the argument structs; element offsets are scaled here.
 typedef unsigned hp_v2u __attribute__((ext_vector_type(2)));
+typedef unsigned hp_v4u __attribute__((ext_vector_type(4)));
 template <bool H>
 __device__ __forceinline__ float4 aload4p(const char* p) {          // p -> four consecutive elements
   if (H) {

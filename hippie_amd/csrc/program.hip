@@ -336,9 +336,9 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
                        o == HP_OP_REPEAT_BWD || o == HP_OP_TAIL_FWD || o == HP_OP_TAIL_BWD_X || o == HP_OP_TAIL_BWD_W;
     const bool bn = o == HP_OP_BN_APPLY || o == HP_OP_BN_BWD_REDUCE || o == HP_OP_BN_BWD_APPLY;
     const bool mm = o == HP_OP_CONV_TAPS || o == HP_OP_WGRAD_TAPS;
-    if (!typed || (bn && (op.i[1] % 4) != 0) || (mm && !(op.flags & HP_CONV_BF16))) {
+    if (!typed || (bn && (op.i[1] % 4) != 0) || (mm && !(op.flags & HP_CONV_BF16)) || (mm && ((op.i[1] % 8) != 0 || (op.i[2] % 8) != 0))) {
       snprintf(buf, sizeof buf, "op %d (opcode %d): HP_FLAG_ACT_BF16 needs an op with activation-typed buffers (BatchNorm ops: channels %% 4 == 0; "
-               "CONV_TAPS / WGRAD_TAPS: HP_CONV_BF16)", index, op.op);
+               "CONV_TAPS / WGRAD_TAPS: HP_CONV_BF16, N and K multiples of 8)", index, op.op);
       why = buf;
       return 1;
     }
