@@ -40,7 +40,7 @@ sys.path.insert(0, ROOT)
 from hippie_amd import parallel, planner, program as P          # noqa: E402
 from hippie_amd.engine import Engine                   # noqa: E402
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04_conv_pmc.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r04b_conv_pmc.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc passes
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_TFLOPS = {"f32": PEAK_F32_MFMA_TFLOPS, "bf16": 2500.0, "bf16x3": 2500.0 / 6}      # bf16x3: six bf16 products per fp32 product
 #   (bf16: ~2.5 PFLOP/s dense, v_mfma_f32_32x32x16_bf16)

@@ -596,6 +596,14 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   conv_epilogue<ABF>(p, acc2, smem, bid, m0, n0);
 }
 
+
+// (Built, measured and removed, round 4: a three-term body for three-tap stride-1 layers that runs the K loop chunk-outer / tap-inner and stages
+// ONE A image per 32-wide chunk — the tile's 64 rows plus a halo row on either side, transformed and split once — for all three taps (a tap =
+// a row offset of the fragment read, sample boundaries = a per-lane flag), i.e. a third of the A-side loads, BatchNorm transforms, splits and
+// LDS stores.  Same results; at batch 512 the plain layers ran 0-7 % faster (K = 512: 50.6 -> 46.9 us), the layers with the BatchNorm input
+// transform 10-30 % slower (15.6 -> 20.3 us at K = 64: the second live image piece and the tap pointers spill inside the steps at 128
+// registers), the pair-step 131.3 k against 138.8 k samples/s.  The K loop at this batch is not bound by the A-side staging work.
+// The same idea IS what runs the weight gradients (wgrad3s_body below), where it removes two of three X images.)
 // (amdgpu_waves_per_eu(4): two 512-thread workgroups per CU, i.e. at most 128 VGPRs, for every instantiation)
 template <bool W_KN, int MODE, int MM = 0, bool ABF = false>
 __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv_taps_kernel(ConvArgs p) {
@@ -1265,6 +1273,7 @@ struct WgradArgs {
   TapMap t;
   int nsplit, rows_per_split, slab_stride;
   int atomic;   // 1: accumulate into `slab` (= the zeroed gradient tensor) with fp32 atomics, no slabs
+  int shared;   // 1 (set by build_wgrad_group): a three-tap stride-1 problem of the three-term mode run by wgrad3s_body (128 x 64 tiles)
 };
 
 
@@ -1524,6 +1533,180 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int tile, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Three-tap stride-1 weight gradient in the three-term mode (HP_CONV_BF16X3): the conv layers whose taps read rows m - 1, m, m + 1 of the
+// SAME tensor (every 3-wide stride-1 Conv1d: most of a backward pass's weight-gradient work).  The general body above stages one X image
+// per tap — three loads, three splits, three LDS images of what is one tensor shifted by a row.  Here ONE image of X (the slice's 32 rows
+// plus a halo row on either side) serves all three taps: a tap is a row offset of the hardware-transpose read.  What the shift cannot
+// express — a row whose neighbour lies in the next sample contributes nothing to that tap — is a mask on the DY fragment of that tap
+// (the lane's 8 contraction rows: zeroed where l(m) + tap offset leaves [0, L)); slabs without a sample boundary skip it.
+// 128 (n) x 64 (k) x 3 taps per 256-thread workgroup, 4 waves of 64 x 32 x 3 = 6 accumulator tiles: every DY fragment feeds 3 taps, every X
+// fragment 2 row tiles — 30 fragment reads for 36 MFMAs per 16-row slab against 24 for 18 in the general body, and a third of its staging work.
+// ------------------------------------------------------------------------------------------------------------------------------------
+constexpr int kW3DyLd = 160, kW3XLd = 96;                 // bf16 row strides: 128 + 32 / 64 + 32 columns (rows 64 bytes apart mod 256: conflict-free transpose reads)
+constexpr int kW3DyPlane = 32 * kW3DyLd, kW3XPlane = 34 * kW3XLd;
+constexpr int kW3Lds = 3 * (kW3DyPlane + kW3XPlane) / 2;  // floats
+
+__device__ __forceinline__ void wgrad3s_body(const WgradArgs& p, const int tile, const int split, float* smem) {
+  const TapMap& t = p.t;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wc = wave & 1, li = lane & 31, lh = lane >> 5;
+  const int ntc = (t.K + 63) >> 6;
+  const int n0 = (tile / ntc) << 7, c0 = (tile % ntc) << 6;
+  const int mbeg = split * p.rows_per_split;
+  const int mend = min(t.M, mbeg + p.rows_per_split);
+  const int L = t.Lout;
+  __bf16* const dyI = reinterpret_cast<__bf16*>(smem);
+  __bf16* const xI = dyI + 3 * kW3DyPlane;
+  const int dr = tid >> 5, dc = (tid & 31) << 2;          // DY slots: rows dr + 8 j (j < 4), columns dc .. dc + 3 of the tile's 128
+  const int xr = tid >> 4, xc = (tid & 15) << 2;          // X slots: image rows xr + 16 j (j < 3, 34 rows: tensor rows mb - 1 .. mb + 32), columns xc .. + 3 of 64
+  const bool x_bn = p.coef != nullptr;
+  float4 xsc = make_float4(1.f, 1.f, 1.f, 1.f), xsh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (x_bn && c0 + xc < t.K) {
+    xsc = gload4(p.coef + c0 + xc);
+    xsh = gload4(p.coef + t.K + c0 + xc);
+  }
+  const float xslope = p.slope;
+  float4 rdy[4], rx[3];
+  auto load_regs = [&](const int mb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int m = mb + dr + 8 * j;
+      rdy[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < mend && n0 + dc < t.N) rdy[j] = gload4(p.DY + (size_t)m * t.N + n0 + dc);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int r = xr + 16 * j, m = mb - 1 + r;
+      rx[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < 34 && m >= 0 && m < t.M && c0 + xc < t.K) rx[j] = gload4(p.X + (size_t)m * t.K + c0 + xc);      // (rows of other splits / samples are real data: the DY side decides what counts)
+    }
+  };
+  auto store_lds = [&]() {
+    bf16x4 h, m, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      split3(rdy[j], h, m, l);
+      __bf16* d = dyI + (dr + 8 * j) * kW3DyLd + dc;
+      *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + kW3DyPlane) = m; *reinterpret_cast<bf16x4*>(d + 2 * kW3DyPlane) = l;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int r = xr + 16 * j;
+      if (r < 34) {
+        float4 v = rx[j];
+        if (x_bn) {      // the activation the forward conv consumed, re-evaluated bit for bit (as wgrad_body)
+          const float fx = fmaf(v.x, xsc.x, xsh.x), fy = fmaf(v.y, xsc.y, xsh.y), fz = fmaf(v.z, xsc.z, xsh.z), fw = fmaf(v.w, xsc.w, xsh.w);
+          v.x = fmaxf(fx, fx * xslope); v.y = fmaxf(fy, fy * xslope); v.z = fmaxf(fz, fz * xslope); v.w = fmaxf(fw, fw * xslope);
+        }
+        split3(v, h, m, l);
+        __bf16* d = xI + r * kW3XLd + xc;
+        *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + kW3XPlane) = m; *reinterpret_cast<bf16x4*>(d + 2 * kW3XPlane) = l;
+      }
+    }
+  };
+
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int tau = 0; tau < 3; ++tau)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tau][i][r] = 0.f;
+
+  __syncthreads();                       // (the body may follow another one in the same workgroup)
+  if (mbeg < mend) {
+    // position within its sample of the first of this lane's 8 contraction rows of a slab, advanced by 16 rows per slab without divisions
+    int l0 = (mbeg + 8 * lh) % L;
+    const int r16 = 16 % L;
+    load_regs(mbeg);
+    store_lds();
+    __syncthreads();
+    for (int mb = mbeg; mb < mend; mb += 32) {
+      const bool more = mb + 32 < mend;
+      if (more) load_regs(mb + 32);
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        // rows of this lane that start (tap offset -1 invalid) / end (offset +1 invalid) a sample
+        unsigned first = 0, last = 0;
+        {
+          int le = l0;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            first |= (le == 0 ? 1u : 0u) << e;
+            last |= (le == L - 1 ? 1u : 0u) << e;
+            le = le + 1 == L ? 0 : le + 1;
+          }
+          l0 += r16;
+          if (l0 >= L) l0 -= L;
+        }
+        bf16x8 af[2][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) af[i][c] = tr_operand(dyI + c * kW3DyPlane, kW3DyLd, st * 16, wn * 64 + i * 32, lane);
+#pragma unroll
+        for (int tau = 0; tau < 3; ++tau) {
+          bf16x8 bf[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) bf[c] = tr_operand(xI + c * kW3XPlane, kW3XLd, st * 16 + tau, wc * 32, lane);
+          bf16x8 am[2][3];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) am[i][c] = af[i][c];
+          const unsigned bad = tau == 0 ? first : (tau == 2 ? last : 0u);
+          if (tau != 1 && __builtin_amdgcn_ballot_w64(bad != 0) != 0) {      // (uniform) a sample boundary inside this slab
+            hp_v4u keep;
+            keep.x = ((bad & 1u) ? 0u : 0x0000ffffu) | ((bad & 2u) ? 0u : 0xffff0000u);
+            keep.y = ((bad & 4u) ? 0u : 0x0000ffffu) | ((bad & 8u) ? 0u : 0xffff0000u);
+            keep.z = ((bad & 16u) ? 0u : 0x0000ffffu) | ((bad & 32u) ? 0u : 0xffff0000u);
+            keep.w = ((bad & 64u) ? 0u : 0x0000ffffu) | ((bad & 128u) ? 0u : 0xffff0000u);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                union { bf16x8 v; hp_v4u u; } w;
+                w.v = am[i][c];
+                w.u.x &= keep.x; w.u.y &= keep.y; w.u.z &= keep.z; w.u.w &= keep.w;
+                am[i][c] = w.v;
+              }
+          }
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            constexpr int ca[6] = {0, 2, 1, 0, 1, 0}, cb[6] = {2, 0, 1, 1, 0, 0};      // the five corrections (smallest first), then the leading product
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[tau][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i][ca[q]], bf[cb[q]], acc[tau][i], 0, 0, 0);
+          }
+        }
+      }
+      __syncthreads();
+      if (more) {
+        store_lds();
+        __syncthreads();
+      }
+    }
+  }
+
+  const int c = c0 + wc * 32 + li;
+  if (c < t.K) {
+#pragma unroll
+    for (int tau = 0; tau < 3; ++tau) {
+      float* dst = p.slab + (p.atomic ? (size_t)0 : (size_t)split * p.slab_stride) + (size_t)t.tap_w[tau] * t.N * t.K;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n < t.N) {
+            if (p.atomic) atomic_add_f32_global(dst + (size_t)n * t.K + c, acc[tau][i][r]);
+            else dst[(size_t)n * t.K + c] = acc[tau][i][r];
+          }
+        }
+    }
+  }
+}
+
 template <int NT, int MM = 0, bool ABF = false>
 __global__ __launch_bounds__(256) void wgrad_taps_kernel(WgradArgs p) {
   __shared__ __attribute__((aligned(16))) float smem[wgrad_lds(NT, MM)];
@@ -1548,6 +1731,20 @@ __global__ __launch_bounds__(256) void wgrad_group_kernel(const WgradArgs* __res
   const WgradArgs p = probs[pj];
   wgrad_body<NT, MM, ABF>(p, tile, split, smem);
 }
+// the three-term mode's group: problems flagged `shared` run on wgrad3s_body.  (Two workgroups per CU: at most 256 registers.)
+template <int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_group3_kernel(const WgradArgs* __restrict__ probs, const int4* __restrict__ blocks) {
+  __shared__ __attribute__((aligned(16))) float smem[wgrad_lds(NT, 2)];
+  const int4 bi = blocks[blockIdx.x];
+  const int pj = __builtin_amdgcn_readfirstlane(bi.x);
+  const int tile = __builtin_amdgcn_readfirstlane(bi.y);
+  const int split = __builtin_amdgcn_readfirstlane(bi.z);
+  const WgradArgs p = probs[pj];
+  if constexpr (NT == 3) {
+    if (p.shared) { wgrad3s_body(p, tile, split, smem); return; }      // (uniform per workgroup)
+  }
+  wgrad_body<NT, 2, false>(p, tile, split, smem);
+}
 
 static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {
   WgradArgs a;
@@ -1561,23 +1758,42 @@ static WgradArgs wgrad_args_from(const HpOp& op, void* const* bases) {
   a.rows_per_split = op.i[23];
   a.slab_stride = op.i[24];
   a.atomic = op.flags & 1;
+  a.shared = 0;
   return a;
 }
 
+// (A/B knob: HIPPIE_WGRAD_SHARED=0 keeps every problem of a group on the general body)
+static bool wgrad_shared_on() {
+  static const bool v = [] {
+    const char* on = getenv("HIPPIE_DEBUG_KNOBS");
+    const char* e = (on && on[0] == '1') ? getenv("HIPPIE_WGRAD_SHARED") : nullptr;
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
 // Build the device tables of one WGRAD_GROUP op from its member records ops[first .. first+count).
 hipError_t hp::build_wgrad_group(const HpOp* members, int count, void* const* bases, void** d_probs, void** d_blocks, int* nblocks) {
   std::vector<WgradArgs> probs(count);
   std::vector<int4> blocks;
   for (int j = 0; j < count; ++j) {
     probs[j] = wgrad_args_from(members[j], bases);
-    const int tiles = hp::cdiv(probs[j].t.N, 64) * hp::cdiv(probs[j].t.K, 64);
+    WgradArgs& q = probs[j];
+    // three-term mode, three taps reading rows m - 1, m, m + 1 of one tensor, at least one full 128-row tile of output channels, summed
+    // with atomics (the split count is then the launch's to choose): wgrad3s_body, on 128 x 64 tiles with half the rows per split
+    if ((members[j].flags & HP_CONV_BF16X3) && !(members[j].flags & HP_FLAG_ACT_BF16) && q.atomic && q.t.ntaps == 3 && q.t.a == 1 && q.t.sh == 0 &&
+        q.t.Lin == q.t.Lout && q.t.P == q.t.Lout && q.t.tap_o[0] == -1 && q.t.tap_o[1] == 0 && q.t.tap_o[2] == 1 && q.t.N >= 128 && wgrad_shared_on()) {
+      q.shared = 1;
+      q.rows_per_split = std::max(32, hp::cdiv(hp::cdiv(q.rows_per_split, 2), 32) * 32);
+      q.nsplit = hp::cdiv(q.t.M, q.rows_per_split);
+    }
+    const int tiles = hp::cdiv(probs[j].t.N, q.shared ? 128 : 64) * hp::cdiv(probs[j].t.K, 64);
     for (int sp = 0; sp < probs[j].nsplit; ++sp)
       for (int tl = 0; tl < tiles; ++tl) blocks.push_back(make_int4(j, tl, sp, 0));
   }
   // longest blocks first (LPT): the group mixes 12-slice and 100-slice blocks, and a long block that starts
   // last is the tail of the whole launch (measured on the time model's 35-problem group: 757 us -> 675 us)
   std::stable_sort(blocks.begin(), blocks.end(), [&](const int4& a, const int4& b) {
-    return probs[a.x].rows_per_split > probs[b.x].rows_per_split;
+    return probs[a.x].rows_per_split * (1 + probs[a.x].shared) > probs[b.x].rows_per_split * (1 + probs[b.x].shared);
   });
   *d_probs = *d_blocks = nullptr;
   hipError_t e = hipMalloc(d_probs, probs.size() * sizeof(WgradArgs));
@@ -1607,8 +1823,8 @@ hipError_t hp::launch_wgrad_group(int ntaps, int bf16, const void* d_probs, cons
     return hipGetLastError();
   }
   if (bf16 == 3) {
-    if (ntaps == 1)      hipLaunchKernelGGL((wgrad_group_kernel<1, 2>), g, th, 0, s, pr, bl);
-    else if (ntaps == 3) hipLaunchKernelGGL((wgrad_group_kernel<3, 2>), g, th, 0, s, pr, bl);
+    if (ntaps == 1)      hipLaunchKernelGGL((wgrad_group3_kernel<1>), g, th, 0, s, pr, bl);
+    else if (ntaps == 3) hipLaunchKernelGGL((wgrad_group3_kernel<3>), g, th, 0, s, pr, bl);
     else return hipErrorInvalidValue;
     return hipGetLastError();
   }

@@ -132,7 +132,7 @@ class OpList:
 
 # ---- shared library ---------------------------------------------------------------
 _LIB = None
-ABI_VERSION = 6          # include/hippie_hip.h: HP_ABI_VERSION
+ABI_VERSION = 7          # include/hippie_hip.h: HP_ABI_VERSION
 
 
 def debug_knob(name, default=None):

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HP_ABI_VERSION 6
+#define HP_ABI_VERSION 7
 
 enum {
   HP_SPACE_WS = 0, HP_SPACE_PARAM = 1, HP_SPACE_GRAD = 2, HP_SPACE_BUF = 3,

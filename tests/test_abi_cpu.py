@@ -19,7 +19,7 @@ def test_header_symbols_are_exported():
     lib = P.load_library()
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.hp_abi_version() == P.ABI_VERSION == 6
+    assert lib.hp_abi_version() == P.ABI_VERSION == 7
 
 
 def test_op_record_layout_matches_header():

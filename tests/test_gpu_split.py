@@ -131,3 +131,31 @@ def test_split_is_exact_over_the_fp32_range():
         recs = rec_of(P.CONV_TAPS, (P.CONV_W_KN if kn else 0) | P.CONV_BF16X3, tm.conv_ints(), (), [a, w, out])
         gpu, _ = run_both(img, recs)
         np.testing.assert_array_equal(view(gpu, out, np.float32, M * N).reshape(M, N), a_np)
+
+
+@pytest.mark.parametrize("L,nb,N,K,nsplit,in_bn", [(1, 70, 128, 64, 1, False), (2, 45, 128, 96, 2, False), (4, 33, 256, 64, 1, True), (7, 50, 256, 256, 3, False),
+                                                    (25, 6, 132, 100, 2, True), (100, 3, 192, 128, 3, False), (50, 5, 512, 64, 4, True)])
+def test_shared_image_weight_gradient_of_three_tap_stride_one_layers(split_records, L, nb, N, K, nsplit, in_bn):
+    """wgrad3s_body (three-term mode, grouped launch, 3 taps reading rows m - 1, m, m + 1 of one tensor, N >= 128): one staged X image serves
+    the three taps, sample boundaries are masks on the DY fragments.  Sample lengths from 1 (every neighbour is a boundary) to 100, row counts
+    that are not multiples of the 32-row slice, ragged channel tiles (N = 132, K = 96 / 100), several splits, with and without the BatchNorm
+    re-evaluation of X — against the interpreter, next to a general-body member in the same launch."""
+    img = Img(500 + L)
+    ol = P.OpList()
+    grads = []
+    tms = [TapMap(nb * L, N, K, L, L, L, 1, 0, [(t - 1, t) for t in range(3)]), T.WGRAD_CASES["up"]()]
+    for j, tm in enumerate(tms):
+        nbb = tm.M // tm.Lout
+        dy, x = img.f32(tm.M * tm.N), img.f32(nbb * tm.Lin * tm.K)
+        numel = 3 * tm.N * tm.K
+        ns0 = nsplit if j == 0 else 1
+        rps = -(-(-(-tm.M // ns0)) // 32) * 32
+        ns = -(-tm.M // rps)
+        g = img.f32(numel, scale=0.5)          # accumulates on top of what is there
+        coef = img.f32(2 * tm.K) if (in_bn and j == 0) else None
+        ol.add(P.WGRAD_TAPS, 1 | P.FLAG_MEMBER | (P.CONV_IN_BN if coef is not None else 0), tm.ints() + [ns, rps, numel], [0.2], [dy, x, g, coef])
+        grads.append((g, numel))
+    ol.add(P.WGRAD_GROUP, 0, [0, len(tms), 3])
+    gpu, cpu = T.run_program_both(img, ol.array())
+    for g, numel in grads:
+        T.check(gpu, cpu, g, numel, rel=3e-5, what=f"shared-image wgrad L={L} N={N} K={K}")

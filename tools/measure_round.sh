@@ -3,7 +3,7 @@
 set -e
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-T=${1:-r04}
+T=${1:-r04b}
 O=$R/gpurun_out/$T
 mkdir -p $O
 cd $R
@@ -39,6 +39,13 @@ rm -rf $O/prof $O/pmc_FETCH_SIZE $O/pmc_WRITE_SIZE $O/pmc_TCC_HIT_sum_TCC_MISS_s
 timeout -k 10 200 python bench.py --dtype bf16 --steps 200 --warmup 20 --no-cpu-baseline --no-trainer --no-dp-probe > $O/${T}_bench_bf16.json 2> $O/${T}_bench_bf16.err
 timeout -k 10 300 python bench.py --batch 4096 --z-dim 32 --wave-len 256 --time-len 32 --units 1000000 --steps 20 --warmup 3 --no-cpu-baseline --no-trainer --no-dp-probe --per-op > $O/${T}_bench_config3_B4096.json 2> $O/${T}_per_op_config3_B4096.txt
 timeout -k 10 400 python bench.py --model-type multimodal --batch 8192 --z-dim 64 --wave-len 256 --time-len 32 --steps 10 --warmup 2 --no-cpu-baseline --no-trainer --no-dp-probe --per-op > $O/${T}_bench_multimodal_B8192.json 2> $O/${T}_multimodal_B8192_per_op.txt
+# the same three lines on the fp32 matrix cores (rounds 1-3's kernels): the A/B behind DESIGN section 5.1's "three-term path" column
+timeout -k 10 300 python bench.py --matrix-path f32 --steps 300 --warmup 30 --no-cpu-baseline --no-trainer --no-dp-probe --per-op > $O/${T}_bench_f32_matrix.json 2> $O/${T}_per_op_f32_matrix.txt
+timeout -k 10 300 python bench.py --matrix-path f32 --batch 4096 --z-dim 32 --wave-len 256 --time-len 32 --units 1000000 --steps 20 --warmup 3 --no-cpu-baseline --no-trainer --no-dp-probe > $O/${T}_bench_config3_B4096_f32_matrix.json 2> /dev/null
+timeout -k 10 400 python bench.py --matrix-path f32 --model-type multimodal --batch 8192 --z-dim 64 --wave-len 256 --time-len 32 --steps 10 --warmup 2 --no-cpu-baseline --no-trainer --no-dp-probe > $O/${T}_bench_multimodal_B8192_f32_matrix.json 2> /dev/null
+# the reduced-precision mode at config 5's shape and the multimodal model at the pipeline's batch 512
+timeout -k 10 400 python bench.py --dtype bf16 --model-type multimodal --batch 8192 --z-dim 64 --wave-len 256 --time-len 32 --steps 10 --warmup 2 --no-cpu-baseline --no-trainer --no-dp-probe --per-op > $O/${T}_bench_multimodal_B8192_bf16.json 2> $O/${T}_multimodal_B8192_bf16_per_op.txt
+timeout -k 10 300 python bench.py --model-type multimodal --batch 512 --steps 200 --warmup 20 --no-cpu-baseline --no-trainer > $O/${T}_bench_multimodal_B512.json 2> /dev/null
 timeout -k 10 300 python tools/micro/op_chain_times.py time > $O/${T}_op_chain_time_model.txt 2>&1 || true
 timeout -k 10 300 python tools/micro/op_chain_times.py wave > $O/${T}_op_chain_wave_model.txt 2>&1 || true
 ls $O
