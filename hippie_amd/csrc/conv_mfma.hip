@@ -32,8 +32,13 @@ __device__ __forceinline__ bf16x4 to_bf16x4(const float4 v) {
 // result carries fp32's own rounding level (the accumulation is fp32 either way), on a pipe 16x the rate of v_mfma_f32_32x32x2_f32 —
 // 2.7x per fp32 product after the six-fold work.
 __device__ __forceinline__ float4 widen4(const bf16x4 h) { return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]); }
+#ifndef HP_ABL
+#define HP_ABL 0      // tools/micro/conv_ablate.sh: 1 = return before the epilogue, 2 = every operand load reads the zero page, 4 = no output store,
+#endif                // 8 = 100 MHz timestamps of the first / last workgroup's phases into the (otherwise unused) E_BS buffer; three-term path (timing only,
+                      // wrong numbers): 16 = only the leading product, 32 = no split arithmetic (m = l = h), 64 = conv_body stores / reads the h image only
 __device__ __forceinline__ void split3(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
   h = to_bf16x4(v);
+  if (HP_ABL & 32) { m = h; l = h; return; }
   const float4 hf = widen4(h);
   const float4 r = make_float4(v.x - hf.x, v.y - hf.y, v.z - hf.z, v.w - hf.w);
   m = to_bf16x4(r);
@@ -99,15 +104,17 @@ struct ConvArgs {
   const float* e_raw2; const float* e_save2;
   double* e_bs; double* e_bs2;
   float e_slope;
+  const char* Wf; const char* Wf2;      // HP_CONV_WFRAG: three-term fragment images of W / W2 (HP_OP_WFRAG, this op's orientation)
   TapMap t;
 };
 
 constexpr int kConvLds = 4 * 64 * 36;   // floats of LDS per workgroup (two double-buffered 64x36 images)
-// matrix mode MM of a conv / weight-gradient body: 0 = fp32 matrix cores, 1 = HP_CONV_BF16, 2 = HP_CONV_BF16X3 (three bf16 images per operand)
+// matrix mode MM of a conv / weight-gradient body: 0 = fp32 matrix cores, 1 = HP_CONV_BF16, 2 = HP_CONV_BF16X3 (three bf16 images per operand),
+// 3 = HP_CONV_BF16X3 | HP_CONV_WFRAG (conv_body only: the B fragments come ready-made from global memory, LDS holds the A images alone)
 constexpr int kSplitA = 64 * 40;        // bf16 elements of one [64 rows][32 k] image (80-byte rows)
 constexpr int kSplitBkn = 32 * 96;      // ... of one [32 k][64 cols] image (192-byte rows, hardware-transpose reads)
 constexpr int conv_lds(int mm, bool w_kn) {      // floats: MM = 2 holds 2 buffers x 3 images per operand
-  return mm == 2 ? (2 * 3 * kSplitA + 2 * 3 * (w_kn ? kSplitBkn : kSplitA)) / 2 : kConvLds;
+  return mm == 3 ? (2 * 3 * kSplitA) / 2 : mm == 2 ? (2 * 3 * kSplitA + 2 * 3 * (w_kn ? kSplitBkn : kSplitA)) / 2 : kConvLds;
 }
 constexpr int kConvCoef = 4 * 512;      // + (scale, shift) of up to 512 input channels, then as many zeros (HP_CONV_IN_BN)
 constexpr int conv_extra_lds(int mode) { return mode == 1 ? kConvCoef : 0; }
@@ -115,9 +122,6 @@ constexpr int kConvThreads = 512;
 
 // Shared epilogue of the conv bodies: sums the two K-halves of every quadrant through LDS, then bias / BatchNorm
 // statistics, the eval-mode BatchNorm fold, or the fused BatchNorm-backward reduction.
-#ifndef HP_ABL
-#define HP_ABL 0      // tools/micro/conv_ablate.sh: 1 = return before the epilogue, 2 = every operand load reads the zero page, 4 = no output store,
-#endif                // 8 = 100 MHz timestamps of the first / last workgroup's phases into the (otherwise unused) E_BS buffer
 #if HP_ABL & 8
 #define HP_TS(k)                                                                                  \
   if (threadIdx.x == 0 && p.e_bs != nullptr) {                                                    \
@@ -292,7 +296,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& p, f32x16 (&acc2)[
 // MODE: 0 = the A operand is a stored tensor; 1 = HP_CONV_IN_BN
 template <bool W_KN, int MODE, int MM = 0, bool ABF = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, float* smem) {
-  constexpr bool BF16 = MM == 1, SPLIT = MM == 2;
+  constexpr bool BF16 = MM == 1, SPLIT = MM == 2 || MM == 3, FRAG = MM == 3;
   constexpr int BIMG = W_KN ? kSplitBkn : kSplitA;      // SPLIT: bf16 elements of one B image; buffers hold 3 images each, A buffers first
   constexpr int ES = ABF ? 2 : 4;      // bytes per stored activation element (HP_FLAG_ACT_BF16; only with BF16)
   constexpr bool IN_BN = MODE == 1;
@@ -363,7 +367,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   auto fetch = [&]() -> Pref {
     Pref r;
     r.a = aload4p<ABF>(pa);
-    r.b = gload4(pb);
+    r.b = FRAG ? make_float4(0.f, 0.f, 0.f, 0.f) : gload4(pb);
     r.kq = 0;
     if (IN_BN) r.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;      // a padded row reads (scale, shift) = (0, 0): its activation is exactly 0
     advance();
@@ -401,9 +405,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
       __bf16* Bh = reinterpret_cast<__bf16*>(smem) + 6 * kSplitA + buf * 3 * BIMG + (W_KN ? kr * kLdtH + nq : ar * kLdaH + aq);
       bf16x4 h, m, l;
       split3(r.a, h, m, l);
-      *reinterpret_cast<bf16x4*>(Ah) = h; *reinterpret_cast<bf16x4*>(Ah + kSplitA) = m; *reinterpret_cast<bf16x4*>(Ah + 2 * kSplitA) = l;
+      *reinterpret_cast<bf16x4*>(Ah) = h;
+      if (!(HP_ABL & 64)) { *reinterpret_cast<bf16x4*>(Ah + kSplitA) = m; *reinterpret_cast<bf16x4*>(Ah + 2 * kSplitA) = l; }
+      if (FRAG) return;
       split3(r.b, h, m, l);
-      *reinterpret_cast<bf16x4*>(Bh) = h; *reinterpret_cast<bf16x4*>(Bh + BIMG) = m; *reinterpret_cast<bf16x4*>(Bh + 2 * BIMG) = l;
+      *reinterpret_cast<bf16x4*>(Bh) = h;
+      if (!(HP_ABL & 64)) { *reinterpret_cast<bf16x4*>(Bh + BIMG) = m; *reinterpret_cast<bf16x4*>(Bh + 2 * BIMG) = l; }
       return;
     }
     if (BF16) {
@@ -428,6 +435,32 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[q][r] = 0.f;
 
+  // FRAG (HP_CONV_WFRAG): the three-term B fragments of a K step are 3 x 16 bytes per lane, read ready-made from the image HP_OP_WFRAG wrote
+  // ([slab][K/16][ceil(N/32)][3][64 lanes][8] bf16), one K step ahead — no weight tile in LDS, no split of the weights in this kernel.
+  // This wave's chunk of step (tap j, chunk kc): (slab tap_w[j], k slab 2 kc + kh, column tile n0/32 + wn).
+  bf16x8 bfn[3];             // (two steps in flight — a second register set — measured slower: 126.8 k against 131.9 k samples/s without fragments, the
+  const char* pf = nullptr;  //  twelve extra registers spill inside the steps at 128; one step ahead: 138.4 k against 135.7 k)
+  int f_tap = 0, f_kc = 0;
+  const int f_jn = (t.N + 31) >> 5;
+  const size_t f_step = (size_t)2 * f_jn * 3072;
+  auto set_ftap = [&](int tap) {
+    const char* base = t.tap_src[tap] != 0 ? p.Wf2 : p.Wf;
+    const int jn = min((n0 >> 5) + wn, f_jn - 1);          // (a column tile past N: its columns are never stored)
+    pf = base + (((size_t)t.tap_w[tap] * (t.K >> 4) + kh) * f_jn + jn) * 3072 + lane * 16;
+  };
+  auto fetch_bfrag = [&]() {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const hp_v4u u = *(const hp_v4u __attribute__((address_space(1)))*)(pf + c * 1024);
+      union { hp_v4u u; bf16x8 v; } w; w.u = u; bfn[c] = w.v;
+    }
+    pf += f_step;
+    if (++f_kc == kper) {
+      f_kc = 0;
+      if (++f_tap < t.ntaps) set_ftap(f_tap);
+    }
+  };
+  if (FRAG) set_ftap(0);
   // One K-step.  LDS[BUF] holds the current slice; ST holds the next one (stored to the other buffer before
   // the second MFMA group); LD receives the slice after that.  Lane (i,h) takes k = 8kk+4h..+3 of its row and
   // MFMA jj pairs element jj of both operands — a K permutation applied identically to A and B.
@@ -461,25 +494,30 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
     const __bf16* Bh = reinterpret_cast<const __bf16*>(smem) + 6 * kSplitA + (BUF) * 3 * BIMG;          \
     bf16x8 af[3], bf[3];                                                                                \
     _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                                     \
+      if ((HP_ABL & 64) && c > 0) { af[c] = af[0]; bf[c] = bf[0]; continue; }                           \
       af[c] = *reinterpret_cast<const bf16x8*>(Ah + c * kSplitA);                                       \
+      if (FRAG) { bf[c] = bfn[c]; continue; }                                                           \
       if (!W_KN) bf[c] = *reinterpret_cast<const bf16x8*>(Bh + c * BIMG + (wn * 32 + li) * kLdaH + kh * 16 + lh * 8); \
       else       bf[c] = tr_operand(Bh + c * BIMG, kLdtH, kh * 16, wn * 32, lane);                      \
     }                                                                                                   \
     if (STASH) load_coef(ST);                                                                           \
+    if (FRAG && (STASH)) fetch_bfrag();         /* (STASH: step s + 1 exists) */                        \
     if (FETCH) {                                                                                        \
       LD.a = aload4p<ABF>(pa);                                                                          \
-      LD.b = gload4(pb);                                                                                \
+      if (!FRAG) LD.b = gload4(pb);                                                                     \
       if (IN_BN) LD.kq = (ia ? 0 : 2 * t.K) + kc * 32 + aq;                                             \
       __builtin_amdgcn_sched_barrier(0);                                                                \
       advance();                                                                                        \
     }                                                                                                   \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc2[1], 0, 0, 0);                  \
+    if (!(HP_ABL & 16)) acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc2[1], 0, 0, 0); \
     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc2[0], 0, 0, 0);                  \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc2[1], 0, 0, 0);                  \
+    if (!(HP_ABL & 16)) acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc2[1], 0, 0, 0); \
     if (STASH) stash((BUF) ^ 1, ST);                                                                    \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc2[1], 0, 0, 0);                  \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc2[1], 0, 0, 0);                  \
-    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc2[1], 0, 0, 0);                  \
+    if (!(HP_ABL & 16)) {                                                                               \
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc2[1], 0, 0, 0);                \
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc2[1], 0, 0, 0);                \
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc2[1], 0, 0, 0);                \
+    }                                                                                                   \
     __syncthreads();                                                                                    \
   }
 #define HP_KSTEP(BUF, ST, LD, FETCH, STASH)                                                             \
@@ -540,6 +578,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& p, const int bid, floa
   HP_TS(1)
   int s = 0;
   if (SPLIT) {
+    if (FRAG) fetch_bfrag();
     for (; s + 3 < nsteps; s += 2) {
       HP_KSTEP_S(0, setA, setB, true, true)
       HP_KSTEP_S(1, setB, setA, true, true)
@@ -1164,6 +1203,8 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
   a.e_raw2 = hp::ptr<const float>(op, 21, bases); a.e_save2 = hp::ptr<const float>(op, 22, bases);
   a.e_bs2 = hp::ptr<double>(op, 23, bases);
   a.e_slope = op.f[5];
+  a.Wf = a.Wf2 = nullptr;
+  if (op.flags & HP_CONV_WFRAG) { a.Wf = hp::ptr<const char>(op, 24, bases); a.Wf2 = hp::ptr<const char>(op, 25, bases); }
   return a;
 }
 
@@ -1171,11 +1212,12 @@ static ConvArgs conv_args_from(const HpOp& op, void* const* bases) {
 // may mix it with plain members), 0 = plain
 static int conv_mode(int flags) { return (flags & HP_CONV_IN_BN) ? 1 : 0; }
 // matrix mode: 0 = fp32 matrix cores, 1 = HP_CONV_BF16, 2 = HP_CONV_BF16X3
-static int conv_mm(int flags) { return (flags & HP_CONV_BF16) ? 1 : (flags & HP_CONV_BF16X3) ? 2 : 0; }
+static int conv_mm(int flags) { return (flags & HP_CONV_BF16) ? 1 : (flags & HP_CONV_BF16X3) ? ((flags & HP_CONV_WFRAG) ? 3 : 2) : 0; }
 
 #define HP_CONV_DISPATCH(KERNEL, KN, MODE, BF, ABF, ...)                                                \
   do {                                                                                                  \
-    if (BF == 2)          { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 2>), __VA_ARGS__); } \
+    if (BF == 3)          { hipLaunchKernelGGL((KERNEL<false, 1, 3>), __VA_ARGS__); }      /* (the weight layout only shapes the B loader, which this form does not have) */ \
+    else if (BF == 2)     { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 2>), __VA_ARGS__); } \
     else if (BF && ABF)        { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 1, true>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 1, true>), __VA_ARGS__); } \
     else if (BF)          { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 1>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 1>), __VA_ARGS__); } \
     else if (MODE == 1)   { if (KN) hipLaunchKernelGGL((KERNEL<true, 1, 0>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 1, 0>), __VA_ARGS__); } \
@@ -1210,7 +1252,7 @@ static int conv_big_nt(const TapMap& t) {
   } while (0)
 
 hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* bases, hipStream_t s) {
-  if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) != (opb.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) ||
+  if ((opa.flags & 1) != (opb.flags & 1) || (opa.flags & (HP_CONV_BF16 | HP_CONV_BF16X3 | HP_CONV_WFRAG)) != (opb.flags & (HP_CONV_BF16 | HP_CONV_BF16X3 | HP_CONV_WFRAG)) ||
       (opa.flags & HP_FLAG_ACT_BF16) != (opb.flags & HP_FLAG_ACT_BF16)) return hipErrorInvalidValue;
   const bool abf = opa.flags & HP_FLAG_ACT_BF16;
   if (abf && !(opa.flags & HP_CONV_BF16)) return hipErrorInvalidValue;      // bf16-stored activations only with the bf16 matrix path

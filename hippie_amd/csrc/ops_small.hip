@@ -1418,13 +1418,68 @@ BnBwdApplyArgs bn_bwd_apply_args(const HpOp& op, void* const* bases) {
 }
 
 
+// ---- HP_OP_WFRAG: three-term MFMA fragments of a conv weight tensor (include/hippie_hip.h) -----------------------------------------
+struct WfragArgs {
+  const float* W; unsigned short* F; unsigned short* G;
+  int T, N, K, which;
+};
+// One workgroup: the 32 x 32 block (n32, k32) of slab t, read once (rows of 128 contiguous bytes), split, and written as its two F chunks
+// (waves 0, 1: the block's two 16-wide k slabs) and its two G chunks (waves 2, 3: its two 16-row n slabs).
+__device__ __forceinline__ void wfrag_body(const WfragArgs& p, const int blk, float* tile /* [32][33] */) {
+  const int kb = p.K >> 5, nb = (p.N + 31) >> 5;
+  const int k32 = blk % kb, n32 = (blk / kb) % nb, t = blk / (kb * nb);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int r = tid >> 3, c = (tid & 7) << 2;          // 32 rows x 8 four-float pieces
+    const int n = n32 * 32 + r;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < p.N) v = *reinterpret_cast<const float4*>(p.W + ((size_t)t * p.N + n) * p.K + k32 * 32 + c);
+    tile[r * 33 + c] = v.x; tile[r * 33 + c + 1] = v.y; tile[r * 33 + c + 2] = v.z; tile[r * 33 + c + 3] = v.w;
+  }
+  __syncthreads();
+  const int j = lane & 31, h = lane >> 5, q = wave & 1;
+  const bool g_form = wave >= 2;
+  if (!(p.which & (g_form ? 2 : 1))) return;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = g_form ? tile[(q * 16 + 8 * h + e) * 33 + j] : tile[j * 33 + q * 16 + 8 * h + e];
+  unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    unsigned short hb[2], mb[2], lb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float v = x[2 * d + u];
+      const __bf16 h1 = (__bf16)v;
+      const float r1 = v - (float)h1;
+      const __bf16 m1 = (__bf16)r1;
+      const __bf16 l1 = (__bf16)(r1 - (float)m1);
+      hb[u] = *reinterpret_cast<const unsigned short*>(&h1); mb[u] = *reinterpret_cast<const unsigned short*>(&m1); lb[u] = *reinterpret_cast<const unsigned short*>(&l1);
+    }
+    hh[d] = (unsigned)hb[0] | ((unsigned)hb[1] << 16); mm[d] = (unsigned)mb[0] | ((unsigned)mb[1] << 16); ll[d] = (unsigned)lb[0] | ((unsigned)lb[1] << 16);
+  }
+  // chunk (t, ks, jn) of the image [T][KK/16][JN][3][64][8]: F: KK = K, JN = ceil(N/32), ks = 2 k32 + q, jn = n32;  G: KK = N, JN = K/32, ks = 2 n32 + q, jn = k32
+  size_t chunk;
+  unsigned short* img;
+  if (!g_form) { img = p.F; chunk = ((size_t)t * (p.K >> 4) + 2 * k32 + q) * nb + n32; }
+  else         { img = p.G; chunk = ((size_t)t * (((p.N + 31) >> 5) * 2) + 2 * n32 + q) * kb + k32; }
+  uint4* dst = reinterpret_cast<uint4*>(img + chunk * (3 * 64 * 8)) + lane;
+  dst[0] = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+  dst[64] = make_uint4(mm[0], mm[1], mm[2], mm[3]);
+  dst[128] = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+}
+__global__ __launch_bounds__(256) void wfrag_kernel(WfragArgs p) {
+  __shared__ float tile[32 * 33];
+  wfrag_body(p, blockIdx.x, tile);
+}
+
 // ---- argument records of the small ops that are launched from a table (the small-leaf group) or share their argument
 // decoding with it --------------------------------------------------------------------------------------------------
 struct SmallEntry {
   int op, variant;          // HP_OP_* ; variant: LINEAR_BWD_W: 1 = matrix-core form (a.wg; gx = tiles, gy = splits)
   int gx, gy, gz;           // virtual grid of 256-thread blocks
   int rows_per_z;           // LINEAR_BWD_W
-  union { LinArgs lin; LinWg wg; EmbArgs emb; ReparamArgs rp; MseArgs mse; LossArgs loss; } a;
+  union { LinArgs lin; LinWg wg; EmbArgs emb; ReparamArgs rp; MseArgs mse; LossArgs loss; WfragArgs wf; } a;
 };
 
 // args + grid of one such op; false for any other opcode
@@ -1433,6 +1488,12 @@ bool small_entry(const HpOp& op, void* const* bases, SmallEntry& e) {
   const int32_t* I = op.i;
   e.op = op.op; e.variant = 0; e.gx = e.gy = e.gz = 1; e.rows_per_z = 0;
   switch (op.op) {
+    case HP_OP_WFRAG: {
+      WfragArgs a{ptr<const float>(op, 0, bases), ptr<unsigned short>(op, 1, bases), ptr<unsigned short>(op, 2, bases), I[0], I[1], I[2], I[3]};
+      e.a.wf = a;
+      e.gx = I[0] * hp::cdiv(I[1], 32) * (I[2] / 32);
+      return true;
+    }
     case HP_OP_EMB_BWD: {
       EmbArgs a{ptr<const float>(op, 0, bases), ptr<const int64_t>(op, 1, bases), ptr<float>(op, 2, bases), I[0], I[1], I[2], I[3], I[4], op.flags & 1};
       e.a.emb = a;
@@ -1511,6 +1572,21 @@ __global__ __launch_bounds__(256) void small_group_kernel(const SmallEntry* __re
       } else if (e.op == HP_OP_EMB_BWD) {
         emb_bwd_body(e.a.emb, bx);
       }
+      return;
+    }
+    b -= nb;
+  }
+}
+
+// a small-leaf group of HP_OP_WFRAG records (a group holds only such records): all conv weights of a model in one launch
+__global__ __launch_bounds__(256) void wfrag_group_kernel(const SmallEntry* __restrict__ entries, int n) {
+  __shared__ float tile[32 * 33];
+  int b = blockIdx.x;
+  for (int k = 0; k < n; ++k) {
+    const int nb = entries[k].gx;
+    if (b < nb) {
+      const WfragArgs w = entries[k].a.wf;      // by value: one scalar load of the record up front
+      wfrag_body(w, b, tile);
       return;
     }
     b -= nb;
@@ -1632,6 +1708,12 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
       SmallEntry e;
       small_entry(op, bases, e);
       hipLaunchKernelGGL(emb_bwd_kernel, dim3(e.gx), dim3(256), 0, s, e.a.emb);
+      break;
+    }
+    case HP_OP_WFRAG: {
+      SmallEntry e;
+      small_entry(op, bases, e);
+      hipLaunchKernelGGL(wfrag_kernel, dim3(e.gx), dim3(256), 0, s, e.a.wf);
       break;
     }
     case HP_OP_LINEAR_FWD: {
@@ -1806,12 +1888,13 @@ hipError_t hp::launch_small(const HpOp& op, void* const* bases, hipStream_t s) {
 
 
 // ---- small-leaf group: host side ------------------------------------------------------------------------------------
-bool hp::groupable(const HpOp& op) { return op.op == HP_OP_LINEAR_BWD_W || op.op == HP_OP_EMB_BWD; }
+bool hp::groupable(const HpOp& op) { return op.op == HP_OP_LINEAR_BWD_W || op.op == HP_OP_EMB_BWD || op.op == HP_OP_WFRAG; }
 
 hipError_t hp::build_small_group(const HpOp* members, int count, void* const* bases, void** d_entries) {
   std::vector<SmallEntry> entries(count);
   for (int j = 0; j < count; ++j)
-    if (!hp::groupable(members[j]) || !small_entry(members[j], bases, entries[j])) return hipErrorInvalidValue;
+    if (!hp::groupable(members[j]) || !small_entry(members[j], bases, entries[j]) ||
+        (members[j].op == HP_OP_WFRAG) != (members[0].op == HP_OP_WFRAG)) return hipErrorInvalidValue;      // (WFRAG records group among themselves)
   *d_entries = nullptr;
   hipError_t e = hipMalloc(d_entries, entries.size() * sizeof(SmallEntry));
   if (e != hipSuccess) return e;
@@ -1829,6 +1912,10 @@ hipError_t hp::launch_small_group(const HpOp* members, const void* d_entries, in
     if (!small_entry(members[j], zero_bases, e)) return hipErrorInvalidValue;      // (grid only: the device table holds the pointers)
     blocks += e.gx * e.gy * e.gz;
     mfma = mfma || e.variant == 1;
+  }
+  if (members[0].op == HP_OP_WFRAG) {
+    hipLaunchKernelGGL(wfrag_group_kernel, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
+    return hipGetLastError();
   }
   if (mfma) hipLaunchKernelGGL(small_group_kernel<true>, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);
   else hipLaunchKernelGGL(small_group_kernel<false>, dim3(blocks), dim3(256), 0, s, (const SmallEntry*)d_entries, count);

@@ -265,7 +265,20 @@ int op_extents(const HpOp& op, int64_t (&need)[HP_OP_NB]) {
       need[7] = B * f8; need[8] = B * z * f4; need[9] = f8;
       break;
     }
+    case HP_OP_WFRAG: {
+      const int64_t T = I[0], N = I[1], K = I[2];
+      need[0] = T * N * K * f4;
+      if (I[3] & 1) need[1] = T * (K / 16) * ((N + 31) / 32) * 3072;
+      if (I[3] & 2) need[2] = T * (((N + 31) / 32) * 2) * (K / 32) * 3072;
+      break;
+    }
     default: break;
+  }
+  if (op.op == HP_OP_CONV_TAPS && (op.flags & HP_CONV_WFRAG)) {
+    // fragment images of the weights this op multiplies with: [slabs][K/16][ceil(N/32)] chunks of 3072 bytes
+    const int64_t chunks = (int64_t)(I[2] / 16) * ((I[1] + 31) / 32) * 3072;
+    if (need[1] > 0) need[24] = need[1] / ((int64_t)I[1] * I[2] * f4) * chunks;
+    if (need[11] > 0) need[25] = need[11] / ((int64_t)I[1] * I[2] * f4) * chunks;
   }
   if (op.flags & HP_FLAG_ACT_BF16) {
     // the op's activation-typed buffers hold bf16: half the bytes (which buffers: include/hippie_hip.h, HP_FLAG_ACT_BF16)
@@ -343,6 +356,17 @@ int validate_op(const HpOp& op, const int64_t* sizes, int index, std::string& wh
       why = buf;
       return 1;
     }
+  }
+  if (op.op == HP_OP_WFRAG && (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] <= 0 || (op.i[1] % 4) != 0 || (op.i[2] % 32) != 0 || (op.i[3] & ~3) != 0 || (op.i[3] & 3) == 0 ||
+                               ((op.i[3] & 2) && (op.i[1] % 32) != 0))) {
+    snprintf(buf, sizeof buf, "op %d: bad WFRAG shape (T=%d N=%d K=%d which=%d: N %% 4, K %% 32, the G form N %% 32)", index, op.i[0], op.i[1], op.i[2], op.i[3]);
+    why = buf;
+    return 1;
+  }
+  if (op.op == HP_OP_CONV_TAPS && (op.flags & HP_CONV_WFRAG) && (!(op.flags & HP_CONV_BF16X3) || (op.flags & HP_FLAG_ACT_BF16))) {
+    snprintf(buf, sizeof buf, "op %d: HP_CONV_WFRAG needs HP_CONV_BF16X3 (and fp32-stored activations)", index);
+    why = buf;
+    return 1;
   }
   if (op.op == HP_OP_STAGE_BATCH && (op.i[0] <= 0 || op.i[1] <= 0 || op.i[2] < 0 || op.i[3] <= 0 || op.i[4] <= 0 || op.i[5] <= 0 || op.i[6] < 0 ||
                                      op.i[6] >= op.i[5] || op.i[7] <= 0)) {
@@ -427,7 +451,7 @@ int hp_program_validate(const HpProgram* p) {
       const HpOp& b = p->ops[g.i[1]];
       const bool kind_ok = a.op == b.op && (a.flags & HP_FLAG_MEMBER) && (b.flags & HP_FLAG_MEMBER) &&
                            (a.flags & HP_FLAG_ACT_BF16) == (b.flags & HP_FLAG_ACT_BF16) &&
-                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & (HP_CONV_BF16 | HP_CONV_BF16X3)) == (b.flags & (HP_CONV_BF16 | HP_CONV_BF16X3))) ||
+                           ((a.op == HP_OP_CONV_TAPS && (a.flags & 1) == (b.flags & 1) && (a.flags & (HP_CONV_BF16 | HP_CONV_BF16X3 | HP_CONV_WFRAG)) == (b.flags & (HP_CONV_BF16 | HP_CONV_BF16X3 | HP_CONV_WFRAG))) ||
                             ((a.op == HP_OP_BN_APPLY || a.op == HP_OP_BN_BWD_REDUCE || a.op == HP_OP_BN_BWD_APPLY) &&
                              (a.i[1] % 4 == 0) == (b.i[1] % 4 == 0)));
       if (!kind_ok) return fail("pair op " + std::to_string(k) + ": members are not two pairable ops of one kind");

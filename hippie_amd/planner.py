@@ -106,6 +106,12 @@ class TrainCfg:
                                         # ... decoder_fc BatchNorm) run as ONE single-workgroup launch (HP_OP_HEADS, csrc/heads_fused.h: 30 us
                                         # against 39 us); the un-fused records stay in the program as its members.  (A backward twin was built,
                                         # tested and removed: 94 us against 42 us, heads_fused.h.)
+    weight_fragments: bool = P.debug_knob("HIPPIE_NO_WFRAG") != "1"      # (the knob: A/B runs of unmodified callers)
+                                        # mfma_dtype "bf16x3": every forward pass starts with ONE launch that splits all conv weights into their three bf16
+                                        # terms and lays them out in MFMA fragment order (HP_OP_WFRAG, both orientations in the training passes); the
+                                        # conv launches served by the 64x64 body then read their B fragments ready-made (HP_CONV_WFRAG) instead of
+                                        # loading, splitting and staging the weight tile through LDS per tile and K step — the same products in the
+                                        # same order, bit-identical results; half the LDS traffic and half the split arithmetic of a K step
     bucketed_bwd: bool = False          # data parallel: the backward segment in two halves, "bwd_dec" (decoders + decoder-side heads, incl.
                                         # THEIR weight-gradient group) and "bwd_enc" (the rest); Plan.grad_buckets lists, per half, the ranges of
                                         # the gradient arena that are complete when it ends, so that the all-reduce of the decoder-side bucket
@@ -229,9 +235,16 @@ class Plan:
 
 # ======================================================================================
 class Lowering:
-    def __init__(self, cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, wgrad_target_blocks=256):
+    def __init__(self, cfg: ModelCfg, batch: int, train: TrainCfg = None, with_class=False, wgrad_target_blocks=256, wfrag_needed=None):
         self.cfg, self.B = cfg, batch
         self.train = train or TrainCfg()
+        # weight-fragment images (TrainCfg.weight_fragments): which (weight key, HP_CONV_W_KN) pairs the convs of a mode use is only known
+        # once the mode has been lowered, and the HP_OP_WFRAG records stand at the HEAD of the forward segment — so `lower` runs the
+        # lowering twice: a first pass that only records the uses (wfrag_used), a second one that is told them (wfrag_needed)
+        self.wfrag_needed = wfrag_needed
+        self.wfrag_used = {"train": set(), "eval": set()}
+        self.wfrag_refs = {}                 # (weight key, w_kn) -> Ref of its fragment image
+        self.mode = None
         self.with_class = with_class
         self.target_blocks = wgrad_target_blocks
         self.pl = Plan(cfg, batch, self.train, with_class)
@@ -373,6 +386,15 @@ class Lowering:
             bufs[15:24] = [epi["g2"], epi["act"], epi["raw"], epi["bn"]["save"], epi["coef"], epi["bs"], epi["raw_b"],
                            epi["bn_b"]["save"] if epi["bn_b"] is not None else None, epi["bs_b"]]
             note += " + " + epi["bn"]["prefix"] + " bwd-reduce"
+        if (flags & P.CONV_BF16X3) and self.train.weight_fragments and self.mode is not None and tm.K % 32 == 0 and (not w_kn or tm.N % 32 == 0):
+            keys = [(w.key, bool(w_kn))] + ([(w2.key, bool(w_kn))] if a2 is not None else [])
+            self.wfrag_used[self.mode].update(keys)
+            if all(k in self.wfrag_refs for k in keys):
+                flags |= P.CONV_WFRAG
+                bufs += [None] * (P.NB - len(bufs))
+                bufs[24] = self.wfrag_refs[keys[0]]
+                if a2 is not None:
+                    bufs[25] = self.wfrag_refs[keys[1]]
         self.o.add(P.CONV_TAPS, flags, i=ii, f=ff, buf=bufs, note=note)
         self.conv_rec_of[out.encode()] = len(self.o.recs) - 1
         if self.count_flops and not w_kn:
@@ -437,7 +459,7 @@ class Lowering:
                 return False
             fa, fb = int(ra["flags"]), int(rb["flags"])
             if op == P.CONV_TAPS:
-                return (fa & 1) == (fb & 1) and (fa & (P.CONV_BF16 | P.CONV_BF16X3)) == (fb & (P.CONV_BF16 | P.CONV_BF16X3))
+                return (fa & 1) == (fb & 1) and (fa & (P.CONV_BF16 | P.CONV_BF16X3 | P.CONV_WFRAG)) == (fb & (P.CONV_BF16 | P.CONV_BF16X3 | P.CONV_WFRAG))
             return (int(ra["i"][1]) % 4 == 0) == (int(rb["i"][1]) % 4 == 0)       # both on the same vector width (C % 4)
 
         order = []                                           # ("o", old index) | ("p", old a, old b)
@@ -976,6 +998,38 @@ class Lowering:
             r["flags"] = int(r["flags"]) | P.FLAG_MEMBER
         self.o.add(P.HEADS, 0, i=[first, n, kind], note=note)
 
+    def emit_wfrags(self, part=None):
+        """The HP_OP_WFRAG records of the pass that is about to be lowered (self.mode): one per conv weight tensor its convs were seen to
+        use on the recording pass, forward (F) and / or HP_CONV_W_KN (G) orientation, as small-leaf groups of at most 64 records — one or
+        two launches for all conv weights of a model.  Images are allocated once per lowering and shared by the train and eval passes.
+        part: None = every weight; "enc" / "dec" = all but the decoders' / the decoders' (the eval forward fragments the decoders' weights
+        where its encoder-only prefix ends, so that the embedding path does not pay for them)."""
+        need = (self.wfrag_needed or {}).get(self.mode)
+        if not need:
+            return
+        recs = []
+        for key in sorted({k for k, _ in need}):
+            if part is not None and key.startswith("decoder") != (part == "dec"):
+                continue
+            w = self.pl.params[key]
+            N, K, T = w.shape                      # reference shape (C_out, C_in, taps); stored tap-major [taps][C_out][C_in] ("tnc"; a 1-tap weight: the same bytes)
+            assert w.layout == "tnc" or T == 1, key
+            which = (1 if (key, False) in need else 0) | (2 if (key, True) in need else 0)
+            for w_kn, bit in ((False, 1), (True, 2)):
+                if (which & bit) and (key, w_kn) not in self.wfrag_refs:
+                    chunks = T * (K // 16) * (-(-N // 32)) if not w_kn else T * ((-(-N // 32)) * 2) * (K // 32)
+                    self.wfrag_refs[(key, w_kn)] = self.pl.ws(chunks * 3072)
+            recs.append(([T, N, K, which], [w.ref, self.wfrag_refs.get((key, False)) if which & 1 else None,
+                                            self.wfrag_refs.get((key, True)) if which & 2 else None], key))
+        for g0 in range(0, len(recs), 64):
+            grp = recs[g0: g0 + 64]
+            n = len(grp)
+            for j, (ii, bufs, key) in enumerate(grp):
+                fl = 0
+                if n > 1:
+                    fl = P.FLAG_MEMBER if j < n - 1 else ((n - 1) << P.FLAG_GROUP_SHIFT)
+                self.o.add(P.WFRAG, fl, i=ii, buf=bufs, note="three-term fragments of " + key + (f" [group of {n}]" if n > 1 and j == n - 1 else ""))
+
     def flush_wgrads(self):
         """Emit the deferred weight-gradient GEMMs as one grouped launch per tap count, then the deferred small leaves as one
         small-leaf group (inside the open segment)."""
@@ -1080,8 +1134,10 @@ class Lowering:
             training = mode == "train"
             self.abf = training and self.train.act_dtype == "bf16"      # (stays set through the backward pass emitted below)
             self.count_flops = training
+            self.mode = mode
             self.o.begin("fwd_" + mode)
             zero_idx = self.o.add(P.ZERO, 0, i=[0, 0], buf=[Ref(P.WS, pl.stats_base)], note="zero statistics")
+            self.emit_wfrags(None if training else "enc")
             marks = [len(self.o.recs)]
             pooled = []
             for e, x, L in zip(enc, xs, lens):
@@ -1124,6 +1180,7 @@ class Lowering:
                 # encoder-only prefix of the eval forward: (enc, mu, logvar) are complete here.  The embedding path
                 # (scripts/utils.py:75-101) keeps only `enc`, so the decoder (44-59 % of the FLOPs) can be skipped.
                 enc_eval_end = len(self.o.recs)
+                self.emit_wfrags("dec")
             zz = pl.f32(B * z)
             self.o.add(P.REPARAM_KL_FWD, 0, i=[B, z], buf=[mulv, eps, zz, loss], note="reparameterize + KL")
             ncat1 = z + 2 * H
@@ -1479,4 +1536,9 @@ def lower_backbone(spec: BackboneCfg, batch: int, train: TrainCfg = None) -> Pla
 def lower(cfg, batch: int, train: TrainCfg = None, with_class=False, **kw) -> Plan:
     if isinstance(cfg, BackboneCfg):
         return lower_backbone(cfg, batch, train)
-    return Lowering(cfg, batch, train, with_class, **kw).build()
+    first = Lowering(cfg, batch, train, with_class, **kw)
+    plan = first.build()
+    if not any(first.wfrag_used.values()):
+        return plan
+    # (second pass: the same lowering with the HP_OP_WFRAG records at the head of each forward segment and HP_CONV_WFRAG on the convs they serve)
+    return Lowering(cfg, batch, train, with_class, wfrag_needed=first.wfrag_used, **kw).build()

@@ -16,21 +16,22 @@ WS, PARAM, GRAD, BUF, ADAM_M, ADAM_V = range(6)
 NUM_SPACES = 6
 NULL = -1
 MAX_TAPS = 6
-NI, NF, NB = 40, 8, 24
+NI, NF, NB = 40, 8, 26
 
 OP_DTYPE = np.dtype([("op", "<i4"), ("flags", "<i4"), ("i", "<i4", (NI,)), ("f", "<f4", (NF,)),
                      ("buf", "<i8", (NB,))], align=True)
-assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 392
+assert OP_DTYPE.itemsize == 8 + 4 * NI + 4 * NF + 8 * NB == 408
 
 (CONV_TAPS, WGRAD_TAPS, SLAB_REDUCE, BN_APPLY, BN_BWD_REDUCE, BN_BWD_APPLY, STEM_FWD, STEM_WGRAD, POOL_FWD,
  POOL_BWD, REPEAT_FWD, REPEAT_BWD, CONCAT, EMB_BWD, LINEAR_FWD, LINEAR_BWD_X, LINEAR_BWD_W, REPARAM_KL_FWD,
  REPARAM_KL_BWD, MSE_FWD_BWD, TAIL_FWD, TAIL_BWD_X, TAIL_BWD_W, LOSS_FINALIZE, GRADNORM, ADAMW, STEP_INC,
- ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR, SF_SCHEDULE, ADAMW_SF, LERP, STATS_SYNC, STAGE_BATCH, HEADS) = range(1, 38)
+ ZERO, WGRAD_GROUP, PAIR, RESAMPLE_LINEAR, SF_SCHEDULE, ADAMW_SF, LERP, STATS_SYNC, STAGE_BATCH, HEADS, WFRAG) = range(1, 39)
 OP_NAMES = {v: k for k, v in list(globals().items()) if isinstance(v, int) and k.isupper() and k not in (
     "WS", "PARAM", "GRAD", "BUF", "ADAM_M", "ADAM_V", "NUM_SPACES", "NULL", "MAX_TAPS", "NI", "NF", "NB")}
 
 CONV_W_KN, CONV_BIAS, CONV_STATS, CONV_BN_EVAL, CONV_ACT, CONV_IN_BN, CONV_EPI_BNRED, CONV_BF16 = 1, 2, 4, 8, 16, 64, 128, 256
 CONV_BF16X3 = 0x800      # fp32 arithmetic on the bf16 matrix cores (three-term operand split; include/hippie_hip.h)
+CONV_WFRAG = 0x1000      # ... with the weight fragments read ready-made from an HP_OP_WFRAG image (buf[24], buf[25])
 FLAG_MEMBER = 0x200      # HP_FLAG_MEMBER: executed by the following WGRAD_GROUP / PAIR launch or by the small-leaf group it belongs to
 FLAG_ACT_BF16 = 0x400            # the op's activation-typed buffers hold bfloat16 (include/hippie_hip.h)
 FLAG_GROUP_SHIFT, FLAG_GROUP_MASK, GROUP_MAX = 16, 0xFF, 64     # small-leaf group: see include/hippie_hip.h

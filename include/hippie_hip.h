@@ -64,7 +64,7 @@ static inline HP_HD int hp_stat_repl(int C) {      /* largest power of two <= 10
 }
 #define HP_OP_NI 40
 #define HP_OP_NF 8
-#define HP_OP_NB 24
+#define HP_OP_NB 26
 
 /* Op flag: the record is a MEMBER of a following HP_OP_WGRAD_GROUP or HP_OP_PAIR op, or of a small-leaf group (below): the
  * program executor skips it (the group launch does its work); hp_run_op and the reference interpreter execute it like any op. */
@@ -126,6 +126,11 @@ typedef struct HpOp {
                                 * accumulation: the error of a dot product is at the level of the fp32 matrix path's own rounding (measured
                                 * against fp64: tests/test_gpu_split.py), at 16/6 of its instruction rate.  Same tensors, same epilogues,
                                 * same tolerances as the fp32 path — this IS the fp32 parity path when TrainCfg.mfma_dtype = "bf16x3". */
+#define HP_CONV_WFRAG    4096   /* CONV_TAPS with HP_CONV_BF16X3: the B operand's three-term fragments are read ready-made from the image an
+                                * HP_OP_WFRAG record wrote earlier in the pass — buf[24] for the weights W (buf[1]), buf[25] for W2 (buf[11]) — instead of
+                                * being loaded as fp32, split and staged through LDS by every tile: no weight tile in LDS at all.  The image must
+                                * have been made for this op's orientation (HP_CONV_W_KN or not) of the same weights; W / W2 stay in the record
+                                * (the 128-row bodies and the reference interpreter read them).  Bit-identical results. */
 enum {
   /* out[m][n] = sum_taps sum_k A_src[row(m,tap)][k] * W_src[tap_w][..] (+bias[n]);  f32 MFMA.
    * Replaces nn.Conv1d forward (backbones.py:24,26,33,50,55), ResizeConv1d =
@@ -330,6 +335,16 @@ enum {
    * registers from layer to layer; BatchNorm statistics are fp64 column sums in a fixed order (csrc/heads_fused.h).  Every tensor the
    * members write is written.  i[0]=first i[1]=count i[2]=0 */
   HP_OP_HEADS = 37,
+  /* Three-term MFMA fragments of a conv weight tensor W[T][N][K] (fp32, PARAM): every value split exactly into three bfloat16 terms
+   * (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)) and laid out in the order v_mfma_f32_32x32x16_bf16 consumes a B operand, once per
+   * pass instead of once per tile.  Image layout (bf16): [T][KK/16][ceil(NN/32)][3 terms][64 lanes][8]; lane (j = lane & 31, h = lane >> 5)
+   * of chunk (t, ks, jn) holds B(k = 16 ks + 8 h + e, n = 32 jn + j), e = 0..7 (zero beyond NN).
+   *   F (i[3] & 1, buf[1]): the forward orientation, B(k, n) = W[t][n][k]   (NN = N, KK = K; K % 32 == 0);
+   *   G (i[3] & 2, buf[2]): the HP_CONV_W_KN orientation, B(k, n) = W[t][k][n] (NN = K, KK = N; N % 32 == 0).
+   * One workgroup reads a 32 x 32 block of a slab once and writes its two F and two G chunks.  Groupable (HP_FLAG_GROUP_SHIFT; a
+   * group holds only WFRAG records): all conv weights of a model in one launch at the head of a forward pass.
+   * i[0]=T i[1]=N i[2]=K i[3]=which   buf[0]=W buf[1]=F buf[2]=G */
+  HP_OP_WFRAG = 38,
   HP_OP__COUNT
 };
 

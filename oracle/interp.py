@@ -51,6 +51,22 @@ def _bf16(x):
     return r.view(np.float32)
 
 
+def wfrag_image(Bm):
+    """Bm[t][k][n] = B(k, n) of slab t (float32) -> the uint16 image [T][KK/16][ceil(NN/32)][3 terms][64 lanes][8] of its exact three-term
+    bfloat16 split (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)); lane = 32 * (k // 8 % 2) + n % 32, element = k % 8"""
+    T, KK, NN = Bm.shape
+    JN = -(-NN // 32)
+    x = np.zeros((T, KK, JN * 32), np.float32)
+    x[:, :, :NN] = Bm
+    h = _bf16(x)
+    r = (x - h).astype(np.float32)
+    m = _bf16(r)
+    l = _bf16((r - m).astype(np.float32))
+    planes = np.stack([(v.view(np.uint32) >> np.uint32(16)).astype(np.uint16) for v in (h, m, l)])      # [3][T][KK][JN*32]
+    planes = planes.reshape(3, T, KK // 16, 2, 8, JN, 32)                                               # [plane][t][ks][hh][e][jn][j]
+    return planes.transpose(1, 2, 5, 0, 3, 6, 4).reshape(-1)                                            # [t][ks][jn][plane][hh][j][e]
+
+
 def stat_repl(C):
     """hp_stat_repl (include/hippie_hip.h): per-channel fp64 slots are double[R][2][C]; this interpreter adds into replica 0."""
     r = 2
@@ -539,5 +555,12 @@ def run(ops, A: Arenas, first=0, count=None):
             A.f32(b[8], B * z)[:] = philox_normal(int(A.i64(b[9], 1)[0]), cur, B * z, rank)
         elif op in (29, 30, 37):   # WGRAD_GROUP / PAIR / HEADS: their member records (before them) were executed in place
             pass
+        elif op == 38:         # WFRAG: three-term MFMA fragments of a conv weight tensor (include/hippie_hip.h, HP_OP_WFRAG)
+            T, N, K, which = [int(v) for v in i[:4]]
+            W = A.f32(b[0], T * N * K).reshape(T, N, K)
+            if which & 1:
+                A.view(b[1], np.uint16, T * (K // 16) * (-(-N // 32)) * 1536)[:] = wfrag_image(W.transpose(0, 2, 1))
+            if which & 2:
+                A.view(b[2], np.uint16, T * (N // 16) * (K // 32) * 1536)[:] = wfrag_image(W)
         else:
             raise ValueError(f"unknown opcode {op}")

@@ -159,3 +159,102 @@ def test_shared_image_weight_gradient_of_three_tap_stride_one_layers(split_recor
     gpu, cpu = T.run_program_both(img, ol.array())
     for g, numel in grads:
         T.check(gpu, cpu, g, numel, rel=3e-5, what=f"shared-image wgrad L={L} N={N} K={K}")
+
+
+def _frag_bytes(nslab, N, K):
+    """bytes of the HP_OP_WFRAG image a CONV_TAPS record with (N, K) multiplies with: [slab][K/16][ceil(N/32)] chunks of 3072 bytes"""
+    return nslab * (K // 16) * (-(-N // 32)) * 3072
+
+
+def _wfrag_rec(ol, w, image, nslab, N, K, w_kn):
+    """the record that writes `image` for a conv of shape (N, K): the F form of W[nslab][N][K], or (HP_CONV_W_KN) the G form of the tensor
+    whose slabs are that conv's [K][N] matrices"""
+    if not w_kn:
+        ol.add(P.WFRAG, 0, [nslab, N, K, 1], (), [w, image, None])
+    else:
+        ol.add(P.WFRAG, 0, [nslab, K, N, 2], (), [w, None, image])
+
+
+@pytest.mark.parametrize("T_,N,K,which", [(3, 64, 64, 3), (1, 128, 64, 3), (3, 36, 96, 1), (2, 100, 32, 1), (3, 512, 256, 3)])
+def test_weight_fragment_image_equals_the_interpreter(T_, N, K, which):
+    """HP_OP_WFRAG against oracle/interp.py::wfrag_image, bit for bit: the exact three-term split of every weight in the order the MFMA
+    consumes a B operand, both orientations, ragged N (zeros past it) for the forward one."""
+    img = Img(31)
+    w = img.f32(T_ * N * K, scale=0.1)
+    f = img.f32(_frag_bytes(T_, N, K) // 4, zero=True) if which & 1 else None
+    g = img.f32(_frag_bytes(T_, K, N) // 4, zero=True) if which & 2 else None
+    ol = P.OpList()
+    ol.add(P.WFRAG, 0, [T_, N, K, which], (), [w, f, g])
+    gpu, cpu = run_both(img, ol.array())
+    for ref, nb in ((f, _frag_bytes(T_, N, K)), (g, _frag_bytes(T_, K, N))):
+        if ref is not None:
+            a, b = view(gpu, ref, np.uint16, nb // 2), view(cpu, ref, np.uint16, nb // 2)
+            assert b.any()
+            np.testing.assert_array_equal(a, b)
+
+
+FRAG_CASES = [n for n in T.CONV_CASES]
+
+
+@pytest.mark.parametrize("name", FRAG_CASES)
+@pytest.mark.parametrize("in_bn", [False, True])
+def test_conv_with_ready_made_weight_fragments_is_bit_identical(name, in_bn):
+    """HP_CONV_WFRAG: the same three-term conv with its B fragments read from the HP_OP_WFRAG image instead of split and staged per tile —
+    the same products in the same order, so the outputs (and the BatchNorm statistics) must be bit-identical.  Every tap-map family incl.
+    the two-source stride-2 input-gradients (W2's image), K up to 512, with and without the BatchNorm input transform."""
+    tm, w_kn, bias = T.CONV_CASES[name]()
+    if in_bn and any(len(t) > 2 and t[2] for t in tm.taps):
+        pytest.skip("the input BatchNorm is not combined with two-source taps")
+    img = Img(77)
+    nb = tm.M // tm.Lout
+    a = img.f32(nb * tm.Lin * tm.K)
+    nslab = max(t[1] for t in tm.taps) + 1
+    w = img.f32(nslab * tm.N * tm.K, scale=0.1)
+    two = any(len(t) > 2 and t[2] for t in tm.taps)
+    a2 = img.f32(nb * tm.Lin * tm.K) if two else None
+    w2 = img.f32(nslab * tm.N * tm.K, scale=0.1) if two else None
+    bv = img.f32(tm.N) if bias else None
+    fimg = img.f32(_frag_bytes(nslab, tm.N, tm.K) // 4, zero=True)
+    fimg2 = img.f32(_frag_bytes(nslab, tm.N, tm.K) // 4, zero=True) if two else None
+    fl = (P.CONV_W_KN if w_kn else 0) | (P.CONV_BIAS if bias else 0) | P.CONV_STATS | P.CONV_BF16X3
+    ol = P.OpList()
+    _wfrag_rec(ol, w, fimg, nslab, tm.N, tm.K, w_kn)
+    if two:
+        _wfrag_rec(ol, w2, fimg2, nslab, tm.N, tm.K, w_kn)
+    outs = []
+    bn_bufs = bn_io = None
+    if in_bn:      # one input BatchNorm for both convs: parameters, running buffers, the statistics its producer would have accumulated
+        bn_bufs = [img.f32(tm.K, scale=0.5), img.f32(tm.K, scale=0.2), img.f32(tm.K, zero=True), img.f32(tm.K, zero=True)]
+        stats_in = img.f64(T.R(tm.K) * 2 * tm.K)
+        bn_io = [stats_in, img.f32(2 * tm.K, zero=True), img.f32(2 * tm.K, zero=True)]
+        raw = T._chunk_array(img, a).reshape(-1, tm.K).astype(np.float64)
+        sv = np.zeros(T.R(tm.K) * 2 * tm.K)
+        sv[:tm.K], sv[tm.K: 2 * tm.K] = raw.sum(0), (raw * raw).sum(0)
+        T._chunk_array(img, stats_in)[:] = sv
+    for frag in (False, True):
+        out = img.f32(tm.out_rows * tm.N, zero=True)       # (the rows a strided-output op does not own stay as they are: the same in both)
+        st = img.f64(T.R(tm.N) * 2 * tm.N)
+        bufs = [a, w, out, bv, st] + [None] * 21
+        bufs[10], bufs[11] = a2, w2
+        ii = tm.conv_ints() + [0, 0]
+        ii += [0] * (40 - len(ii))
+        ff = [0.0] * 6
+        f2 = fl
+        if in_bn:
+            f2 |= P.CONV_IN_BN
+            bufs[5:9] = bn_bufs
+            bufs[12:15] = bn_io
+            ii[31], ii[32] = nb * tm.Lin, 0
+            ff[2], ff[3], ff[4] = 0.01, 1e-5, 0.1
+        if frag:
+            f2 |= P.CONV_WFRAG
+            bufs[24], bufs[25] = fimg, fimg2
+        ol.add(P.CONV_TAPS, f2, ii, ff, bufs)
+        outs.append((out, st))
+    gpu, cpu = run_both(img, ol.array())
+    (o0, s0), (o1, s1) = outs
+    T.check(gpu, cpu, o1, tm.out_rows * tm.N, what=name + " out vs interpreter")
+    np.testing.assert_array_equal(view(gpu, o0, np.float32, tm.out_rows * tm.N), view(gpu, o1, np.float32, tm.out_rows * tm.N))
+    n_st = T.R(tm.N) * 2 * tm.N
+    np.testing.assert_allclose(view(gpu, s0, np.float64, n_st).reshape(T.R(tm.N), -1).sum(0), view(gpu, s1, np.float64, n_st).reshape(T.R(tm.N), -1).sum(0),
+                               rtol=1e-12, atol=1e-9)      # (fp64 atomics of identical addends: only the order may differ)

@@ -195,7 +195,8 @@ def test_plain_c_host_steps_two_models_on_picked_streams(tmp_path):
     for j in range(2):
         got = np.array([[float(v) for v in ln.split()[4:]] for ln in lines if ln.startswith(f"model {j} step ")])
         assert got.shape == (steps, 4), out
-        np.testing.assert_allclose(got, wants[j], rtol=1e-5)        # same kernels; only the order of atomic sums differs
+        np.testing.assert_allclose(got, wants[j], rtol=1e-4)        # same kernels; only the order of the weight gradients' fp32 atomic sums differs from run to run,
+            # and three AdamW steps amplify it: 1e-7 after the first step, up to 2.5e-5 after the third (measured)
         assert f"model {j} batches_tracked {steps}" in out
 
 

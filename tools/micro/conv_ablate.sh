@@ -8,6 +8,6 @@ make -s
 mkdir -p ../../tools/micro/variants
 for v in ${VARIANTS:-1 2 3 4 8}; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DHP_ABL=$v -c conv_mfma.hip -o /tmp/conv_abl$v.o
-  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 program.o /tmp/conv_abl$v.o ops_small.o -o ../../tools/micro/variants/libhippie_abl$v.so
+  /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 program.o model.o /tmp/conv_abl$v.o ops_small.o -o ../../tools/micro/variants/libhippie_abl$v.so
   echo "built variant $v"
 done
