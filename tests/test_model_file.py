@@ -143,7 +143,7 @@ def test_plain_c_host_steps_the_model(tmp_path, kind, use_graph, dp):
     for _ in range(steps):
         eng.train_step(use_graph=False)
         want.append(eng.scalars())
-    np.testing.assert_allclose(got, np.array(want), rtol=1e-5)        # same kernels; only the order of atomic sums differs
+    np.testing.assert_allclose(got, np.array(want), rtol=1e-4)        # same kernels; only the order of atomic sums differs (amplified step by step: see the pair test below)
     enc = eng.io("enc_train").double()
     tail = dict(ln.split(" sum ") for ln in lines if " sum " in ln)
     s, s2 = (float(v) for v in tail["enc_train"].replace("sumsq ", "").split())
@@ -284,7 +284,7 @@ def test_c_level_staged_steps_match_the_python_engine(tmp_path, use_graph):
     cur = (ctypes.c_int64 * 1)()
     assert lib.hp_model_read(m, b"cursor", cur, 8, 0, None) == 0 and cur[0] == steps
     assert lib.hp_model_batches_tracked(m) == steps
-    np.testing.assert_allclose(np.array(got), np.array(want), rtol=1e-5)
+    np.testing.assert_allclose(np.array(got), np.array(want), rtol=1e-4)      # (the order of fp32 atomic sums differs from run to run; AdamW steps amplify it)
     # the batch the last step trained on is the permutation's: row b of "x" is table row perm[(steps-1)*B + b]
     xb = np.zeros((B, L), dtype=np.float32)
     assert lib.hp_model_read(m, b"x", xb.ctypes.data_as(ctypes.c_void_p), xb.nbytes, 0, None) == 0
