@@ -650,6 +650,12 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4,
   conv_body<W_KN, MODE, MM, ABF>(p, blockIdx.x, smem);
 }
 
+// (Built, measured and removed, round 4: a REGISTER-DIRECT form of the fragment body — nothing of the K loop through LDS: every wave loads its own
+// A fragment (per lane 8 consecutive k of one row = 32 contiguous bytes, two 16-byte loads a step ahead), applies the input BatchNorm, splits in
+// registers and multiplies with the ready-made weight fragments; no staging stores, no fragment reads, no barrier until the epilogue.  Bit-identical
+// (the op tests ran on it) and slower: conv launch 22.7 us against 18.6 us back to back, 120.5 k against 140.7 k samples/s.  A wave's load touches
+// 32 rows x 64 bytes — 32 cache lines per instruction instead of 8 for the staged form's 128-byte row pieces — and both column-half waves issue it:
+// the L1 / address path is the bound, not LDS.)
 // HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, a block's conv1
 // and its shortcut, or the even / odd output phases of a stride-2 input-gradient) in ONE launch: twice the
 // workgroups per launch at batch 512, where a single layer only fills each CU with one workgroup.
