@@ -682,8 +682,8 @@ constexpr int big_buf_h(int nt) {                     // bf16 elements of one st
 }
 constexpr int kBigEpiTile = 32 * 36;                  // one 32 x 32 fp32 tile of the transposed epilogue, 144-byte rows
 constexpr int kBigEpiFloats = 4 * 3 * kBigEpiTile;    // per wave: values, xhat, xhat of a second BatchNorm
-constexpr int big_stage_floats(int nt, int mm) {      // staging area: two buffers of big_buf_h bf16 (= big_buf_h floats); MM = 2: ONE buffer of three images each (3/2 of that)
-  return mm == 2 ? 3 * big_buf_h(nt) / 2 : big_buf_h(nt);
+constexpr int big_stage_floats(int nt, int mm) {      // staging area: two buffers of big_buf_h bf16 (= big_buf_h floats); MM = 2: ONE buffer of three images each (3/2 of that);
+  return mm == 3 ? 3 * 128 * kLdaH / 2 : mm == 2 ? 3 * big_buf_h(nt) / 2 : big_buf_h(nt);      // MM = 3: of the A operand alone
 }
 constexpr int big_lds_floats(int nt, int mode, int mm = 1) {      // staging + IN_BN coefficients; >= the epilogue's tiles
   return (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) > kBigEpiFloats ? (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) : kBigEpiFloats;
@@ -696,7 +696,8 @@ constexpr int big_lds_floats(int nt, int mode, int mm = 1) {      // staging + I
 template <bool W_KN, int MODE, int NT, bool ABF, int MM = 1>
 __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr bool IN_BN = MODE == 1;
-  constexpr bool SPLIT = MM == 2;                       // HP_CONV_BF16X3: three bf16 images per operand and buffer, six products per fragment pair
+  constexpr bool SPLIT = MM == 2 || MM == 3;            // HP_CONV_BF16X3: three bf16 images per operand and buffer, six products per fragment pair
+  constexpr bool FRAG = MM == 3;                        // ... | HP_CONV_WFRAG: the B fragments come ready-made from global memory, a 16-deep slab ahead; LDS holds the A images alone
   constexpr int IMG = SPLIT ? 3 : 1;
   static_assert(!(SPLIT && ABF), "the three-term mode reads fp32-stored tensors");
   constexpr int MT = 2, TM = 128, TN = 64 * NT, WN = 32 * NT;
@@ -774,8 +775,10 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     Pref r;
 #pragma unroll
     for (int j = 0; j < NA; ++j) r.a[j] = *(const hp_v4u __attribute__((address_space(1)))*)(pa[j]);
+    if (!FRAG) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) r.b[j] = gload4(pb[j]);
+      for (int j = 0; j < NB; ++j) r.b[j] = gload4(pb[j]);
+    }
     r.kq = kc * 32 + aqa;
 #pragma unroll
     for (int j = 0; j < NA; ++j) pa[j] += ia[j];
@@ -846,7 +849,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     }
     }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
+    for (int j = 0; j < (FRAG ? 0 : NB); ++j) {
       __bf16* d = W_KN ? Bh + (kr + 16 * (j & 1)) * LDT + nq + 64 * (j >> 1) : Bh + (ar + 32 * j) * kLdaH + aq;
       if (SPLIT) {
         bf16x4 h, m, l;
@@ -863,6 +866,34 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     for (int j = 0; j < NA; ++j) m |= (ia[j] ? 1u : 0u) << j;
     return m;
   };
+
+  // FRAG: this wave's B fragments of a 16-deep slab — NT column tiles x 3 terms x 16 bytes per lane — straight from the HP_OP_WFRAG image, one
+  // slab ahead: bq[0] holds the first slab of a K step, bq[1] the second; each is refilled for the next use while the other one is multiplied
+  bf16x8 bq[FRAG ? 2 : 1][NT][3];
+  const char* pfq = nullptr;
+  int fq_half = 0, fq_tap = 0;
+  const int fq_jn = (t.N + 31) >> 5;
+  int fq_off[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) fq_off[j] = min((n0 >> 5) + wn * NT + j, fq_jn - 1) * 3072;      // (a column tile past N: never stored)
+  auto set_fq = [&](int tap) {
+    pfq = (t.tap_src[tap] != 0 ? p.Wf2 : p.Wf) + (size_t)t.tap_w[tap] * (t.K >> 4) * fq_jn * 3072 + lane * 16;
+  };
+  auto fetch_bq = [&](const int set) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const hp_v4u u = *(const hp_v4u __attribute__((address_space(1)))*)(pfq + fq_off[j] + c * 1024);
+        union { hp_v4u u; bf16x8 v; } w; w.u = u; bq[FRAG ? set : 0][j][c] = w.v;
+      }
+    pfq += (size_t)fq_jn * 3072;
+    if (++fq_half == 2 * kper) {
+      fq_half = 0;
+      if (++fq_tap < t.ntaps) set_fq(fq_tap);
+    }
+  };
+  if (FRAG) { set_fq(0); fetch_bq(0); }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -895,6 +926,32 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     if (more) { ok_nxt = okbits(); nxt = fetch(); }      // in flight under this step's MFMAs
     const __bf16* Ah = lds + (SPLIT ? 0 : buf) * BUF_H;
     const __bf16* Bh = Ah + IMG * A_H;
+    if (FRAG) {
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[MT][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i][c] = *reinterpret_cast<const bf16x8*>(Ah + c * A_H + (wm * 64 + i * 32 + li) * kLdaH + kk * 16 + lh * 8);
+        if (kk == 0) fetch_bq(1);                     // this step's second slab, in flight under the first one's MFMAs
+        else if (more) fetch_bq(0);                   // the next step's first slab
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          constexpr int ca[6] = {0, 2, 1, 0, 1, 0}, cb[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca[q]], bq[FRAG ? kk : 0][j][cb[q]], acc[i][j], 0, 0, 0);
+        }
+      }
+      __syncthreads();
+      if (more) {
+        stash(0, nxt, ok_nxt);
+        __syncthreads();
+      }
+      continue;
+    }
     if (SPLIT) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
@@ -1170,6 +1227,18 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
   if ((int)blockIdx.x < nblk_a) conv_big_body<W_KN, 1, NT, false, 2>(a, blockIdx.x, smem);
   else conv_big_body<W_KN, 1, NT, false, 2>(b, blockIdx.x - nblk_a, smem);
 }
+// ... and with the weight fragments (HP_CONV_WFRAG): LDS holds the A images alone
+template <int NT>
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big3f_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, 1, 3)];
+  conv_big_body<false, 1, NT, false, 3>(p, blockIdx.x, smem);
+}
+template <int NT>
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big3f_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, 1, 3)];
+  if ((int)blockIdx.x < nblk_a) conv_big_body<false, 1, NT, false, 3>(a, blockIdx.x, smem);
+  else conv_big_body<false, 1, NT, false, 3>(b, blockIdx.x - nblk_a, smem);
+}
 #define HP_BIG3_DISPATCH(KERNEL, KN, NT, ...)                                                                     \
   do {                                                                                                            \
     if (NT == 2) { if (KN) hipLaunchKernelGGL((KERNEL<true, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 2>), __VA_ARGS__); } \
@@ -1240,6 +1309,15 @@ static int conv_big_min_tiles() {
   }();
   return v;
 }
+// (A/B knob: HIPPIE_CONV_BIGFRAG=0 keeps the 128-row three-term bodies on the LDS-staged weight tile)
+static bool conv_bigfrag_on() {
+  static const bool v = [] {
+    const char* on = getenv("HIPPIE_DEBUG_KNOBS");
+    const char* e = (on && on[0] == '1') ? getenv("HIPPIE_CONV_BIGFRAG") : nullptr;
+    return e ? atoi(e) != 0 : true;
+  }();
+  return v;
+}
 static int conv_big_nt(const TapMap& t) {
   const int rows = hp::cdiv(t.M, 128);
   if (t.N >= 128 && rows * hp::cdiv(t.N, 128) >= conv_big_min_tiles()) return 2;
@@ -1271,7 +1349,10 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
       const int na = hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, tn), nb = hp::cdiv(b.t.M, 128) * hp::cdiv(b.t.N, tn);
       const bool kn = opa.flags & 1;
       const int mode = ma > mb ? ma : mb;
-      if (opa.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_pair_kernel, kn, big, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+      if ((opa.flags & HP_CONV_BF16X3) && (opa.flags & HP_CONV_WFRAG) && conv_bigfrag_on()) {
+        if (big == 2) hipLaunchKernelGGL((conv_big3f_pair_kernel<2>), dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+        else          hipLaunchKernelGGL((conv_big3f_pair_kernel<1>), dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+      } else if (opa.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_pair_kernel, kn, big, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
       else HP_BIG_DISPATCH(conv_big_pair_kernel, kn, mode, big, abf, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
       return hipGetLastError();
     }
@@ -1295,7 +1376,10 @@ hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t 
       const bool kn = op.flags & 1;
       const int mode = conv_mode(op.flags);
       const dim3 g(hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, 64 * big));
-      if (op.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_kernel, kn, big, g, dim3(kBigThreads), 0, s, a);
+      if ((op.flags & HP_CONV_BF16X3) && (op.flags & HP_CONV_WFRAG) && conv_bigfrag_on()) {
+        if (big == 2) hipLaunchKernelGGL((conv_big3f_kernel<2>), g, dim3(kBigThreads), 0, s, a);
+        else          hipLaunchKernelGGL((conv_big3f_kernel<1>), g, dim3(kBigThreads), 0, s, a);
+      } else if (op.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_kernel, kn, big, g, dim3(kBigThreads), 0, s, a);
       else HP_BIG_DISPATCH(conv_big_kernel, kn, mode, big, abf, g, dim3(kBigThreads), 0, s, a);
       return hipGetLastError();
     }
