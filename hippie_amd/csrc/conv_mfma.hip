@@ -683,7 +683,7 @@ constexpr int big_buf_h(int nt) {                     // bf16 elements of one st
 constexpr int kBigEpiTile = 32 * 36;                  // one 32 x 32 fp32 tile of the transposed epilogue, 144-byte rows
 constexpr int kBigEpiFloats = 4 * 3 * kBigEpiTile;    // per wave: values, xhat, xhat of a second BatchNorm
 constexpr int big_stage_floats(int nt, int mm) {      // staging area: two buffers of big_buf_h bf16 (= big_buf_h floats); MM = 2: ONE buffer of three images each (3/2 of that);
-  return mm == 3 ? 3 * 128 * kLdaH / 2 : mm == 2 ? 3 * big_buf_h(nt) / 2 : big_buf_h(nt);      // MM = 3: of the A operand alone
+  return mm == 3 ? 2 * 3 * 128 * kLdaH / 2 : mm == 2 ? 3 * big_buf_h(nt) / 2 : big_buf_h(nt);      // MM = 3: TWO buffers of the A operand's three images alone
 }
 constexpr int big_lds_floats(int nt, int mode, int mm = 1) {      // staging + IN_BN coefficients; >= the epilogue's tiles
   return (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) > kBigEpiFloats ? (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) : kBigEpiFloats;
@@ -704,7 +704,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
   constexpr int LDT = TN + 32;                          // [k][n] image row stride (bf16): rows 64 bytes apart mod 256 -> conflict-free tr reads
   constexpr int A_H = TM * kLdaH;                       // bf16 elements of one A image
   constexpr int B_H = W_KN ? 32 * LDT : TN * kLdaH;
-  constexpr int BUF_H = IMG * big_buf_h(NT);            // one buffer (A + the larger B form; IMG images of each)
+  constexpr int BUF_H = FRAG ? 3 * A_H : IMG * big_buf_h(NT);      // one buffer (A + the larger B form; IMG images of each; FRAG: the A images alone)
   constexpr int B_HS = big_buf_h(NT) - A_H;             // distance between the B images of a buffer
   // A pieces per thread: fp32-stored 128 rows x 8 four-float pieces / 256 threads = 4 (16 bytes each); bf16-stored (ABF) 128 rows x 4
   // eight-element pieces = 2 — 16 bytes per lane either way (8-byte bf16 pieces issue twice the loads per byte)
@@ -924,7 +924,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     unsigned ok_nxt = 0;
     Pref nxt;
     if (more) { ok_nxt = okbits(); nxt = fetch(); }      // in flight under this step's MFMAs
-    const __bf16* Ah = lds + (SPLIT ? 0 : buf) * BUF_H;
+    const __bf16* Ah = lds + ((SPLIT && !FRAG) ? 0 : buf) * BUF_H;
     const __bf16* Bh = Ah + IMG * A_H;
     if (FRAG) {
 #pragma unroll
@@ -945,11 +945,9 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca[q]], bq[FRAG ? kk : 0][j][cb[q]], acc[i][j], 0, 0, 0);
         }
       }
+      // (the A images alone are small enough for TWO staging buffers at two workgroups per CU: the next slice goes to the other buffer, one barrier per step)
+      if (more) stash(buf ^ 1, nxt, ok_nxt);
       __syncthreads();
-      if (more) {
-        stash(0, nxt, ok_nxt);
-        __syncthreads();
-      }
       continue;
     }
     if (SPLIT) {
