@@ -35,7 +35,8 @@ __device__ __forceinline__ float4 widen4(const bf16x4 h) { return make_float4((f
 #ifndef HP_ABL
 #define HP_ABL 0      // tools/micro/conv_ablate.sh: 1 = return before the epilogue, 2 = every operand load reads the zero page, 4 = no output store,
 #endif                // 8 = 100 MHz timestamps of the first / last workgroup's phases into the (otherwise unused) E_BS buffer; three-term path (timing only,
-                      // wrong numbers): 16 = only the leading product, 32 = no split arithmetic (m = l = h), 64 = conv_body stores / reads the h image only
+                      // wrong numbers): 16 = only the leading product, 32 = no split arithmetic (m = l = h), 64 = conv_body stores / reads the h image only,
+                      // 256 / 512 = the 128-row fragment body skips its A staging / its B fragment loads
 __device__ __forceinline__ void split3(const float4 v, bf16x4& h, bf16x4& m, bf16x4& l) {
   h = to_bf16x4(v);
   if (HP_ABL & 32) { m = h; l = h; return; }
@@ -934,19 +935,23 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
         for (int c = 0; c < 3; ++c)
 #pragma unroll
           for (int i = 0; i < MT; ++i) af[i][c] = *reinterpret_cast<const bf16x8*>(Ah + c * A_H + (wm * 64 + i * 32 + li) * kLdaH + kk * 16 + lh * 8);
-        if (kk == 0) fetch_bq(1);                     // this step's second slab, in flight under the first one's MFMAs
-        else if (more) fetch_bq(0);                   // the next step's first slab
+        if (!(HP_ABL & 512)) {
+          if (kk == 0) fetch_bq(1);                   // this step's second slab, in flight under the first one's MFMAs
+          else if (more) fetch_bq(0);                 // the next step's first slab
+        }
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
           constexpr int ca[6] = {0, 2, 1, 0, 1, 0}, cb[6] = {2, 0, 1, 1, 0, 0};
+          if ((HP_ABL & 16) && q < 5) continue;
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca[q]], bq[FRAG ? kk : 0][j][cb[q]], acc[i][j], 0, 0, 0);
         }
       }
-      // (the A images alone are small enough for TWO staging buffers at two workgroups per CU: the next slice goes to the other buffer, one barrier per step)
-      if (more) stash(buf ^ 1, nxt, ok_nxt);
+      // (the A images alone are small enough for TWO staging buffers at two workgroups per CU: the next slice goes to the other buffer, one barrier per
+      // step.  Staging half of it after each slab's MFMAs — two short phases instead of one — measured no better: 131.4 k against 132.1 k at config 5.)
+      if (more && !(HP_ABL & 256)) stash(buf ^ 1, nxt, ok_nxt);
       __syncthreads();
       continue;
     }
