@@ -894,7 +894,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
       if (++fq_tap < t.ntaps) set_fq(fq_tap);
     }
   };
-  if (FRAG) { set_fq(0); fetch_bq(0); }
+  if (FRAG) { set_fq(0); fetch_bq(0); fetch_bq(1); }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -935,10 +935,6 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
         for (int c = 0; c < 3; ++c)
 #pragma unroll
           for (int i = 0; i < MT; ++i) af[i][c] = *reinterpret_cast<const bf16x8*>(Ah + c * A_H + (wm * 64 + i * 32 + li) * kLdaH + kk * 16 + lh * 8);
-        if (!(HP_ABL & 512)) {
-          if (kk == 0) fetch_bq(1);                   // this step's second slab, in flight under the first one's MFMAs
-          else if (more) fetch_bq(0);                 // the next step's first slab
-        }
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
           constexpr int ca[6] = {0, 2, 1, 0, 1, 0}, cb[6] = {2, 0, 1, 1, 0, 0};
@@ -948,6 +944,9 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
 #pragma unroll
             for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca[q]], bq[FRAG ? kk : 0][j][cb[q]], acc[i][j], 0, 0, 0);
         }
+        // this slab's fragment registers are free once its MFMAs are issued: refill them for the SAME slab of the next K step — a whole step of
+        // lead (the other slab's MFMAs, the staging phase, the barrier) instead of one slab's
+        if (more && !(HP_ABL & 512)) fetch_bq(kk);
       }
       // (the A images alone are small enough for TWO staging buffers at two workgroups per CU: the next slice goes to the other buffer, one barrier per
       // step.  Staging half of it after each slab's MFMAs — two short phases instead of one — measured no better: 131.4 k against 132.1 k at config 5.)
