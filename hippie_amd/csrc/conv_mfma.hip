@@ -657,6 +657,10 @@ __global__ __launch_bounds__(kConvThreads) __attribute__((amdgpu_waves_per_eu(4,
 // (the op tests ran on it) and slower: conv launch 22.7 us against 18.6 us back to back, 120.5 k against 140.7 k samples/s.  A wave's load touches
 // 32 rows x 64 bytes — 32 cache lines per instruction instead of 8 for the staged form's 128-byte row pieces — and both column-half waves issue it:
 // the L1 / address path is the bound, not LDS.)
+// (Built, measured and removed, round 4: a 256-register instantiation of the fragment body (amdgpu_waves_per_eu(2, 2): 158 registers, no spills) for
+// launches of at most 256 tiles, which never have two workgroups on a CU.  Per launch it IS faster — 18.07 against 18.43 us back to back — and the
+// pair-step is slower, 137.4 k against 142.0 k samples/s, twice in a row: two waves per SIMD at 158 registers leave no room for a workgroup of the
+// OTHER model's stream (2 x 128) on the same CU, and that overlap is worth more than the spills cost.)
 // HP_OP_PAIR: two independent convolutions (e.g. the same layer of the wave and the time model, a block's conv1
 // and its shortcut, or the even / odd output phases of a stride-2 input-gradient) in ONE launch: twice the
 // workgroups per launch at batch 512, where a single layer only fills each CU with one workgroup.
