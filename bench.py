@@ -13,9 +13,11 @@ region; each step gathers its batch by index from them.  One process per GPU; wi
 holds a replica, takes its own 512-unit batch (Lightning-DDP semantics, weak scaling) and the
 gradients are mean-all-reduced over RCCL between backward and AdamW.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the f32-MFMA implicit-GEMM
-convolution `conv_taps_kernel`), timed with HIP events per launch in an untimed pass right after the
-timed region; `cpu_baseline` times the torch-CPU oracle on a bounded sample on this host's cores.
+Prints ONE JSON line (rank 0).  `dtype` "f32": the arithmetic is the reference's fp32; `matrix_path` says which matrix cores carry it —
+"bf16x3" (default: every fp32 operand split exactly into three bf16 terms, six bf16 MFMA products per fp32 product, fp32 accumulation;
+error against fp64 at or below the fp32 matrix cores', tests/test_gpu_split.py) or "f32" (`--matrix-path f32`: v_mfma_f32_32x32x2_f32).
+`roofline` is for the dominant kernel (the implicit-GEMM convolution `conv_taps_kernel`), timed with HIP events per launch in an untimed pass
+right after the timed region — algorithmic fp32 flops against the path's peak (bf16 dense / 6 = 417 TFLOP/s; `frac_of_f32_mfma_peak`: against 157.3); `cpu_baseline` times the torch-CPU oracle on a bounded sample on this host's cores.
 Secondary figures on the same line (N = 1): `trainer_samples_per_s` (the reference-API path: Trainer.fit of both modules,
 concurrently), `inference_path` (get_embeddings over the pool), `dp_overhead_1rank` (the step with a 1-rank RCCL all-reduce in it);
 `config.stream_pair` / `config.run_ahead` say how the two model streams were scheduled.
