@@ -688,8 +688,8 @@ constexpr int big_buf_h(int nt) {                     // bf16 elements of one st
 constexpr int kBigEpiTile = 32 * 36;                  // one 32 x 32 fp32 tile of the transposed epilogue, 144-byte rows
 constexpr int kBigEpiFloats = 4 * 3 * kBigEpiTile;    // per wave: values, xhat, xhat of a second BatchNorm
 constexpr int big_stage_floats(int nt, int mm) {      // staging area: two buffers of big_buf_h bf16 (= big_buf_h floats); MM = 2: ONE buffer of three images each (3/2 of that);
-  return mm == 3 ? 2 * 3 * 128 * kLdaH / 2 : mm == 2 ? 3 * big_buf_h(nt) / 2 : big_buf_h(nt);      // MM = 3: TWO buffers of the A operand's three images alone
-}
+  return mm == 4 ? 2 * 3 * 130 * kLdaH / 2 : mm == 3 ? 2 * 3 * 128 * kLdaH / 2 : mm == 2 ? 3 * big_buf_h(nt) / 2 : big_buf_h(nt);      // MM = 3: TWO buffers of the A operand's
+}                                                                                                                                   // three images alone; MM = 4: with a halo row either side
 constexpr int big_lds_floats(int nt, int mode, int mm = 1) {      // staging + IN_BN coefficients; >= the epilogue's tiles
   return (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) > kBigEpiFloats ? (big_stage_floats(nt, mm) + (mode == 1 ? kConvCoef : 0)) : kBigEpiFloats;
 }
@@ -701,8 +701,9 @@ constexpr int big_lds_floats(int nt, int mode, int mm = 1) {      // staging + I
 template <bool W_KN, int MODE, int NT, bool ABF, int MM = 1>
 __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, float* smem) {
   constexpr bool IN_BN = MODE == 1;
-  constexpr bool SPLIT = MM == 2 || MM == 3;            // HP_CONV_BF16X3: three bf16 images per operand and buffer, six products per fragment pair
-  constexpr bool FRAG = MM == 3;                        // ... | HP_CONV_WFRAG: the B fragments come ready-made from global memory, a 16-deep slab ahead; LDS holds the A images alone
+  constexpr bool SPLIT = MM >= 2;                       // HP_CONV_BF16X3: three bf16 images per operand and buffer, six products per fragment pair
+  constexpr bool FRAG = MM == 3 || MM == 4;             // ... | HP_CONV_WFRAG: the B fragments come ready-made from global memory, a 16-deep slab ahead; LDS holds the A images alone
+  constexpr bool SH = MM == 4;                          // ... three taps reading rows m - 1, m, m + 1 of one tensor: ONE A image per 32-wide K chunk serves all three (below)
   constexpr int IMG = SPLIT ? 3 : 1;
   static_assert(!(SPLIT && ABF), "the three-term mode reads fp32-stored tensors");
   constexpr int MT = 2, TM = 128, TN = 64 * NT, WN = 32 * NT;
@@ -898,7 +899,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
       if (++fq_tap < t.ntaps) set_fq(fq_tap);
     }
   };
-  if (FRAG) { set_fq(0); fetch_bq(0); fetch_bq(1); }
+  if (FRAG && !SH) { set_fq(0); fetch_bq(0); fetch_bq(1); }
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -908,6 +909,128 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  if constexpr (SH) {
+    // ---- chunk-outer / tap-inner K loop over ONE staged A image per 32-wide chunk (the tile's 128 rows + a halo row either side, transformed and
+    // split once): a tap is a row offset of the fragment read, a sample boundary a per-lane flag; the weights come as fragments, so between two
+    // barriers a wave issues the MFMAs of three taps (144 at NT = 2) against one third of the staging work of the tap-outer loop.
+    constexpr int AS = 130 * kLdaH;                       // bf16 elements of one image
+    const float* pi[5];
+    int ii_[5], irow[5];
+    const int icol = (tid & 7) << 2;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int pc = j < 4 ? tid + 256 * j : 1024 + tid;  // piece index: 130 rows x 8 four-float pieces = 1040; the last 16 belong to threads 0 .. 15
+      irow[j] = pc >> 3;
+      const int m = m0 - 1 + irow[j];
+      const bool ok = (j < 4 || tid < 16) && m >= 0 && m < t.M;
+      pi[j] = ok ? p.A + (size_t)m * t.K + icol : hp_zero16;
+      ii_[j] = ok ? 32 : 0;
+    }
+    float4 img[5];
+    auto fetch_img = [&]() {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) { img[j] = gload4(pi[j]); pi[j] += ii_[j]; }
+    };
+    auto stash_img = [&](const int buf, const int kc_) {
+      float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (IN_BN && in_bn) {
+        sc = *reinterpret_cast<const float4*>(s_coef + kc_ * 32 + icol);
+        sh = *reinterpret_cast<const float4*>(s_coef + t.K + kc_ * 32 + icol);
+      }
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        if (j == 4 && tid >= 16) break;
+        float4 v = img[j];
+        if (IN_BN && in_bn) {      // (rows that are padding for a tap are zeroed at the fragment read, whatever stands here)
+          const float vx = fmaf(v.x, sc.x, sh.x), vy = fmaf(v.y, sc.y, sh.y), vz = fmaf(v.z, sc.z, sh.z), vw = fmaf(v.w, sc.w, sh.w);
+          v.x = fmaxf(vx, vx * in_slope); v.y = fmaxf(vy, vy * in_slope); v.z = fmaxf(vz, vz * in_slope); v.w = fmaxf(vw, vw * in_slope);
+        }
+        bf16x4 h, m, l;
+        split3(v, h, m, l);
+        __bf16* d = lds + buf * 3 * AS + irow[j] * kLdaH + icol;
+        *reinterpret_cast<bf16x4*>(d) = h; *reinterpret_cast<bf16x4*>(d + AS) = m; *reinterpret_cast<bf16x4*>(d + 2 * AS) = l;
+      }
+    };
+    // per lane and row tile: the fragment's image row, and whether tap tau's source row exists
+    int arow[MT];
+    bool rok[MT][3];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + li;
+      const int l = m % t.Lout;
+      arow[i] = (wm * 64 + i * 32 + li + 1) * kLdaH + lh * 8;
+#pragma unroll
+      for (int tau = 0; tau < 3; ++tau) rok[i][tau] = m < t.M && l + t.tap_o[tau] >= 0 && l + t.tap_o[tau] < t.Lout;
+    }
+    // weight fragments: one pointer per tap, advanced a chunk (two 16-deep slabs) once its second slab has been requested
+    const char* pfb[3];
+#pragma unroll
+    for (int tau = 0; tau < 3; ++tau) pfb[tau] = p.Wf + (size_t)t.tap_w[tau] * (t.K >> 4) * fq_jn * 3072 + lane * 16;
+    auto fetch_slab = [&](const int set, const int tau, const int kk) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const hp_v4u u = *(const hp_v4u __attribute__((address_space(1)))*)(pfb[tau] + (size_t)kk * fq_jn * 3072 + fq_off[j] + c * 1024);
+          union { hp_v4u u; bf16x8 v; } w; w.u = u; bq[set][j][c] = w.v;
+        }
+      if (kk == 1) pfb[tau] += (size_t)2 * fq_jn * 3072;
+    };
+    fetch_img();
+    if (IN_BN && in_bn) {
+      float* sc_w = smem + big_stage_floats(NT, MM);
+      for (int c = tid; c < t.K; c += kBigThreads) {
+        const BnCoef k = bn_coef(true, p.in_Mstat, p.in_stats, t.K, c, p.gamma, p.beta, p.rmean, p.rvar, p.in_eps);
+        sc_w[c] = k.scale;
+        sc_w[t.K + c] = k.shift;
+        if (bid == 0) bn_side_effects(k, p.in_Mstat, t.K, c, p.in_save, p.rmean, p.rvar, p.in_mom, p.in_coef);
+      }
+      __syncthreads();
+    }
+    stash_img(0, 0);
+    if (kper > 1) fetch_img();
+    fetch_slab(0, 0, 0);
+    fetch_slab(1, 0, 1);
+    __syncthreads();
+    for (int kc_ = 0; kc_ < kper; ++kc_) {
+      const bool more = kc_ + 1 < kper;
+      const __bf16* Ai = lds + (kc_ & 1) * 3 * AS;
+#pragma unroll
+      for (int tau = 0; tau < 3; ++tau) {
+        const int oshift = t.tap_o[tau] * kLdaH;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          bf16x8 af[MT][3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i][c] = *reinterpret_cast<const bf16x8*>(Ai + c * AS + arow[i] + oshift + kk * 16);
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+            if (!rok[i][tau]) {
+              const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+              af[i][0] = z; af[i][1] = z; af[i][2] = z;
+            }
+#pragma unroll
+          for (int q = 0; q < 6; ++q) {
+            constexpr int ca[6] = {0, 2, 1, 0, 1, 0}, cb[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][ca[q]], bq[kk][j][cb[q]], acc[i][j], 0, 0, 0);
+          }
+          // this set's next use: the same slab of the next tap, or of the next chunk's first tap
+          if (tau < 2) fetch_slab(kk, tau + 1, kk);
+          else if (more) fetch_slab(kk, 0, kk);
+        }
+        if (tau == 0 && more) {
+          stash_img((kc_ + 1) & 1, kc_ + 1);
+          if (kc_ + 2 < kper) fetch_img();
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   unsigned ok_cur = okbits();
   Pref cur = fetch();
   if (IN_BN && in_bn) {
@@ -1009,6 +1132,8 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
     if (more) stash(buf ^ 1, nxt, ok_nxt);
     __syncthreads();
   }
+
+  }      // (!SH)
 
   // ---- epilogue (the expressions of conv_epilogue; every wave owns whole accumulator tiles) ------------------------------------------
   // An accumulator tile leaves the registers through LDS, TRANSPOSED: in the MFMA layout a lane holds one column of 16 rows — 2- or 4-byte
@@ -1245,6 +1370,18 @@ __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 
   if ((int)blockIdx.x < nblk_a) conv_big_body<false, 1, NT, false, 3>(a, blockIdx.x, smem);
   else conv_big_body<false, 1, NT, false, 3>(b, blockIdx.x - nblk_a, smem);
 }
+// ... and for three-tap stride-1 launches: one A image per K chunk for all three taps (MM = 4)
+template <int NT>
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big3s_kernel(ConvArgs p) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, 1, 4)];
+  conv_big_body<false, 1, NT, false, 4>(p, blockIdx.x, smem);
+}
+template <int NT>
+__global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_big3s_pair_kernel(ConvArgs a, ConvArgs b, int nblk_a) {
+  __shared__ __attribute__((aligned(16))) float smem[big_lds_floats(NT, 1, 4)];
+  if ((int)blockIdx.x < nblk_a) conv_big_body<false, 1, NT, false, 4>(a, blockIdx.x, smem);
+  else conv_big_body<false, 1, NT, false, 4>(b, blockIdx.x - nblk_a, smem);
+}
 #define HP_BIG3_DISPATCH(KERNEL, KN, NT, ...)                                                                     \
   do {                                                                                                            \
     if (NT == 2) { if (KN) hipLaunchKernelGGL((KERNEL<true, 2>), __VA_ARGS__); else hipLaunchKernelGGL((KERNEL<false, 2>), __VA_ARGS__); } \
@@ -1324,6 +1461,22 @@ static bool conv_bigfrag_on() {
   }();
   return v;
 }
+// three taps reading rows m - 1, m, m + 1 of ONE source tensor at stride 1: the launches conv_big_body's MM = 4 form serves
+// (the knob: HIPPIE_CONV_BIGSHARED=0 for the A/B)
+static bool conv_shared_taps(const TapMap& t) {
+  static const bool on = [] {
+    const char* k = getenv("HIPPIE_DEBUG_KNOBS");
+    const char* e = (k && k[0] == '1') ? getenv("HIPPIE_CONV_BIGSHARED") : nullptr;
+    return e ? atoi(e) != 0 : true;
+  }();
+  if (!on || t.ntaps != 3 || t.a != 1 || t.sh != 0 || t.Lin != t.Lout || t.P != t.Lout) return false;
+  int seen = 0;
+  for (int j = 0; j < 3; ++j) {
+    if (t.tap_src[j] != 0 || t.tap_o[j] < -1 || t.tap_o[j] > 1) return false;
+    seen |= 1 << (t.tap_o[j] + 1);
+  }
+  return seen == 7;
+}
 static int conv_big_nt(const TapMap& t) {
   const int rows = hp::cdiv(t.M, 128);
   if (t.N >= 128 && rows * hp::cdiv(t.N, 128) >= conv_big_min_tiles()) return 2;
@@ -1355,7 +1508,10 @@ hipError_t hp::launch_conv_pair(const HpOp& opa, const HpOp& opb, void* const* b
       const int na = hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, tn), nb = hp::cdiv(b.t.M, 128) * hp::cdiv(b.t.N, tn);
       const bool kn = opa.flags & 1;
       const int mode = ma > mb ? ma : mb;
-      if ((opa.flags & HP_CONV_BF16X3) && (opa.flags & HP_CONV_WFRAG) && conv_bigfrag_on()) {
+      if ((opa.flags & HP_CONV_BF16X3) && (opa.flags & HP_CONV_WFRAG) && conv_bigfrag_on() && conv_shared_taps(a.t) && conv_shared_taps(b.t)) {
+        if (big == 2) hipLaunchKernelGGL((conv_big3s_pair_kernel<2>), dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+        else          hipLaunchKernelGGL((conv_big3s_pair_kernel<1>), dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
+      } else if ((opa.flags & HP_CONV_BF16X3) && (opa.flags & HP_CONV_WFRAG) && conv_bigfrag_on()) {
         if (big == 2) hipLaunchKernelGGL((conv_big3f_pair_kernel<2>), dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
         else          hipLaunchKernelGGL((conv_big3f_pair_kernel<1>), dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
       } else if (opa.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_pair_kernel, kn, big, dim3(na + nb), dim3(kBigThreads), 0, s, a, b, na);
@@ -1382,7 +1538,10 @@ hipError_t hp::launch_conv_taps(const HpOp& op, void* const* bases, hipStream_t 
       const bool kn = op.flags & 1;
       const int mode = conv_mode(op.flags);
       const dim3 g(hp::cdiv(a.t.M, 128) * hp::cdiv(a.t.N, 64 * big));
-      if ((op.flags & HP_CONV_BF16X3) && (op.flags & HP_CONV_WFRAG) && conv_bigfrag_on()) {
+      if ((op.flags & HP_CONV_BF16X3) && (op.flags & HP_CONV_WFRAG) && conv_bigfrag_on() && conv_shared_taps(a.t)) {
+        if (big == 2) hipLaunchKernelGGL((conv_big3s_kernel<2>), g, dim3(kBigThreads), 0, s, a);
+        else          hipLaunchKernelGGL((conv_big3s_kernel<1>), g, dim3(kBigThreads), 0, s, a);
+      } else if ((op.flags & HP_CONV_BF16X3) && (op.flags & HP_CONV_WFRAG) && conv_bigfrag_on()) {
         if (big == 2) hipLaunchKernelGGL((conv_big3f_kernel<2>), g, dim3(kBigThreads), 0, s, a);
         else          hipLaunchKernelGGL((conv_big3f_kernel<1>), g, dim3(kBigThreads), 0, s, a);
       } else if (op.flags & HP_CONV_BF16X3) HP_BIG3_DISPATCH(conv_big3_kernel, kn, big, g, dim3(kBigThreads), 0, s, a);

@@ -254,7 +254,16 @@ def test_conv_with_ready_made_weight_fragments_is_bit_identical(name, in_bn):
     gpu, cpu = run_both(img, ol.array())
     (o0, s0), (o1, s1) = outs
     T.check(gpu, cpu, o1, tm.out_rows * tm.N, what=name + " out vs interpreter")
-    np.testing.assert_array_equal(view(gpu, o0, np.float32, tm.out_rows * tm.N), view(gpu, o1, np.float32, tm.out_rows * tm.N))
+    if BIG_FORCED:
+        # (the 128-row fragment body runs a three-tap stride-1 launch chunk-outer / tap-inner over one A image per K chunk: the same products,
+        # summed in another order than the staged-weights body's tap-outer loop)
+        a0, a1 = view(gpu, o0, np.float32, tm.out_rows * tm.N).astype(np.float64), view(gpu, o1, np.float32, tm.out_rows * tm.N).astype(np.float64)
+        assert np.abs(a0 - a1).max() <= 3e-6 * np.abs(a0).max()
+    else:
+        np.testing.assert_array_equal(view(gpu, o0, np.float32, tm.out_rows * tm.N), view(gpu, o1, np.float32, tm.out_rows * tm.N))
     n_st = T.R(tm.N) * 2 * tm.N
-    np.testing.assert_allclose(view(gpu, s0, np.float64, n_st).reshape(T.R(tm.N), -1).sum(0), view(gpu, s1, np.float64, n_st).reshape(T.R(tm.N), -1).sum(0),
-                               rtol=1e-12, atol=1e-9)      # (fp64 atomics of identical addends: only the order may differ)
+    st0, st1 = view(gpu, s0, np.float64, n_st).reshape(T.R(tm.N), -1).sum(0), view(gpu, s1, np.float64, n_st).reshape(T.R(tm.N), -1).sum(0)
+    if BIG_FORCED:
+        assert np.abs(st0 - st1).max() <= 1e-5 * np.abs(st0).max()      # (sums of outputs that agree to fp32 rounding)
+    else:
+        np.testing.assert_allclose(st0, st1, rtol=1e-12, atol=1e-9)      # (fp64 atomics of identical addends: only the order may differ)
