@@ -1023,7 +1023,7 @@ __device__ __forceinline__ void conv_big_body(const ConvArgs& p, const int bid, 
           if (tau < 2) fetch_slab(kk, tau + 1, kk);
           else if (more) fetch_slab(kk, 0, kk);
         }
-        if (tau == 0 && more) {
+        if (tau == 1 && more) {
           stash_img((kc_ + 1) & 1, kc_ + 1);
           if (kc_ + 2 < kper) fetch_img();
         }
